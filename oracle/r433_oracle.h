@@ -1,0 +1,181 @@
+/* r433_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of rtl_433's IQ -> pulse package -> bitbuffer hot
+ * path, written from the algorithm (not copied) and pinned against the real
+ * reference built into oracle/_ref/ (see oracle/Makefile, tests/test_oracle_vs_ref.py).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library; the product (rtl_433_amd/) never does.
+ *
+ * Every function names the reference file:line whose behaviour it follows
+ * (paths relative to the reference tree root).
+ */
+#ifndef R433_ORACLE_H_
+#define R433_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+#include "r433_records.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------- baseband (reference src/baseband.c) ---------- */
+
+/* src/baseband.c:36-45   squared-magnitude envelope of cu8; returns wrapped u32 sum */
+uint32_t orc_envelope_cu8(uint8_t const *iq, uint16_t *env, uint32_t n);
+/* src/baseband.c:65-79   122/51 magnitude estimate of cu8 */
+uint32_t orc_magest_cu8(uint8_t const *iq, uint16_t *env, uint32_t n);
+/* src/baseband.c:96-110  122/51 magnitude estimate of cs16 */
+uint32_t orc_magest_cs16(int16_t const *iq, uint16_t *env, uint32_t n);
+/* src/baseband.c:44,78 + include/baseband.h:36-37  frame level in dB from the sum */
+float orc_level_db(uint32_t sum, uint32_t n, int is_magnitude);
+
+typedef struct orc_lpf_state {
+    int16_t y_prev; /* filter_state_t.y[0] */
+    int16_t x_prev; /* filter_state_t.x[0] (u16 sample stored in an s16 slot) */
+} orc_lpf_state;
+
+/* src/baseband.c:145-169  first-order envelope low-pass */
+void orc_lowpass(orc_lpf_state *st, uint16_t const *x, int16_t *y, uint32_t n);
+
+typedef struct orc_fm_state {
+    int32_t xr, xi, xf, yf; /* demodfm_state_t.xr/xi/xf/yf */
+    uint32_t rate;          /* rate the coefficients were derived for */
+    int32_t a16, b16;       /* alp_16[1], blp_16[0] */
+    int64_t a32, b32;       /* alp_32[1], blp_32[0] */
+} orc_fm_state;
+
+/* src/baseband.c:217-232 / 310-325  coefficient derivation (host double math) */
+void orc_fm_coeffs(float low_pass, uint32_t rate, int32_t *a16, int32_t *b16, int64_t *a32, int64_t *b32);
+/* src/baseband.c:210-272  FM discriminator + low-pass, cu8 */
+void orc_fm_cu8(orc_fm_state *st, uint8_t const *iq, int16_t *out, uint32_t n, uint32_t rate, float low_pass);
+/* src/baseband.c:303-366  FM discriminator + low-pass, cs16 */
+void orc_fm_cs16(orc_fm_state *st, int16_t const *iq, int16_t *out, uint32_t n, uint32_t rate, float low_pass);
+
+/* ---------- pulse detector (reference src/pulse_detect.c, src/pulse_detect_fsk.c) ---------- */
+
+typedef struct orc_pulses {
+    uint64_t offset;
+    uint32_t sample_rate;
+    uint32_t start_ago;
+    uint32_t end_ago;
+    uint32_t num;
+    int32_t pulse[R433_PD_MAX_PULSES];
+    int32_t gap[R433_PD_MAX_PULSES];
+    int32_t ook_low, ook_high;
+    int32_t fsk_f1, fsk_f2;
+} orc_pulses;
+
+typedef struct orc_fsk_state {
+    uint32_t run;  /* fsk_pulse_length */
+    int32_t state; /* 0 init, 1 high, 2 low, 3 error */
+    int32_t f1, f2;
+    int16_t vmax, vmin;
+    int32_t skip;
+} orc_fsk_state;
+
+typedef struct orc_levels {
+    int32_t use_mag;
+    int32_t fixed_high; /* 0 = automatic */
+    int32_t min_high;
+    int32_t ratio;
+    int32_t max_high; /* OOK_MAX_HIGH_LEVEL */
+} orc_levels;
+
+typedef struct orc_detector {
+    orc_levels lv;
+    int32_t state; /* 0 idle, 1 pulse, 2 gap-start, 3 gap */
+    int32_t run;   /* pulse_length */
+    int32_t max_pulse;
+    int32_t pos;   /* data_counter */
+    int32_t lead_in;
+    int32_t low, high;
+    orc_fsk_state fsk;
+} orc_detector;
+
+/* include/baseband.h:44-47 + src/pulse_detect.c:86-105  dB levels -> integer levels */
+void orc_levels_from_db(orc_levels *lv, int use_mag, float fixed_db, float min_db, float ratio_db);
+/* src/pulse_detect.c:74-84 */
+void orc_detector_reset(orc_detector *d);
+/* src/pulse_detect.c:199-483; returns 0, R433_PKG_OOK or R433_PKG_FSK */
+int orc_detect_package(orc_detector *d, int16_t const *am, int16_t const *fm, int len, uint32_t rate,
+        uint64_t sample_offset, orc_pulses *ook, orc_pulses *fsk, unsigned fpdm);
+
+/* ---------- slicers + bitbuffer (reference src/pulse_slicer.c, src/bitbuffer.c:17-133) ---------- */
+
+typedef struct orc_bitbuf {
+    uint16_t num_rows, free_row;
+    uint16_t bits[R433_BB_ROWS];
+    uint16_t syncs[R433_BB_ROWS];
+    uint16_t extent[R433_BB_ROWS]; /* oracle bookkeeping: max bits ever held by the row */
+    uint8_t bb[R433_BB_ROWS * R433_BB_COLS];
+} orc_bitbuf;
+
+void orc_bb_clear(orc_bitbuf *b);
+void orc_bb_add_bit(orc_bitbuf *b, int bit);
+void orc_bb_add_row(orc_bitbuf *b);
+void orc_bb_add_sync(orc_bitbuf *b);
+
+/* called once per account_event; returns what decode_fn would return */
+typedef int (*orc_event_fn)(void *ctx, unsigned dev, unsigned ordinal, orc_bitbuf const *bits);
+
+/* dispatch on modulation like src/r_api.c:438-550 does for ONE device; returns number of
+ * account_event calls (NOT decode successes) via *n_calls, and summed positive returns as result */
+int orc_slice(orc_pulses const *p, r433_dev_timing const *t, unsigned dev, int is_fsk_package,
+        orc_event_fn fn, void *ctx, unsigned *n_calls);
+
+/* ---------- whole flow (reference src/r_flow.c:104-340 for file input) ---------- */
+
+typedef struct orc_flow_cfg {
+    uint32_t sample_size;   /* 2 = cu8, 4 = cs16 */
+    uint32_t samp_rate;
+    uint32_t frame_samples; /* 131072 for cu8, 65536 for cs16 (reference include/rtl_433.h:17) */
+    uint32_t fpdm;          /* 0 classic, 1 minmax (resolved) */
+    uint32_t use_mag_est;
+    uint32_t enable_fm;     /* enable_FM_demod */
+    float fm_low_pass;      /* 0 = default */
+    float level_limit_db;   /* -Y level, 0 = auto */
+    float min_level_db;     /* -Y minlevel, default -12.1442 */
+    float min_snr_db;       /* -Y minsnr, default 9 */
+    float auto_level;       /* -Y autolevel > 0 */
+} orc_flow_cfg;
+
+typedef struct orc_blob {
+    uint8_t *data;
+    size_t len, cap;
+    uint32_t count;
+} orc_blob;
+
+typedef struct orc_flow_out {
+    orc_blob packages; /* r433_pkg_rec stream in detection order */
+    orc_blob events;   /* r433_evt_rec stream, (pkg, dev, ordinal) order */
+    uint16_t *env;     /* optional taps, caller allocated, n samples each */
+    int16_t *am;
+    int16_t *fm;
+    uint32_t *frame_sums; /* optional, one u32 per frame */
+} orc_flow_out;
+
+void orc_blob_free(orc_blob *b);
+
+/* Runs one capture through envelope/LPF/FM/detector in reference frames, then slices every
+ * package with every device row.  stream_index is copied into the package records; pkg_base is
+ * the canonical index of this stream's first package.  Returns number of packages, <0 on error. */
+int orc_flow_run(orc_flow_cfg const *cfg, void const *iq, size_t n_bytes, r433_dev_timing const *devs,
+        unsigned n_devs, uint32_t stream_index, uint32_t pkg_base, orc_flow_out *out);
+
+/* Slices already-detected packages (a r433_pkg_rec stream) with every device row. */
+int orc_slice_packages(uint8_t const *pkg_blob, size_t pkg_len, r433_dev_timing const *devs, unsigned n_devs,
+        uint32_t pkg_base, orc_blob *events);
+
+/* Canonical form of an event stream: per row trailing zero bytes trimmed (so that a recorder that
+ * only sees a reference bitbuffer_t produces the same bytes).  Returns new length (in place). */
+size_t orc_events_normalize(uint8_t *evt_blob, size_t len);
+/* FNV-1a 64 over an event stream after inflating every event to the reference bitbuffer image
+ * {num_rows, free_row, bits[50], syncs[50], bb[50][128]} -- the "checksum of checksums". */
+uint64_t orc_events_digest(uint8_t const *evt_blob, size_t len, uint32_t *n_events);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* R433_ORACLE_H_ */
