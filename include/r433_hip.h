@@ -1,0 +1,132 @@
+/* r433_hip.h -- C ABI of librtl433hip.so: the MI355X (gfx950) implementation of rtl_433's
+ * IQ -> pulse package -> bitbuffer -> decoder fan-out path.
+ *
+ * Plain C, pointers and sizes only.  Device pointers are ordinary HIP device addresses (e.g.
+ * torch.Tensor.data_ptr()); `stream` arguments are a hipStream_t passed as void* (NULL = default
+ * stream).  Every entry point names the reference interface it stands in for (paths relative to the
+ * reference tree).  All functions return 0 / a count on success and a negative R433_E* code on
+ * failure; r433_last_error() gives the text.  Nothing here falls back to a CPU implementation: without
+ * a usable HIP device every compute call fails with R433_ENODEV.
+ */
+#ifndef R433_HIP_H_
+#define R433_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "r433_abi.h"
+#include "r433_records.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define R433_OK 0
+#define R433_EINVAL (-1)
+#define R433_ENODEV (-2)
+#define R433_EHIP (-3)
+#define R433_ENOMEM (-4)
+#define R433_EOVERFLOW (-5)
+#define R433_EDECODER (-6) /* a decode_fn returned an invalid code (reference src/pulse_slicer.c:44-47 exits) */
+
+int r433_version(void);
+char const *r433_last_error(void);
+/* number of visible HIP devices, or R433_ENODEV */
+int r433_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Flow configuration: the fields of struct dm_state / r_cfg that parameterise the hot path
+ * (reference include/r_private.h:19-86, set per frame in src/rtl_433.c:1094-1120).
+ */
+typedef struct r433_flow_cfg {
+    uint32_t sample_size;   /* 2 = cu8, 4 = cs16 (dm_state.sample_size) */
+    uint32_t samp_rate;     /* dm_state.samp_rate */
+    uint32_t frame_samples; /* samples per push_sdr_flow call; 0 = file default 262144 / sample_size */
+    uint32_t fpdm;          /* resolved FSK detector: 0 classic, 1 minmax (src/rtl_433.c:1094-1102) */
+    uint32_t use_mag_est;   /* -Y magest */
+    uint32_t enable_fm;     /* dm_state.enable_FM_demod; 0 reproduces the buf.fm/buf.temp aliasing */
+    float fm_low_pass;      /* -Y filter, 0 = 0.1 (classic) / 0.2 (minmax), src/r_flow.c:204 */
+    float level_limit_db;   /* -Y level, 0 = adaptive */
+    float min_level_db;     /* -Y minlevel, default -12.1442 */
+    float min_snr_db;       /* -Y minsnr, default 9.0 */
+    float auto_level;       /* -Y autolevel > 0 */
+    uint32_t center_frequency; /* only for reporting (freq fields of calc_rssi_snr) */
+} r433_flow_cfg;
+
+void r433_flow_cfg_default(r433_flow_cfg *cfg, uint32_t sample_size, uint32_t samp_rate);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batch engine: N independent captures ("-r a.cu8 -r b.cu8 ..." with reset_sdr_flow between,
+ * reference src/rtl_433.c:1703-1854) decoded in one go.  Stands in for push_sdr_flow /
+ * flush_sdr_flow / reset_sdr_flow (include/r_flow.h:19-23) + run_ook_demods / run_fsk_demods
+ * (include/r_api.h:50-52) over a whole file list.
+ */
+typedef struct r433_batch r433_batch;
+
+/* devs: timing rows of the registered r_devices in registration order (may be 0 rows: detection only) */
+r433_batch *r433_batch_create(r433_flow_cfg const *cfg, r433_dev_timing const *devs, uint32_t n_devs);
+void r433_batch_destroy(r433_batch *b);
+
+/* Decode n_streams captures resident in device memory.  Capture s starts at d_iq + s*stride_bytes
+ * (stride and base 16-byte aligned) and holds stream_bytes[s] bytes (host array; NULL = all
+ * stride_bytes).  Runs detection and the slicer fan-out, leaves package and event records in device
+ * memory and mirrors them to pinned host memory.  Returns the number of packages. */
+int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint32_t const *stream_bytes,
+        uint32_t n_streams, void *stream);
+
+/* Host views of the last run (valid until the next run/destroy). */
+int r433_batch_packages(r433_batch *b, uint8_t const **blob, size_t *len, uint32_t *count);
+int r433_batch_events(r433_batch *b, uint8_t const **blob, size_t *len, uint32_t *count);
+/* per (capture, frame) wrapped u32 envelope sums -> avg_db (reference src/baseband.c:39-44) */
+int r433_batch_frame_sums(r433_batch *b, uint32_t const **sums, uint32_t *frames_cap);
+/* device-side record arenas of the last run (for consumers that stay on the GPU) */
+int r433_batch_device_events(r433_batch *b, void const **d_events, size_t *len);
+
+/* Optional parity taps: per-sample envelope (u16), low-passed envelope (s16) and FM (s16) of every
+ * capture, written to device buffers of n_streams*tap_stride samples.  Pass NULLs to disable. */
+int r433_batch_set_taps(r433_batch *b, void *d_env, void *d_am, void *d_fm, uint64_t tap_stride);
+
+/* Kernel timing of the last run measured with HIP events on the caller's stream (ms). */
+typedef struct r433_batch_timing {
+    float detect_ms;  /* k_stream: IQ -> packages */
+    float dir_ms;     /* package directory */
+    float count_ms;   /* slicer pass 1 */
+    float scan_ms;
+    float write_ms;   /* slicer pass 2 */
+    float d2h_ms;     /* record copies */
+    float total_ms;
+} r433_batch_timing;
+int r433_batch_set_profiling(r433_batch *b, int on);
+int r433_batch_get_timing(r433_batch *b, r433_batch_timing *t);
+
+/* ------------------------------------------------------------------------------------------------
+ * Decoder dispatch: replays the events of the last run into the registered plugins exactly as
+ * run_ook_demods / run_fsk_demods + account_event would (reference src/r_api.c:438-550,
+ * src/pulse_slicer.c:26-66): packages in detection order, priority levels ascending until one
+ * produced an event, devices in registration order, events in pulse order.  Each event is inflated
+ * into a reference-layout bitbuffer_t and handed to r_device.decode_fn on the calling thread;
+ * decode_events / decode_ok / decode_messages / decode_fails are updated like the reference does.
+ *
+ * devices[i] must correspond to timing row i given at r433_batch_create.
+ * pkg_cb (may be NULL) is called before the decoders of each package with the inflated
+ * pulse_data_t (rssi/snr/freq filled as calc_rssi_snr does, reference src/r_flow.c:35-64).
+ * Returns the number of successful decode events (sum of positive decode_fn returns). */
+typedef void (*r433_package_fn)(void *user, uint32_t stream, uint32_t type, r433_pulse_data const *pulses);
+int r433_batch_dispatch(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices, r433_package_fn pkg_cb,
+        void *user);
+
+/* ------------------------------------------------------------------------------------------------
+ * Function-level seam on device buffers: the prototypes of include/baseband.h with device pointers.
+ */
+/* envelope_detect (src/baseband.c:36-45): d_sum receives the wrapped u32 sum of the outputs */
+int r433_envelope_detect(void const *d_iq, void *d_env, uint32_t n, uint32_t *d_sum, void *stream);
+/* magnitude_est_cu8 (src/baseband.c:65-79) / magnitude_est_cs16 (:96-110) */
+int r433_magnitude_est_cu8(void const *d_iq, void *d_env, uint32_t n, uint32_t *d_sum, void *stream);
+int r433_magnitude_est_cs16(void const *d_iq, void *d_env, uint32_t n, uint32_t *d_sum, void *stream);
+/* AMP_TO_DB / MAG_TO_DB of a frame sum (include/baseband.h:36-37, src/baseband.c:44,78) */
+float r433_level_db(uint32_t sum, uint32_t n, int is_magnitude);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* R433_HIP_H_ */

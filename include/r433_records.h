@@ -27,8 +27,9 @@ extern "C" {
 #define R433_PKG_FSK 2 /* PULSE_DATA_FSK */
 #define R433_RET_FLUSH 0xffffffffu
 
-/* One detected pulse package.  Followed by int32 pulse[num_pulses] then
- * int32 gap[num_pulses] (sample counts). total_bytes = 64 + 8*num_pulses. */
+/* One detected pulse package.  Followed by num_pulses pairs {int32 pulse, int32 gap}
+ * (sample counts), i.e. pulse_data_t.pulse[i] / .gap[i] interleaved.
+ * total_bytes = 64 + 8*num_pulses. */
 typedef struct r433_pkg_rec {
     uint32_t total_bytes; /* size of this record incl. pulse/gap arrays */
     uint32_t stream;      /* index of the capture in the batch */

@@ -203,7 +203,7 @@ def parse_packages(blob):
         body = np.frombuffer(mv[at + PKG_HDR:at + PKG_HDR + 8 * npul], dtype=np.int32)
         out.append(dict(stream=int(h[1]), type=int(h[2]), num=npul, frame=int(h[4]), ret_pos=int(h[5]),
                         offset=offset, start_ago=int(h[8]), end_ago=int(h[9]), low=int(ints[0]), high=int(ints[1]),
-                        f1=int(ints[2]), f2=int(ints[3]), rate=int(h[14]), pulse=body[:npul].copy(), gap=body[npul:].copy()))
+                        f1=int(ints[2]), f2=int(ints[3]), rate=int(h[14]), pulse=body[0::2].copy(), gap=body[1::2].copy()))
         at += total
     return out
 

@@ -1186,8 +1186,11 @@ static void put_package(orc_blob *b, orc_pulses const *p, uint32_t stream, int t
     h.fsk_f2 = p->fsk_f2;
     h.sample_rate = p->sample_rate;
     memcpy(b->data + b->len, &h, sizeof(h));
-    memcpy(b->data + b->len + sizeof(h), p->pulse, 4u * p->num);
-    memcpy(b->data + b->len + sizeof(h) + 4u * p->num, p->gap, 4u * p->num);
+    int32_t *pairs = (int32_t *)(b->data + b->len + sizeof(h));
+    for (uint32_t i = 0; i < p->num; ++i) {
+        pairs[2 * i] = p->pulse[i];
+        pairs[2 * i + 1] = p->gap[i];
+    }
     b->len += sz;
     b->count += 1;
 }
@@ -1237,8 +1240,10 @@ static void record_to_pulses(uint8_t const *rec, orc_pulses *p)
     p->ook_high = h.ook_high;
     p->fsk_f1 = h.fsk_f1;
     p->fsk_f2 = h.fsk_f2;
-    memcpy(p->pulse, rec + sizeof(h), 4u * h.num_pulses);
-    memcpy(p->gap, rec + sizeof(h) + 4u * h.num_pulses, 4u * h.num_pulses);
+    for (uint32_t i = 0; i < h.num_pulses && i < R433_PD_MAX_PULSES; ++i) {
+        memcpy(&p->pulse[i], rec + sizeof(h) + 8u * i, 4);
+        memcpy(&p->gap[i], rec + sizeof(h) + 8u * i + 4, 4);
+    }
 }
 
 int orc_slice_packages(uint8_t const *pkg_blob, size_t pkg_len, r433_dev_timing const *devs, unsigned n_devs,

@@ -110,8 +110,10 @@ static void record_package(pulse_data_t const *p, int type)
         r.fsk_f2 = p->fsk_f2_est;
         r.sample_rate = p->sample_rate;
         blob_put(&h->packages, &r, sizeof(r));
-        blob_put(&h->packages, p->pulse, 4u * p->num_pulses);
-        blob_put(&h->packages, p->gap, 4u * p->num_pulses);
+        for (unsigned i = 0; i < p->num_pulses; ++i) {
+            int32_t pair[2] = {p->pulse[i], p->gap[i]};
+            blob_put(&h->packages, pair, 8);
+        }
         h->packages.count++;
     }
     for (void **it = h->cfg->demod->r_devs.elems; it && *it; ++it)

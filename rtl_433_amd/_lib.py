@@ -1,0 +1,102 @@
+"""ctypes loader for librtl433hip.so.  Fails loudly: there is no Python/CPU fallback for the hot path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "librtl433hip.so")
+
+
+class FlowCfg(C.Structure):
+    """r433_flow_cfg (include/r433_hip.h)."""
+    _fields_ = [("sample_size", C.c_uint32), ("samp_rate", C.c_uint32), ("frame_samples", C.c_uint32),
+                ("fpdm", C.c_uint32), ("use_mag_est", C.c_uint32), ("enable_fm", C.c_uint32),
+                ("fm_low_pass", C.c_float), ("level_limit_db", C.c_float), ("min_level_db", C.c_float),
+                ("min_snr_db", C.c_float), ("auto_level", C.c_float), ("center_frequency", C.c_uint32)]
+
+
+class BatchTiming(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("detect_ms", "dir_ms", "count_ms", "scan_ms", "write_ms", "d2h_ms", "total_ms")]
+
+
+class RDevice(C.Structure):
+    """r433_r_device == the reference's r_device (include/r433_abi.h)."""
+
+
+DECODE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(RDevice), C.c_void_p)
+RDevice._fields_ = [
+    ("protocol_num", C.c_uint), ("name", C.c_char_p), ("modulation", C.c_uint),
+    ("short_width", C.c_float), ("long_width", C.c_float), ("reset_limit", C.c_float),
+    ("gap_limit", C.c_float), ("sync_width", C.c_float), ("tolerance", C.c_float),
+    ("decode_fn", C.c_void_p), ("create_fn", C.c_void_p), ("priority", C.c_uint), ("disabled", C.c_uint),
+    ("fields", C.c_void_p), ("verbose", C.c_int), ("verbose_bits", C.c_int), ("log_fn", C.c_void_p),
+    ("output_fn", C.c_void_p), ("decode_events", C.c_uint), ("decode_ok", C.c_uint),
+    ("decode_messages", C.c_uint), ("decode_fails", C.c_uint * 5), ("decode_ctx", C.c_void_p),
+    ("output_ctx", C.c_void_p)]
+
+PACKAGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p)
+
+_lib = None
+
+EXPORTS = [
+    "r433_version", "r433_last_error", "r433_device_count", "r433_flow_cfg_default", "r433_level_db",
+    "r433_batch_create", "r433_batch_destroy", "r433_batch_run", "r433_batch_packages", "r433_batch_events",
+    "r433_batch_frame_sums", "r433_batch_device_events", "r433_batch_set_taps", "r433_batch_set_profiling",
+    "r433_batch_get_timing", "r433_batch_dispatch", "r433_envelope_detect", "r433_magnitude_est_cu8",
+    "r433_magnitude_est_cs16",
+]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -m rtl_433_amd.build` (hipcc, gfx950). "
+                           "rtl_433_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.r433_version.restype = C.c_int
+    L.r433_last_error.restype = C.c_char_p
+    L.r433_device_count.restype = C.c_int
+    L.r433_flow_cfg_default.restype = None
+    L.r433_flow_cfg_default.argtypes = [C.POINTER(FlowCfg), C.c_uint32, C.c_uint32]
+    L.r433_level_db.restype = C.c_float
+    L.r433_level_db.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
+    L.r433_batch_create.restype = vp
+    L.r433_batch_create.argtypes = [C.POINTER(FlowCfg), vp, C.c_uint32]
+    L.r433_batch_destroy.restype = None
+    L.r433_batch_destroy.argtypes = [vp]
+    L.r433_batch_run.restype = C.c_int
+    L.r433_batch_run.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp]
+    for f in (L.r433_batch_packages, L.r433_batch_events):
+        f.restype = C.c_int
+        f.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]
+    L.r433_batch_frame_sums.restype = C.c_int
+    L.r433_batch_frame_sums.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint32)]
+    L.r433_batch_device_events.restype = C.c_int
+    L.r433_batch_device_events.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.r433_batch_set_taps.restype = C.c_int
+    L.r433_batch_set_taps.argtypes = [vp, vp, vp, vp, C.c_uint64]
+    L.r433_batch_set_profiling.restype = C.c_int
+    L.r433_batch_set_profiling.argtypes = [vp, C.c_int]
+    L.r433_batch_get_timing.restype = C.c_int
+    L.r433_batch_get_timing.argtypes = [vp, C.POINTER(BatchTiming)]
+    L.r433_batch_dispatch.restype = C.c_int
+    L.r433_batch_dispatch.argtypes = [vp, vp, C.c_uint32, vp, vp]
+    for f in (L.r433_envelope_detect, L.r433_magnitude_est_cu8, L.r433_magnitude_est_cs16):
+        f.restype = C.c_int
+        f.argtypes = [vp, vp, C.c_uint32, vp, vp]
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().r433_last_error().decode(errors="replace")
+
+
+def check(rc, what):
+    if rc < 0:
+        raise RuntimeError(f"{what} failed ({rc}): {last_error()}")
+    return rc

@@ -1,0 +1,86 @@
+// baseband_kernels.hip -- the stateless baseband maps as stand-alone, HBM-bound kernels.
+//
+// envelope_detect / magnitude_est_cu8 / magnitude_est_cs16 (reference src/baseband.c:36-45,
+// 65-79, 96-110): one 16-byte load per lane (8 cu8 or 4 cs16 samples), one 16/8-byte store,
+// per-wave shuffle reduction and a single atomicAdd per block for the frame sum (the reference's
+// uint32 accumulator wraps; addition mod 2^32 is associative, so the parallel sum is exact).
+#include "dsp_device.hpp"
+#include "r433_internal.hpp"
+
+namespace r433 {
+
+namespace {
+
+template <int KIND> __device__ __forceinline__ uint32_t env_one(uint32_t pr)
+{
+    if (KIND == ENV_AMP_CU8)
+        return env_amp_cu8(pr & 0xffu, (pr >> 8) & 0xffu);
+    if (KIND == ENV_MAG_CU8)
+        return env_mag_cu8(pr & 0xffu, (pr >> 8) & 0xffu);
+    return env_mag_cs16((int)(int16_t)(pr & 0xffffu), (int)(int16_t)(pr >> 16));
+}
+
+template <int KIND> __global__ __launch_bounds__(256) void k_envelope(uint8_t const *iq, uint16_t *env, uint32_t n,
+        uint32_t *sum)
+{
+    constexpr int SS = KIND == ENV_MAG_CS16 ? 4 : 2;
+    constexpr int SPV = 16 / SS; // samples per 16-byte vector
+    uint32_t const n_vec = n / SPV;
+    uint32_t acc = 0;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n_vec; v += gridDim.x * blockDim.x) {
+        uint4 w = ((uint4 const *)iq)[v];
+        if (SS == 2) {
+            uint32_t e0 = env_one<KIND>(w.x & 0xffffu), e1 = env_one<KIND>(w.x >> 16);
+            uint32_t e2 = env_one<KIND>(w.y & 0xffffu), e3 = env_one<KIND>(w.y >> 16);
+            uint32_t e4 = env_one<KIND>(w.z & 0xffffu), e5 = env_one<KIND>(w.z >> 16);
+            uint32_t e6 = env_one<KIND>(w.w & 0xffffu), e7 = env_one<KIND>(w.w >> 16);
+            acc += e0 + e1 + e2 + e3 + e4 + e5 + e6 + e7;
+            ((uint4 *)env)[v] = make_uint4(e0 | (e1 << 16), e2 | (e3 << 16), e4 | (e5 << 16), e6 | (e7 << 16));
+        }
+        else {
+            uint32_t e0 = env_one<KIND>(w.x), e1 = env_one<KIND>(w.y), e2 = env_one<KIND>(w.z), e3 = env_one<KIND>(w.w);
+            acc += e0 + e1 + e2 + e3;
+            ((uint2 *)env)[v] = make_uint2(e0 | (e1 << 16), e2 | (e3 << 16));
+        }
+    }
+    // ragged tail (< one vector), handled by the first lanes of block 0
+    if (blockIdx.x == 0) {
+        uint32_t i = n_vec * SPV + threadIdx.x;
+        if (i < n) {
+            uint32_t pr = SS == 2 ? ((uint16_t const *)iq)[i] : ((uint32_t const *)iq)[i];
+            uint32_t e = env_one<KIND>(pr);
+            env[i] = (uint16_t)e;
+            acc += e;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1)
+        acc += (uint32_t)__shfl_down((int)acc, o, 64);
+    __shared__ uint32_t part[4];
+    if ((threadIdx.x & 63) == 0)
+        part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && sum)
+        atomicAdd(sum, part[0] + part[1] + part[2] + part[3]);
+}
+
+} // namespace
+
+void launch_envelope(int kind, void const *d_iq, uint16_t *d_env, uint32_t n, uint32_t *d_sum, hipStream_t st)
+{
+    uint32_t spv = kind == ENV_MAG_CS16 ? 4 : 8;
+    uint32_t vecs = n / spv;
+    uint32_t blocks = (vecs + 255) / 256;
+    if (blocks < 1)
+        blocks = 1;
+    if (blocks > 4096) // 256 CUs x 8 blocks + grid stride, cdna guide G11
+        blocks = 4096;
+    uint8_t const *iq = (uint8_t const *)d_iq;
+    if (kind == ENV_AMP_CU8)
+        hipLaunchKernelGGL(k_envelope<ENV_AMP_CU8>, dim3(blocks), dim3(256), 0, st, iq, d_env, n, d_sum);
+    else if (kind == ENV_MAG_CU8)
+        hipLaunchKernelGGL(k_envelope<ENV_MAG_CU8>, dim3(blocks), dim3(256), 0, st, iq, d_env, n, d_sum);
+    else
+        hipLaunchKernelGGL(k_envelope<ENV_MAG_CS16>, dim3(blocks), dim3(256), 0, st, iq, d_env, n, d_sum);
+}
+
+} // namespace r433

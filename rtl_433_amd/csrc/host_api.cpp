@@ -1,0 +1,840 @@
+// host_api.cpp -- the C ABI of librtl433hip.so (include/r433_hip.h): buffer management, kernel
+// sequencing, record mirroring and the host-side decoder dispatch that mirrors the reference's
+// run_ook_demods / run_fsk_demods + account_event (src/r_api.c:438-550, src/pulse_slicer.c:26-66).
+//
+// There is no CPU implementation of the hot path in here: if HIP is unusable every compute entry
+// point fails with R433_ENODEV.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "r433_hip.h"
+#include "r433_internal.hpp"
+
+using namespace r433;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, char const *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess)                                                                                          \
+            return fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? R433_ENODEV : R433_EHIP, "%s: %s",   \
+                    #expr, hipGetErrorString(e_));                                                                     \
+    } while (0)
+
+// ---- host-side scalar math the reference also does on the host (same libm) ----
+
+// DB_TO_AMP / DB_TO_MAG / DB_TO_AMP_F / DB_TO_MAG_F, reference include/baseband.h:44-47;
+// pulse_detect_set_levels, src/pulse_detect.c:86-105; OOK_MAX_HIGH_LEVEL, :24
+void levels_from_db(DetCfg &c, int use_mag, float fixed_db, float min_db, float ratio_db)
+{
+    if (use_mag) {
+        c.fixed_high = fixed_db < 0.0 ? (int)powf(10, (fixed_db + 84.2884f) / 20.0f) : 0;
+        c.min_high = (int)powf(10, (min_db + 84.2884f) / 20.0f);
+        c.ratio = (int)(0.5 + powf(10, ratio_db / 20.0f));
+    }
+    else {
+        c.fixed_high = fixed_db < 0.0 ? (int)powf(10, (fixed_db + 42.1442f) / 10.0f) : 0;
+        c.min_high = (int)powf(10, (min_db + 42.1442f) / 10.0f);
+        c.ratio = (int)(0.5 + powf(10, ratio_db / 10.0f));
+    }
+    c.max_high = (int)powf(10, (0 + 42.1442f) / 10.0f);
+}
+
+// coefficient derivation of baseband_demod_FM(_cs16), reference src/baseband.c:217-232, 310-325
+void fm_coeffs(float low_pass, uint32_t rate, int &a16, int &b16, long long &a32, long long &b32)
+{
+    if (low_pass > 1e4f)
+        low_pass = low_pass / rate;
+    else if (low_pass >= 1.0f)
+        low_pass = 1e6f / low_pass / rate;
+    double ita = 1.0 / tan(M_PI_2 * low_pass);
+    double g16 = 1.0 / (1.0 + ita) / 2;
+    double g32 = 1.0 / (1.0 + ita);
+    a16 = (int)((ita - 1.0) * g16 * 32768);
+    b16 = (int)(g16 * 32768);
+    a32 = (int)((ita - 1.0) * g32 * 1073741824);
+    b32 = (int)(g32 * 1073741824);
+}
+
+// integer timing of a device at a sample rate, reference src/pulse_slicer.c:70-99 (same float ops)
+DevRow resolve_timing(r433_dev_timing const &d, uint32_t rate, int orig)
+{
+    DevRow r;
+    memset(&r, 0, sizeof(r));
+    volatile float us = rate / 1.0e6f;
+    r.modulation = (int)d.modulation;
+    r.orig = orig;
+    r.is_fsk = d.modulation >= 16;
+    volatile float v;
+    v = d.short_width * us;
+    r.s_short = (int)v;
+    v = d.long_width * us;
+    r.s_long = (int)v;
+    v = d.reset_limit * us;
+    r.s_reset = (int)v;
+    v = d.gap_limit * us;
+    r.s_gap = (int)v;
+    v = d.sync_width * us;
+    r.s_sync = (int)v;
+    v = d.tolerance * us;
+    r.s_tol = (int)v;
+    bool ok = !((d.short_width > 0 && r.s_short <= 0) || (d.long_width > 0 && r.s_long <= 0)
+            || (d.reset_limit > 0 && r.s_reset <= 0));
+    if (d.modulation != 13) // pulse_slicer_rzi only checks short/long/reset, src/pulse_slicer.c:876-882
+        ok = ok
+                && !((d.gap_limit > 0 && r.s_gap <= 0) || (d.sync_width > 0 && r.s_sync <= 0)
+                        || (d.tolerance > 0 && r.s_tol <= 0));
+    volatile float ps = d.short_width * us, pl = d.long_width * us;
+    r.f_short = d.short_width > 0.0f ? 1.0f / ps : 0;
+    r.f_long = d.long_width > 0.0f ? 1.0f / pl : 0;
+    switch (d.modulation) {
+    case 3: case 4: case 5: case 6: case 8: case 9: case 10: case 11: case 12: case 13: case 16: case 17: case 18:
+        break;
+    default:
+        ok = false; // "Unknown modulation" in the reference's switch
+    }
+    r.valid = ok ? 1 : 0;
+    return r;
+}
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0; // elements
+    int ensure(size_t n)
+    {
+        if (n <= cap)
+            return 0;
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 4 + 16;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e != hipSuccess)
+            return fail(R433_ENOMEM, "hipMalloc(%zu bytes): %s", want * sizeof(T), hipGetErrorString(e));
+        cap = want;
+        return 0;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+template <typename T> struct PinBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n)
+    {
+        if (n <= cap)
+            return 0;
+        if (p)
+            (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 4 + 16;
+        hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess)
+            return fail(R433_ENOMEM, "hipHostMalloc(%zu bytes): %s", want * sizeof(T), hipGetErrorString(e));
+        cap = want;
+        return 0;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+} // namespace
+
+struct r433_batch {
+    r433_flow_cfg cfg;
+    DetCfg det;
+    int a16 = 0, b16 = 0;
+    long long a32 = 0, b32 = 0;
+    std::vector<r433_dev_timing> timing; // registration order
+    std::vector<DevRow> rows;            // sorted for the fan-out
+    std::vector<uint32_t> prio_levels;   // distinct priorities ascending
+
+    DevBuf<DevRow> d_rows;
+    DevBuf<uint8_t> d_arena;
+    DevBuf<int2> d_ring;
+    DevBuf<StreamState> d_state;
+    DevBuf<uint32_t> d_frame_sums, d_stream_bytes, d_pkg_base, d_scal;
+    DevBuf<uint32_t> d_dir_stream, d_dir_off, d_rec_bytes, d_rec_off, d_sizes, d_pkg_bytes, d_pkg_off;
+    DevBuf<uint8_t> d_pkg_blob, d_events;
+    PinBuf<uint32_t> h_scal, h_frame_sums;
+    PinBuf<uint8_t> h_pkg_blob, h_events;
+
+    uint32_t arena_stride = 0;
+    uint32_t frames_cap = 0;
+    uint32_t n_streams = 0;
+    uint32_t n_pkgs = 0, n_events = 0;
+    size_t pkg_bytes = 0, evt_bytes = 0;
+    bool events_counted = false;
+
+    void *tap_env = nullptr, *tap_am = nullptr, *tap_fm = nullptr;
+    uint64_t tap_stride = 0;
+
+    bool profiling = false;
+    hipEvent_t ev[8] = {};
+    bool ev_made = false;
+    r433_batch_timing last_timing = {};
+
+    // dispatch scratch
+    r433_bitbuffer *bits = nullptr;
+    r433_pulse_data *pulses = nullptr;
+};
+
+extern "C" {
+
+int r433_version(void)
+{
+    return 100; // 0.1.0
+}
+
+char const *r433_last_error(void)
+{
+    return g_err.c_str();
+}
+
+int r433_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(R433_ENODEV, "no usable HIP device: %s", hipGetErrorString(e));
+    return n;
+}
+
+void r433_flow_cfg_default(r433_flow_cfg *cfg, uint32_t sample_size, uint32_t samp_rate)
+{
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->sample_size = sample_size;
+    cfg->samp_rate = samp_rate;
+    cfg->frame_samples = 0;
+    cfg->fpdm = 0;
+    cfg->enable_fm = 1;
+    cfg->min_level_db = -12.1442f; // reference src/r_api.c:152-154
+    cfg->min_snr_db = 9.0f;
+    cfg->center_frequency = 433920000;
+}
+
+float r433_level_db(uint32_t sum, uint32_t n, int is_magnitude)
+{
+    float x = 1.0f;
+    if (n > 0 && sum >= n)
+        x = (float)sum / n;
+    float lg = x > 0 ? log10f(x) : 0;
+    return is_magnitude ? 20.0f * lg - 84.2884f : 10.0f * lg - 42.1442f;
+}
+
+r433_batch *r433_batch_create(r433_flow_cfg const *cfg, r433_dev_timing const *devs, uint32_t n_devs)
+{
+    if (!cfg || (cfg->sample_size != 2 && cfg->sample_size != 4) || cfg->samp_rate == 0) {
+        fail(R433_EINVAL, "bad flow configuration");
+        return nullptr;
+    }
+    if (n_devs > 2048) {
+        fail(R433_EINVAL, "at most 2048 devices per batch engine");
+        return nullptr;
+    }
+    if (r433_device_count() < 0)
+        return nullptr;
+    r433_batch *b = new r433_batch();
+    b->cfg = *cfg;
+    if (b->cfg.frame_samples == 0)
+        b->cfg.frame_samples = 262144u / cfg->sample_size; // DEFAULT_BUF_LENGTH, reference include/rtl_433.h:17
+    if (b->cfg.frame_samples % 64 != 0) {
+        fail(R433_EINVAL, "frame_samples must be a multiple of 64");
+        delete b;
+        return nullptr;
+    }
+    levels_from_db(b->det, (int)cfg->use_mag_est, cfg->level_limit_db, cfg->min_level_db, cfg->min_snr_db);
+    b->det.per_ms = (int)(cfg->samp_rate / 1000);
+    b->det.rate = cfg->samp_rate;
+    b->det.fpdm = (int)cfg->fpdm;
+    float lp = cfg->fm_low_pass != 0.0f ? cfg->fm_low_pass : cfg->fpdm ? 0.2f : 0.1f; // src/r_flow.c:204
+    fm_coeffs(lp, cfg->samp_rate, b->a16, b->b16, b->a32, b->b32);
+
+    b->timing.assign(devs, devs + n_devs);
+    b->rows.reserve(n_devs);
+    for (uint32_t i = 0; i < n_devs; ++i)
+        b->rows.push_back(resolve_timing(devs[i], cfg->samp_rate, (int)i));
+    std::stable_sort(b->rows.begin(), b->rows.end(), [](DevRow const &x, DevRow const &y) {
+        if (x.is_fsk != y.is_fsk)
+            return x.is_fsk < y.is_fsk;
+        return x.modulation < y.modulation;
+    });
+    for (uint32_t i = 0; i < n_devs; ++i)
+        b->prio_levels.push_back(devs[i].priority);
+    std::sort(b->prio_levels.begin(), b->prio_levels.end());
+    b->prio_levels.erase(std::unique(b->prio_levels.begin(), b->prio_levels.end()), b->prio_levels.end());
+    if (n_devs) {
+        if (b->d_rows.ensure(n_devs) != 0
+                || hipMemcpy(b->d_rows.p, b->rows.data(), n_devs * sizeof(DevRow), hipMemcpyHostToDevice) != hipSuccess) {
+            if (g_err.empty())
+                fail(R433_EHIP, "device table upload failed");
+            r433_batch_destroy(b);
+            return nullptr;
+        }
+    }
+    if (b->d_scal.ensure(16) != 0 || b->h_scal.ensure(16) != 0) {
+        r433_batch_destroy(b);
+        return nullptr;
+    }
+    return b;
+}
+
+void r433_batch_destroy(r433_batch *b)
+{
+    if (!b)
+        return;
+    b->d_rows.release();
+    b->d_arena.release();
+    b->d_ring.release();
+    b->d_state.release();
+    b->d_frame_sums.release();
+    b->d_stream_bytes.release();
+    b->d_pkg_base.release();
+    b->d_scal.release();
+    b->d_dir_stream.release();
+    b->d_dir_off.release();
+    b->d_rec_bytes.release();
+    b->d_rec_off.release();
+    b->d_sizes.release();
+    b->d_pkg_bytes.release();
+    b->d_pkg_off.release();
+    b->d_pkg_blob.release();
+    b->d_events.release();
+    b->h_scal.release();
+    b->h_frame_sums.release();
+    b->h_pkg_blob.release();
+    b->h_events.release();
+    if (b->ev_made)
+        for (auto &e : b->ev)
+            (void)hipEventDestroy(e);
+    free(b->bits);
+    free(b->pulses);
+    delete b;
+}
+
+int r433_batch_set_taps(r433_batch *b, void *d_env, void *d_am, void *d_fm, uint64_t tap_stride)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    if ((d_env || d_am || d_fm) && !(d_env && d_am && d_fm))
+        return fail(R433_EINVAL, "taps come as a set of three");
+    b->tap_env = d_env;
+    b->tap_am = d_am;
+    b->tap_fm = d_fm;
+    b->tap_stride = tap_stride;
+    return 0;
+}
+
+int r433_batch_set_profiling(r433_batch *b, int on)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    if (on && !b->ev_made) {
+        for (auto &e : b->ev)
+            HIP_TRY(hipEventCreate(&e));
+        b->ev_made = true;
+    }
+    b->profiling = on != 0;
+    return 0;
+}
+
+int r433_batch_get_timing(r433_batch *b, r433_batch_timing *t)
+{
+    if (!b || !t)
+        return fail(R433_EINVAL, "null argument");
+    *t = b->last_timing;
+    return 0;
+}
+
+int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint32_t const *stream_bytes,
+        uint32_t n_streams, void *stream)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    if (n_streams == 0) {
+        b->n_streams = 0;
+        b->n_pkgs = b->n_events = 0;
+        b->pkg_bytes = b->evt_bytes = 0;
+        return 0;
+    }
+    if (!d_iq || (stride_bytes & 15u) || ((uintptr_t)d_iq & 15u))
+        return fail(R433_EINVAL, "capture base and stride must be 16-byte aligned");
+    if (stride_bytes > 0xfffffff0ull)
+        return fail(R433_EINVAL, "captures are limited to 4 GiB each");
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t const ss = b->cfg.sample_size;
+    uint32_t max_bytes = 0;
+    if (stream_bytes) {
+        for (uint32_t i = 0; i < n_streams; ++i) {
+            if (stream_bytes[i] > stride_bytes)
+                return fail(R433_EINVAL, "capture %u is longer than the stride", i);
+            max_bytes = std::max(max_bytes, stream_bytes[i]);
+        }
+    }
+    else {
+        max_bytes = (uint32_t)stride_bytes;
+    }
+    uint32_t const max_samples = max_bytes / ss;
+    uint32_t const frames_cap = max_samples / b->cfg.frame_samples + 2;
+
+    int rc;
+    if ((rc = b->d_ring.ensure((size_t)n_streams * R433_PD_MAX_PULSES)) || (rc = b->d_state.ensure(n_streams))
+            || (rc = b->d_frame_sums.ensure((size_t)n_streams * frames_cap)) || (rc = b->d_pkg_base.ensure(n_streams)))
+        return rc;
+    if (stream_bytes) {
+        if ((rc = b->d_stream_bytes.ensure(n_streams)))
+            return rc;
+        HIP_TRY(hipMemcpyAsync(b->d_stream_bytes.p, stream_bytes, n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    }
+    b->frames_cap = frames_cap;
+    b->n_streams = n_streams;
+
+    // arena: worst case is one (pulse, gap) pair per 20 samples plus headers; start at ~1 B/sample
+    uint32_t want_stride = std::max<uint32_t>(16384u, ((max_samples + 4096u) + 15u) & ~15u);
+    if (b->arena_stride < want_stride)
+        b->arena_stride = want_stride;
+
+    if (b->profiling)
+        HIP_TRY(hipEventRecord(b->ev[0], st));
+    uint32_t total_pkgs = 0;
+    for (int attempt = 0;; ++attempt) {
+        if ((rc = b->d_arena.ensure((size_t)n_streams * b->arena_stride)))
+            return rc;
+        StreamParams sp;
+        memset(&sp, 0, sizeof(sp));
+        sp.iq = (uint8_t const *)d_iq;
+        sp.stride_bytes = stride_bytes;
+        sp.stream_bytes = stream_bytes ? b->d_stream_bytes.p : nullptr;
+        sp.uniform_bytes = (uint32_t)stride_bytes;
+        sp.n_streams = n_streams;
+        sp.frame_samples = b->cfg.frame_samples;
+        sp.flags = 0;
+        sp.det = b->det;
+        sp.use_mag = (int)b->cfg.use_mag_est;
+        sp.enable_fm = (int)b->cfg.enable_fm;
+        sp.a16 = b->a16;
+        sp.b16 = b->b16;
+        sp.a32 = b->a32;
+        sp.b32 = b->b32;
+        sp.arena = b->d_arena.p;
+        sp.arena_stride = b->arena_stride;
+        sp.fsk_ring = b->d_ring.p;
+        sp.state = b->d_state.p;
+        sp.frame_sums = b->d_frame_sums.p;
+        sp.frames_cap = frames_cap;
+        sp.frame_min_high = nullptr;
+        sp.tap_env = (uint16_t *)b->tap_env;
+        sp.tap_am = (int16_t *)b->tap_am;
+        sp.tap_fm = (int16_t *)b->tap_fm;
+        sp.tap_stride = b->tap_stride;
+        HIP_TRY(hipMemsetAsync(b->d_frame_sums.p, 0, (size_t)n_streams * frames_cap * sizeof(uint32_t), st));
+        launch_stream(sp, ss, st);
+        HIP_TRY(hipGetLastError());
+        if (b->profiling && attempt == 0)
+            HIP_TRY(hipEventRecord(b->ev[1], st));
+        launch_pkg_scan(b->d_state.p, n_streams, b->d_pkg_base.p, b->d_scal.p, st);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(b->h_scal.p, b->d_scal.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        total_pkgs = b->h_scal.p[0];
+        if (!b->h_scal.p[1])
+            break;
+        if (attempt >= 6 || b->arena_stride > (1u << 28))
+            return fail(R433_EOVERFLOW, "package arena overflow (stride %u)", b->arena_stride);
+        b->arena_stride *= 4;
+    }
+    b->n_pkgs = total_pkgs;
+    b->n_events = 0;
+    b->pkg_bytes = b->evt_bytes = 0;
+    uint32_t const n_devs = (uint32_t)b->rows.size();
+    uint32_t const max_pkgs = std::max<uint32_t>(total_pkgs, 1);
+
+    if ((rc = b->d_dir_stream.ensure(max_pkgs)) || (rc = b->d_dir_off.ensure(max_pkgs))
+            || (rc = b->d_rec_bytes.ensure(max_pkgs)) || (rc = b->d_rec_off.ensure(max_pkgs))
+            || (rc = b->d_pkg_bytes.ensure(max_pkgs)) || (rc = b->d_pkg_off.ensure(max_pkgs))
+            || (rc = b->d_sizes.ensure((size_t)max_pkgs * std::max<uint32_t>(n_devs, 1))))
+        return rc;
+
+    launch_directory(b->d_arena.p, b->arena_stride, b->d_state.p, n_streams, b->d_pkg_base.p, b->d_dir_stream.p,
+            b->d_dir_off.p, b->d_rec_bytes.p, max_pkgs, st);
+    launch_scan_u32(b->d_rec_bytes.p, b->d_rec_off.p, b->d_scal.p, max_pkgs, b->d_scal.p + 2, st);
+    HIP_TRY(hipGetLastError());
+    if (b->profiling)
+        HIP_TRY(hipEventRecord(b->ev[2], st));
+
+    SliceParams lp;
+    memset(&lp, 0, sizeof(lp));
+    lp.arena = b->d_arena.p;
+    lp.arena_stride = b->arena_stride;
+    lp.dir_stream = b->d_dir_stream.p;
+    lp.dir_off = b->d_dir_off.p;
+    lp.n_pkgs = b->d_scal.p;
+    lp.devs = b->d_rows.p;
+    lp.n_devs = n_devs;
+    lp.sizes = b->d_sizes.p;
+    lp.pkg_bytes = b->d_pkg_bytes.p;
+    lp.pkg_off = b->d_pkg_off.p;
+    lp.max_pkgs = max_pkgs;
+    if (n_devs && total_pkgs) {
+        HIP_TRY(hipMemsetAsync(b->d_pkg_bytes.p, 0, (size_t)max_pkgs * sizeof(uint32_t), st));
+        launch_slice_count(lp, total_pkgs, st);
+        HIP_TRY(hipGetLastError());
+        if (b->profiling)
+            HIP_TRY(hipEventRecord(b->ev[3], st));
+        launch_scan_u32(b->d_pkg_bytes.p, b->d_pkg_off.p, b->d_scal.p, max_pkgs, b->d_scal.p + 3, st);
+    }
+    else {
+        HIP_TRY(hipMemsetAsync(b->d_scal.p + 3, 0, sizeof(uint32_t), st));
+        if (b->profiling)
+            HIP_TRY(hipEventRecord(b->ev[3], st));
+    }
+    if (b->profiling)
+        HIP_TRY(hipEventRecord(b->ev[4], st));
+    HIP_TRY(hipMemcpyAsync(b->h_scal.p, b->d_scal.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    size_t const pkg_bytes = b->h_scal.p[2];
+    size_t const evt_bytes = b->h_scal.p[3];
+    if (evt_bytes > 0xf0000000ull)
+        return fail(R433_EOVERFLOW, "event stream exceeds 4 GiB; split the batch");
+
+    if ((rc = b->d_pkg_blob.ensure(pkg_bytes + 16)) || (rc = b->h_pkg_blob.ensure(pkg_bytes + 16))
+            || (rc = b->d_events.ensure(evt_bytes + 16)) || (rc = b->h_events.ensure(evt_bytes + 16))
+            || (rc = b->h_frame_sums.ensure((size_t)n_streams * frames_cap)))
+        return rc;
+    if (total_pkgs) {
+        launch_gather_packages(b->d_arena.p, b->arena_stride, b->d_dir_stream.p, b->d_dir_off.p, b->d_rec_off.p,
+                b->d_scal.p, max_pkgs, b->d_pkg_blob.p, (uint32_t)std::min<size_t>(b->d_pkg_blob.cap, 0xffffffffu),
+                total_pkgs, st);
+        if (n_devs && evt_bytes) {
+            lp.events = b->d_events.p;
+            lp.events_cap = (uint32_t)std::min<size_t>(b->d_events.cap, 0xffffffffu);
+            launch_slice_write(lp, total_pkgs, st);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    if (b->profiling)
+        HIP_TRY(hipEventRecord(b->ev[5], st));
+    if (pkg_bytes)
+        HIP_TRY(hipMemcpyAsync(b->h_pkg_blob.p, b->d_pkg_blob.p, pkg_bytes, hipMemcpyDeviceToHost, st));
+    if (evt_bytes)
+        HIP_TRY(hipMemcpyAsync(b->h_events.p, b->d_events.p, evt_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(b->h_frame_sums.p, b->d_frame_sums.p, (size_t)n_streams * frames_cap * sizeof(uint32_t),
+            hipMemcpyDeviceToHost, st));
+    if (b->profiling)
+        HIP_TRY(hipEventRecord(b->ev[6], st));
+    HIP_TRY(hipStreamSynchronize(st));
+    b->pkg_bytes = pkg_bytes;
+    b->evt_bytes = evt_bytes;
+    b->events_counted = false;
+
+    if (b->profiling) {
+        r433_batch_timing &t = b->last_timing;
+        (void)hipEventElapsedTime(&t.detect_ms, b->ev[0], b->ev[1]);
+        (void)hipEventElapsedTime(&t.dir_ms, b->ev[1], b->ev[2]);
+        (void)hipEventElapsedTime(&t.count_ms, b->ev[2], b->ev[3]);
+        (void)hipEventElapsedTime(&t.scan_ms, b->ev[3], b->ev[4]);
+        (void)hipEventElapsedTime(&t.write_ms, b->ev[4], b->ev[5]);
+        (void)hipEventElapsedTime(&t.d2h_ms, b->ev[5], b->ev[6]);
+        (void)hipEventElapsedTime(&t.total_ms, b->ev[0], b->ev[6]);
+    }
+    return (int)total_pkgs;
+}
+
+int r433_batch_packages(r433_batch *b, uint8_t const **blob, size_t *len, uint32_t *count)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    if (blob)
+        *blob = b->h_pkg_blob.p;
+    if (len)
+        *len = b->pkg_bytes;
+    if (count)
+        *count = b->n_pkgs;
+    return 0;
+}
+
+int r433_batch_events(r433_batch *b, uint8_t const **blob, size_t *len, uint32_t *count)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    if (!b->events_counted) {
+        uint32_t n = 0;
+        size_t at = 0;
+        while (at + sizeof(r433_evt_rec) <= b->evt_bytes) {
+            uint32_t total;
+            memcpy(&total, b->h_events.p + at, 4);
+            if (total < sizeof(r433_evt_rec) || at + total > b->evt_bytes)
+                return fail(R433_EHIP, "corrupt event stream at byte %zu", at);
+            at += total;
+            n++;
+        }
+        b->n_events = n;
+        b->events_counted = true;
+    }
+    if (blob)
+        *blob = b->h_events.p;
+    if (len)
+        *len = b->evt_bytes;
+    if (count)
+        *count = b->n_events;
+    return 0;
+}
+
+int r433_batch_frame_sums(r433_batch *b, uint32_t const **sums, uint32_t *frames_cap)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    if (sums)
+        *sums = b->h_frame_sums.p;
+    if (frames_cap)
+        *frames_cap = b->frames_cap;
+    return 0;
+}
+
+int r433_batch_device_events(r433_batch *b, void const **d_events, size_t *len)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    if (d_events)
+        *d_events = b->d_events.p;
+    if (len)
+        *len = b->evt_bytes;
+    return 0;
+}
+
+// ---- decoder dispatch ----
+
+namespace {
+
+// calc_rssi_snr, reference src/r_flow.c:35-64
+void fill_levels(r433_flow_cfg const &cfg, r433_pulse_data &p)
+{
+    float hi = p.ook_high_estimate > 0 ? p.ook_high_estimate : 1;
+    float lo = p.ook_low_estimate > 0 ? p.ook_low_estimate : 1;
+    int const max_high = (int)powf(10, (0 + 42.1442f) / 10.0f);
+    float mx = hi < max_high ? hi : max_high;
+    float asnr = mx / lo;
+    float f1 = (float)p.fsk_f1_est / INT16_MAX * cfg.samp_rate / 2.0f;
+    float f2 = (float)p.fsk_f2_est / INT16_MAX * cfg.samp_rate / 2.0f;
+    p.freq1_hz = f1 + cfg.center_frequency;
+    p.freq2_hz = f2 + cfg.center_frequency;
+    p.centerfreq_hz = cfg.center_frequency;
+    p.depth_bits = cfg.sample_size * 4;
+    if (cfg.sample_size == 2 && !cfg.use_mag_est) {
+        p.range_db = 42.1442f;
+        p.rssi_db = 10.0f * log10f(hi) - 42.1442f;
+        p.noise_db = 10.0f * log10f(lo) - 42.1442f;
+        p.snr_db = 10.0f * log10f(asnr);
+    }
+    else {
+        p.range_db = 84.2884f;
+        p.rssi_db = 20.0f * log10f(hi) - 84.2884f;
+        p.noise_db = 20.0f * log10f(lo) - 84.2884f;
+        p.snr_db = 20.0f * log10f(asnr);
+    }
+}
+
+struct EvtRef {
+    uint32_t at; // byte offset of the record
+};
+
+} // namespace
+
+int r433_batch_dispatch(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices, r433_package_fn pkg_cb,
+        void *user)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    if (n_devices != b->timing.size())
+        return fail(R433_EINVAL, "dispatch needs the %zu devices the engine was created with", b->timing.size());
+    if (!b->bits)
+        b->bits = (r433_bitbuffer *)calloc(1, sizeof(r433_bitbuffer));
+    if (!b->pulses)
+        b->pulses = (r433_pulse_data *)calloc(1, sizeof(r433_pulse_data));
+    r433_bitbuffer *bits = b->bits;
+    uint8_t const *ev = b->h_events.p;
+    size_t const ev_len = b->evt_bytes;
+    uint8_t const *pk = b->h_pkg_blob.p;
+
+    std::vector<uint32_t> first(n_devices, 0), count(n_devices, 0);
+    std::vector<uint32_t> touched;
+    std::vector<EvtRef> refs;
+    int decoded = 0;
+    size_t eat = 0, pat = 0;
+
+    for (uint32_t pkg = 0; pkg < b->n_pkgs; ++pkg) {
+        r433_pkg_rec ph;
+        memcpy(&ph, pk + pat, sizeof(ph));
+        if (pkg_cb) {
+            r433_pulse_data &pd = *b->pulses;
+            memset(&pd, 0, sizeof(pd));
+            pd.offset = ph.offset;
+            pd.sample_rate = ph.sample_rate;
+            pd.start_ago = ph.start_ago;
+            pd.end_ago = ph.end_ago;
+            pd.num_pulses = ph.num_pulses;
+            int32_t const *pairs = (int32_t const *)(pk + pat + sizeof(ph));
+            for (uint32_t i = 0; i < ph.num_pulses && i < R433_MAX_PULSES; ++i) {
+                pd.pulse[i] = pairs[2 * i];
+                pd.gap[i] = pairs[2 * i + 1];
+            }
+            pd.ook_low_estimate = ph.ook_low;
+            pd.ook_high_estimate = ph.ook_high;
+            pd.fsk_f1_est = ph.fsk_f1;
+            pd.fsk_f2_est = ph.fsk_f2;
+            fill_levels(b->cfg, pd);
+            pkg_cb(user, ph.stream, ph.type, &pd);
+        }
+        pat += ph.total_bytes;
+
+        // index this package's events by device (they arrive sorted by device, then ordinal)
+        refs.clear();
+        touched.clear();
+        while (eat + sizeof(r433_evt_rec) <= ev_len) {
+            r433_evt_rec eh;
+            memcpy(&eh, ev + eat, sizeof(eh));
+            if (eh.pkg != pkg)
+                break;
+            if (eh.dev >= n_devices)
+                return fail(R433_EHIP, "event names device %u of %u", eh.dev, n_devices);
+            if (count[eh.dev] == 0) {
+                first[eh.dev] = (uint32_t)refs.size();
+                touched.push_back(eh.dev);
+            }
+            count[eh.dev]++;
+            refs.push_back(EvtRef{(uint32_t)eat});
+            eat += eh.total_bytes;
+        }
+
+        int p_events = 0;
+        for (uint32_t level : b->prio_levels) { // src/r_api.c:442-451: next level only while nothing decoded
+            if (p_events)
+                break;
+            for (uint32_t dev : touched) {
+                if (b->timing[dev].priority != level)
+                    continue;
+                r433_r_device *rd = devices[dev];
+                for (uint32_t k = 0; k < count[dev]; ++k) {
+                    uint8_t const *rec = ev + refs[first[dev] + k].at;
+                    r433_evt_rec eh;
+                    memcpy(&eh, rec, sizeof(eh));
+                    // inflate into the reference bitbuffer layout
+                    bits->num_rows = eh.num_rows;
+                    bits->free_row = eh.free_row;
+                    uint8_t const *rp = rec + sizeof(eh);
+                    for (uint32_t r = 0; r < eh.num_rows && r < R433_BITBUF_ROWS; ++r) {
+                        r433_row_rec rr;
+                        memcpy(&rr, rp, sizeof(rr));
+                        bits->bits_per_row[r] = rr.bits;
+                        bits->syncs_before_row[r] = rr.syncs;
+                        size_t room = (size_t)(R433_BITBUF_ROWS - r) * R433_BITBUF_COLS;
+                        memcpy(bits->bb[r], rp + sizeof(rr), rr.nbytes < room ? rr.nbytes : room);
+                        rp += sizeof(rr) + ((rr.nbytes + 3u) & ~3u);
+                    }
+                    uint32_t used_rows = std::max<uint32_t>(eh.num_rows, eh.free_row);
+
+                    int ret = 0;
+                    if (rd && rd->decode_fn)
+                        ret = rd->decode_fn(rd, bits);
+                    if (rd) { // statistics, src/pulse_slicer.c:35-47
+                        rd->decode_events += 1;
+                        if (ret > 0) {
+                            rd->decode_ok += 1;
+                            rd->decode_messages += (unsigned)ret;
+                        }
+                        else if (ret >= R433_DECODE_FAIL_SANITY) {
+                            rd->decode_fails[-ret] += 1;
+                            ret = 0;
+                        }
+                        else {
+                            return fail(R433_EDECODER, "decoder \"%s\" gave invalid return value %d",
+                                    rd->name ? rd->name : "?", ret);
+                        }
+                    }
+                    if (ret > 0)
+                        p_events += ret;
+                    // bitbuffer_clear: only what can be dirty (the decoder may have grown the buffer)
+                    used_rows = std::max<uint32_t>(used_rows, std::max<uint32_t>(bits->num_rows, bits->free_row));
+                    if (used_rows > R433_BITBUF_ROWS)
+                        used_rows = R433_BITBUF_ROWS;
+                    memset(bits->bb, 0, (size_t)used_rows * R433_BITBUF_COLS);
+                    memset(bits, 0, offsetof(r433_bitbuffer, bb));
+                }
+            }
+        }
+        decoded += p_events;
+        for (uint32_t dev : touched)
+            count[dev] = 0;
+    }
+    return decoded;
+}
+
+// ---- function-level seam ----
+
+static int run_envelope(int kind, void const *d_iq, void *d_env, uint32_t n, uint32_t *d_sum, void *stream)
+{
+    if (r433_device_count() < 0)
+        return R433_ENODEV;
+    if (!d_iq || !d_env)
+        return fail(R433_EINVAL, "null buffer");
+    if (((uintptr_t)d_iq & 15u) || ((uintptr_t)d_env & 15u))
+        return fail(R433_EINVAL, "buffers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (d_sum)
+        HIP_TRY(hipMemsetAsync(d_sum, 0, sizeof(uint32_t), st));
+    launch_envelope(kind, d_iq, (uint16_t *)d_env, n, d_sum, st);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int r433_envelope_detect(void const *d_iq, void *d_env, uint32_t n, uint32_t *d_sum, void *stream)
+{
+    return run_envelope(ENV_AMP_CU8, d_iq, d_env, n, d_sum, stream);
+}
+
+int r433_magnitude_est_cu8(void const *d_iq, void *d_env, uint32_t n, uint32_t *d_sum, void *stream)
+{
+    return run_envelope(ENV_MAG_CU8, d_iq, d_env, n, d_sum, stream);
+}
+
+int r433_magnitude_est_cs16(void const *d_iq, void *d_env, uint32_t n, uint32_t *d_sum, void *stream)
+{
+    return run_envelope(ENV_MAG_CS16, d_iq, d_env, n, d_sum, stream);
+}
+
+} // extern "C"

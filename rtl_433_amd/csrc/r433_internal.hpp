@@ -1,0 +1,115 @@
+// r433_internal.hpp -- kernel parameter blocks and launch entry points shared by the
+// translation units of librtl433hip.so.  Not part of the public C ABI (include/r433_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "detect_device.hpp"
+#include "r433_records.h"
+
+namespace r433 {
+
+// Per-capture carry between launches: everything the reference keeps in filter_state_t,
+// demodfm_state_t, struct pulse_detect and the two open pulse_data_t.
+struct StreamState {
+    int lpf_y, lpf_x;
+    int fm_xr, fm_xi, fm_xf, fm_yf;
+    int state, run, max_pulse, lead_in, low, high;
+    uint32_t f_run;
+    int f_state, f_f1, f_f2, f_vmax, f_vmin, f_skip;
+    uint32_t ook_num;
+    int cur_pulse, ook_f1;
+    uint32_t fsk_num;
+    uint32_t start_ago;
+    uint64_t offset, fsk_offset;
+    uint64_t input_pos;
+    uint32_t frame;
+    uint32_t cursor;
+    uint32_t n_pkgs;
+    uint32_t overflow;
+};
+
+enum : uint32_t {
+    RUN_CONTINUE = 1u, // resume from StreamState instead of a reset flow
+    RUN_NOFLUSH = 2u,  // do not issue the end-of-input flush call
+};
+
+struct StreamParams {
+    uint8_t const *iq;            // n_streams captures, stride_bytes apart (16-byte aligned)
+    uint64_t stride_bytes;
+    uint32_t const *stream_bytes; // per capture, or nullptr: all uniform_bytes
+    uint32_t uniform_bytes;
+    uint32_t n_streams;
+    uint32_t frame_samples;
+    uint32_t flags;
+    DetCfg det;
+    int use_mag;
+    int enable_fm;
+    int a16, b16;
+    long long a32, b32;
+    uint8_t *arena;               // n_streams * arena_stride bytes
+    uint32_t arena_stride;
+    int2 *fsk_ring;               // n_streams * 1200 pairs
+    StreamState *state;           // n_streams
+    uint32_t *frame_sums;         // n_streams * frames_cap (may be null)
+    uint32_t frames_cap;
+    int const *frame_min_high;    // optional per (capture, frame) override of det.min_high
+    // optional taps (parity tests): n_streams * tap_stride samples each, may be null
+    uint16_t *tap_env;
+    int16_t *tap_am;
+    int16_t *tap_fm;
+    uint64_t tap_stride;
+};
+
+void launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st);
+
+// ---- slicer fan-out ----
+
+// integer timing of one r_device at one sample rate (host-resolved, reference src/pulse_slicer.c:70-99)
+struct DevRow {
+    int modulation;
+    int s_short, s_long, s_reset, s_gap, s_sync, s_tol;
+    float f_short, f_long;
+    int valid;    // 0: "sample rate too low" early return, or degenerate timing
+    int orig;     // index in registration order
+    int is_fsk;
+};
+
+struct SliceParams {
+    uint8_t const *arena;
+    uint32_t arena_stride;
+    uint32_t const *dir_stream; // per package: capture index
+    uint32_t const *dir_off;    // per package: byte offset of its record in that capture's arena
+    uint32_t const *n_pkgs;     // device scalar: total packages
+    DevRow const *devs;         // sorted by modulation
+    uint32_t n_devs;
+    uint32_t *sizes;            // [pkg][orig dev] bytes of event records
+    uint32_t *pkg_bytes;        // [pkg] total
+    uint32_t const *pkg_off;    // [pkg] exclusive scan of pkg_bytes
+    uint8_t *events;
+    uint32_t events_cap;
+    uint32_t max_pkgs;
+};
+
+// scal[0] = total packages, scal[1] = any arena overflow
+void launch_pkg_scan(StreamState const *state, uint32_t n_streams, uint32_t *pkg_base, uint32_t *scal, hipStream_t st);
+// fills dir_stream/dir_off/rec_bytes for every package (canonical order)
+void launch_directory(uint8_t const *arena, uint32_t arena_stride, StreamState const *state, uint32_t n_streams,
+        uint32_t const *pkg_base, uint32_t *dir_stream, uint32_t *dir_off, uint32_t *rec_bytes, uint32_t max_pkgs,
+        hipStream_t st);
+// out[i] = sum(in[0..i)), *total = sum(in[0..n)), n = min(*n_ptr, n_cap); single block
+void launch_scan_u32(uint32_t const *in, uint32_t *out, uint32_t const *n_ptr, uint32_t n_cap, uint32_t *total,
+        hipStream_t st);
+// dense copy of all package records in canonical order
+void launch_gather_packages(uint8_t const *arena, uint32_t arena_stride, uint32_t const *dir_stream,
+        uint32_t const *dir_off, uint32_t const *rec_off, uint32_t const *n_pkgs, uint32_t max_pkgs, uint8_t *dst,
+        uint32_t dst_cap, uint32_t grid_pkgs, hipStream_t st);
+void launch_slice_count(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st);
+void launch_slice_write(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st);
+
+// ---- function-level baseband kernels (device pointers) ----
+enum { ENV_AMP_CU8 = 0, ENV_MAG_CU8 = 1, ENV_MAG_CS16 = 2 };
+void launch_envelope(int kind, void const *d_iq, uint16_t *d_env, uint32_t n, uint32_t *d_sum, hipStream_t st);
+
+} // namespace r433

@@ -1,0 +1,126 @@
+"""Host-side mirror of the reference's offline flow for the accelerated path.
+
+`BatchEngine` is what `rtl_433 -r a.cu8 -r b.cu8 ...` does between reading the files and calling
+the decoders (reference src/rtl_433.c:1703-1854 -> src/r_flow.c:104-340 -> src/r_api.c:438-550),
+for N captures at once, on one MI355X.  Device memory and streams come from PyTorch; everything
+else goes through the C ABI in include/r433_hip.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import FlowCfg
+
+DEV_DTYPE = np.dtype([("modulation", "<u4"), ("short_width", "<f4"), ("long_width", "<f4"),
+                      ("reset_limit", "<f4"), ("gap_limit", "<f4"), ("sync_width", "<f4"),
+                      ("tolerance", "<f4"), ("priority", "<u4")])
+
+DEFAULT_DEVICE_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "r_devices_default.json")
+
+
+def load_device_table(path=DEFAULT_DEVICE_TABLE):
+    """Timing rows of the reference's default-enabled r_devices, in registration order.
+    Returns (DEV_DTYPE array, protocol numbers, names)."""
+    with open(path) as f:
+        doc = json.load(f)
+    rows = doc["devices"]
+    devs = np.zeros(len(rows), dtype=DEV_DTYPE)
+    for i, r in enumerate(rows):
+        devs[i] = (r["modulation"], r["short_width"], r["long_width"], r["reset_limit"], r["gap_limit"],
+                   r["sync_width"], r["tolerance"], r["priority"])
+    return devs, [r["protocol"] for r in rows], [r["name"] for r in rows]
+
+
+def flow_cfg(sample_size=2, samp_rate=250000, fpdm=0, enable_fm=1, use_mag_est=0, fm_low_pass=0.0,
+             level_limit_db=0.0, min_level_db=-12.1442, min_snr_db=9.0, auto_level=0.0, frame_samples=0,
+             center_frequency=433920000):
+    return FlowCfg(sample_size, samp_rate, frame_samples, fpdm, use_mag_est, enable_fm, fm_low_pass,
+                   level_limit_db, min_level_db, min_snr_db, auto_level, center_frequency)
+
+
+class BatchEngine:
+    def __init__(self, cfg: FlowCfg, devs=None, profiling=False):
+        self.L = _lib.lib()
+        _lib.check(self.L.r433_device_count(), "r433_device_count")
+        self.cfg = cfg
+        self.devs = np.zeros(0, dtype=DEV_DTYPE) if devs is None else np.ascontiguousarray(devs, dtype=DEV_DTYPE)
+        ptr = self.devs.ctypes.data_as(C.c_void_p) if len(self.devs) else None
+        self.h = self.L.r433_batch_create(C.byref(cfg), ptr, len(self.devs))
+        if not self.h:
+            raise RuntimeError("r433_batch_create failed: " + _lib.last_error())
+        if profiling:
+            _lib.check(self.L.r433_batch_set_profiling(self.h, 1), "r433_batch_set_profiling")
+        self._taps = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.r433_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, iq, stream_bytes=None, stream=None):
+        """iq: CUDA tensor [n_streams, stride] of uint8 (cu8) or int16 (cs16), contiguous."""
+        import torch
+        assert iq.is_cuda and iq.is_contiguous() and iq.dim() == 2
+        n_streams = iq.shape[0]
+        stride = iq.shape[1] * iq.element_size()
+        sb = None
+        if stream_bytes is not None:
+            sb_arr = np.ascontiguousarray(stream_bytes, dtype=np.uint32)
+            assert len(sb_arr) == n_streams
+            sb = sb_arr.ctypes.data_as(C.c_void_p)
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        rc = self.L.r433_batch_run(self.h, C.c_void_p(iq.data_ptr()), stride, sb, n_streams, C.c_void_p(st))
+        return _lib.check(rc, "r433_batch_run")
+
+    def enable_taps(self, n_streams, n_samples):
+        import torch
+        env = torch.zeros((n_streams, n_samples), dtype=torch.int16, device="cuda")  # u16 payload
+        am = torch.zeros((n_streams, n_samples), dtype=torch.int16, device="cuda")
+        fm = torch.zeros((n_streams, n_samples), dtype=torch.int16, device="cuda")
+        _lib.check(self.L.r433_batch_set_taps(self.h, C.c_void_p(env.data_ptr()), C.c_void_p(am.data_ptr()),
+                                              C.c_void_p(fm.data_ptr()), n_samples), "r433_batch_set_taps")
+        self._taps = (env, am, fm)
+        return self._taps
+
+    def taps(self):
+        env, am, fm = self._taps
+        return env.cpu().numpy().view(np.uint16), am.cpu().numpy(), fm.cpu().numpy()
+
+    def _blob(self, fn):
+        p, n, c = C.c_void_p(), C.c_size_t(), C.c_uint32()
+        _lib.check(fn(self.h, C.byref(p), C.byref(n), C.byref(c)), fn.__name__)
+        return (C.string_at(p, n.value) if n.value else b""), c.value
+
+    def packages(self):
+        return self._blob(self.L.r433_batch_packages)
+
+    def events(self):
+        return self._blob(self.L.r433_batch_events)
+
+    def frame_sums(self, n_streams):
+        p, cap = C.c_void_p(), C.c_uint32()
+        _lib.check(self.L.r433_batch_frame_sums(self.h, C.byref(p), C.byref(cap)), "r433_batch_frame_sums")
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n_streams * cap.value,))
+        return a.reshape(n_streams, cap.value).copy()
+
+    def timing(self):
+        t = _lib.BatchTiming()
+        _lib.check(self.L.r433_batch_get_timing(self.h, C.byref(t)), "r433_batch_get_timing")
+        return {n: getattr(t, n) for n, _ in t._fields_}
+
+    def dispatch(self, rdevices, pkg_cb=None, user=None):
+        """rdevices: ctypes array of POINTER(RDevice) in registration order."""
+        cb = C.cast(pkg_cb, C.c_void_p) if pkg_cb is not None else None
+        rc = self.L.r433_batch_dispatch(self.h, C.cast(rdevices, C.c_void_p), len(rdevices), cb, user)
+        return _lib.check(rc, "r433_batch_dispatch")

@@ -1,0 +1,55 @@
+"""Seeded parity cases shared by the golden generator (oracle/gen_golden.py) and the tests."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from rtl_433_amd import synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+CASES = [
+    "kat", "ook0", "ook1", "ook2", "ook3", "ook4", "ook5", "ook6", "ook7", "ook_long", "noise", "random",
+    "silence", "fsk_cu8", "fsk_cu8_minmax", "fsk_cs16", "fsk_cs16_classic", "fsk_cs16_pcm", "empty", "tiny", "ragged",
+]
+
+
+def make_case(name):
+    """-> (iq array, sample_size, sample rate, centre frequency)"""
+    if name == "kat":
+        return np.fromfile(os.path.join(GOLD, "nice_250k.cu8"), dtype=np.uint8), 2, 250000, 433920000
+    if name.startswith("ook") and name[3:].isdigit():
+        iq, _ = synth.ook_stream(int(name[3:]))
+        return iq, 2, 250000, 433920000
+    if name == "ook_long":  # five bursts over 2.5 reference frames (131072 samples each)
+        iq = np.concatenate([synth.ook_stream(100 + k)[0] for k in range(5)])
+        return iq, 2, 250000, 433920000
+    if name == "noise":
+        return synth.noise_cu8(1, 300000, 6.0), 2, 250000, 433920000
+    if name == "random":
+        return synth.random_cu8(2, 200000), 2, 250000, 433920000
+    if name == "silence":
+        return np.full(2 * 140000, 128, dtype=np.uint8), 2, 250000, 433920000
+    if name == "fsk_cu8":
+        return synth.fsk_stream_cu8(3, 150000), 2, 250000, 433920000
+    if name == "fsk_cu8_minmax":
+        return synth.fsk_stream_cu8(4, 150000, n_bursts=3), 2, 250000, 868300000
+    if name == "fsk_cs16":
+        return synth.fsk_stream_cs16(3, 200000), 4, 1024000, 868000000
+    if name == "fsk_cs16_classic":
+        return synth.fsk_stream_cs16(5, 150000), 4, 1024000, 433920000
+    if name == "fsk_cs16_pcm":
+        return synth.fsk_stream_cs16(6, 150000, coding="pcm", halfbit_us=52.0, nbits=64), 4, 1024000, 868000000
+    if name == "empty":
+        return np.zeros(0, dtype=np.uint8), 2, 250000, 433920000
+    if name == "tiny":
+        return synth.random_cu8(7, 10), 2, 250000, 433920000
+    if name == "ragged":
+        return synth.ook_stream(9, 70001)[0], 2, 250000, 433920000
+    raise KeyError(name)
+
+
+def fpdm_for(freq):
+    """FSK detector resolution for AUTO mode, reference src/rtl_433.c:1094-1102."""
+    return 1 if freq > 800000000 else 0
