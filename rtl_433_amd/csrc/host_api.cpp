@@ -592,6 +592,10 @@ int r433_batch_events(r433_batch *b, uint8_t const **blob, size_t *len, uint32_t
 {
     if (!b)
         return fail(R433_EINVAL, "null batch");
+    if (blob)
+        *blob = b->h_events.p;
+    if (len)
+        *len = b->evt_bytes;
     if (!b->events_counted) {
         uint32_t n = 0;
         size_t at = 0;
@@ -606,10 +610,6 @@ int r433_batch_events(r433_batch *b, uint8_t const **blob, size_t *len, uint32_t
         b->n_events = n;
         b->events_counted = true;
     }
-    if (blob)
-        *blob = b->h_events.p;
-    if (len)
-        *len = b->evt_bytes;
     if (count)
         *count = b->n_events;
     return 0;

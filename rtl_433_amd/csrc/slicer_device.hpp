@@ -29,6 +29,9 @@ struct PulseView {
 
 template <bool WRITE> struct BitSink {
     uint8_t *out;       // lane's record region (WRITE only)
+    uint32_t limit;     // size of that region: the bytes COUNT attributed to fired events.  A bitbuffer that is
+                        // cleared or never fired is built past `off` too, but must not leak into the next lane's
+                        // region, so every store is bounded by this.
     uint32_t off;       // bytes of finished events
     uint32_t pkg;
     uint16_t dev;
@@ -44,9 +47,16 @@ template <bool WRITE> struct BitSink {
     uint32_t row_hdr;   // offset of the current row's header (relative to out)
     uint32_t wr;        // write cursor (relative to out)
 
-    __device__ __forceinline__ void begin(uint8_t *o, uint32_t pkg_, uint32_t dev_)
+    __device__ __forceinline__ void put32(uint32_t at, uint32_t v)
+    {
+        if (WRITE && at + 4u <= limit)
+            *(uint32_t *)(out + at) = v;
+    }
+
+    __device__ __forceinline__ void begin(uint8_t *o, uint32_t limit_, uint32_t pkg_, uint32_t dev_)
     {
         out = o;
+        limit = limit_;
         off = 0;
         pkg = pkg_;
         dev = (uint16_t)dev_;
@@ -83,11 +93,14 @@ template <bool WRITE> struct BitSink {
     __device__ __forceinline__ void store_word(uint32_t k, uint32_t bits_be)
     {
         if (WRITE) {
-            uint32_t *p = (uint32_t *)(out + row_hdr + sizeof(r433_row_rec)) + k;
-            uint32_t v = __builtin_bswap32(bits_be);
-            if (k < written)
-                v |= *p; // only after the 50-row overflow reset: OR onto what the row already holds
-            *p = v;
+            uint32_t at = row_hdr + (uint32_t)sizeof(r433_row_rec) + 4u * k;
+            if (at + 4u <= limit) {
+                uint32_t *p = (uint32_t *)(out + at);
+                uint32_t v = __builtin_bswap32(bits_be);
+                if (k < written)
+                    v |= *p; // only after the 50-row overflow reset: OR onto what the row already holds
+                *p = v;
+            }
         }
     }
 
@@ -98,11 +111,8 @@ template <bool WRITE> struct BitSink {
         if (cur_bits & 31u)
             store_word(k, acc);
         uint32_t nbytes = (extent + 7u) >> 3;
-        if (WRITE) {
-            uint32_t *h = (uint32_t *)(out + row_hdr);
-            h[0] = (cur_bits & 0xffffu) | (cur_syncs << 16);
-            h[1] = nbytes & 0xffffu;
-        }
+        put32(row_hdr, (cur_bits & 0xffffu) | (cur_syncs << 16));
+        put32(row_hdr + 4, nbytes & 0xffffu);
         wr = row_hdr + (uint32_t)sizeof(r433_row_rec) + ((nbytes + 3u) & ~3u);
     }
 
@@ -139,11 +149,8 @@ template <bool WRITE> struct BitSink {
             close_row();
             uint32_t skipped = free_row - num_rows; // rows the spill ran through: logical rows of length 0
             for (uint32_t i = 0; i < skipped; ++i) {
-                if (WRITE) {
-                    uint32_t *h = (uint32_t *)(out + wr);
-                    h[0] = 0;
-                    h[1] = 0;
-                }
+                put32(wr, 0);
+                put32(wr + 4, 0);
                 wr += (uint32_t)sizeof(r433_row_rec);
             }
             free_row++;
@@ -180,13 +187,10 @@ template <bool WRITE> struct BitSink {
     {
         if (num_rows > 0)
             close_row();
-        if (WRITE) {
-            uint32_t *h = (uint32_t *)(out + off);
-            h[0] = wr - off;
-            h[1] = pkg;
-            h[2] = (uint32_t)dev | ((uint32_t)ordinal << 16);
-            h[3] = (num_rows & 0xffffu) | (free_row << 16);
-        }
+        put32(off, wr - off);
+        put32(off + 4, pkg);
+        put32(off + 8, (uint32_t)dev | ((uint32_t)ordinal << 16));
+        put32(off + 12, (num_rows & 0xffffu) | (free_row << 16));
         off = wr;
         ordinal++;
         clear();

@@ -72,15 +72,17 @@ template <bool WRITE> __global__ __launch_bounds__(64) void k_slice(SliceParams 
             bool const run = t.valid && (t.is_fsk != 0) == (type == R433_PKG_FSK);
             BitSink<WRITE> sink;
             uint8_t *out = nullptr;
+            uint32_t limit = 0;
             bool fits = true;
             if (WRITE) {
                 uint32_t base = p.pkg_off[pkg] + prefix[t.orig];
-                fits = (uint64_t)base + p.sizes[(uint64_t)pkg * p.n_devs + t.orig] <= p.events_cap;
+                limit = p.sizes[(uint64_t)pkg * p.n_devs + t.orig];
+                fits = limit > 0 && (uint64_t)base + limit <= p.events_cap;
                 out = p.events + base;
             }
             if (run && fits) {
                 PulseView pv{pairs, num};
-                sink.begin(out, pkg, (uint32_t)t.orig);
+                sink.begin(out, limit, pkg, (uint32_t)t.orig);
                 slice_dispatch<WRITE>(pv, t, sink);
                 my_bytes = sink.off;
             }
