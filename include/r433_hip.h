@@ -114,6 +114,34 @@ int r433_batch_get_timing(r433_batch *b, r433_batch_timing *t);
 typedef void (*r433_package_fn)(void *user, uint32_t stream, uint32_t type, r433_pulse_data const *pulses);
 int r433_batch_dispatch(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices, r433_package_fn pkg_cb,
         void *user);
+/* Same, with the packages spread over n_threads host threads (contiguous package ranges, so all
+ * reference ordering rules hold inside a package; decode_fn / pkg_cb must be thread-safe and
+ * cross-package output order is the caller's business). */
+int r433_batch_dispatch_mt(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices, r433_package_fn pkg_cb,
+        void *user, uint32_t n_threads);
+
+/* What the dispatcher is handing to decode_fn right now, for plugins that want to tag their output
+ * (the reference's `output_tag FILE` needs the capture; time stamps need start_ago).  Thread-local. */
+typedef struct r433_dispatch_info {
+    uint32_t stream;       /* capture index in the batch */
+    uint32_t package;      /* canonical package index */
+    uint32_t device;       /* registration index of the r_device */
+    uint32_t ordinal;      /* n-th bitbuffer of this (package, device) */
+    uint32_t package_type; /* R433_PKG_OOK / R433_PKG_FSK */
+    uint32_t start_ago;    /* pulse_data_t.start_ago of the package */
+} r433_dispatch_info;
+int r433_dispatch_current(r433_dispatch_info *info);
+
+/* A ready-made decode_fn (reference plugin signature) that checksums every bitbuffer it receives:
+ * FNV-1a 64 over {package, device, ordinal, num_rows, free_row, per row: bits, syncs, payload bytes},
+ * summed mod 2^64 into decode_ctx (a r433_digest_ctx).  bench.py registers it for every device; the
+ * oracle computes the same sum from its own records, so a full-size run is parity-checked by one
+ * number.  Always returns DECODE_ABORT_LENGTH (no event). */
+typedef struct r433_digest_ctx {
+    uint64_t sum;
+    uint64_t events;
+} r433_digest_ctx;
+int r433_plugin_digest_decode(r433_r_device *decoder, r433_bitbuffer *bits);
 
 /* ------------------------------------------------------------------------------------------------
  * Function-level seam on device buffers: the prototypes of include/baseband.h with device pointers.

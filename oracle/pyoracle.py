@@ -113,6 +113,8 @@ def oracle():
         L.orc_events_normalize.argtypes = [C.c_void_p, C.c_size_t]
         L.orc_events_digest.restype = C.c_uint64
         L.orc_events_digest.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]
+        L.orc_events_digest2.restype = C.c_uint64
+        L.orc_events_digest2.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]
         _oracle = L
     return _oracle
 
@@ -186,6 +188,13 @@ def events_digest(blob):
     a = np.frombuffer(bytes(blob), dtype=np.uint8)
     cnt = C.c_uint32(0)
     d = oracle().orc_events_digest(_ptr(a) if a.size else None, a.size, C.byref(cnt))
+    return int(d), int(cnt.value)
+
+
+def events_digest2(blob):
+    a = np.frombuffer(bytes(blob), dtype=np.uint8)
+    cnt = C.c_uint32(0)
+    d = oracle().orc_events_digest2(_ptr(a) if a.size else None, a.size, C.byref(cnt))
     return int(d), int(cnt.value)
 
 
@@ -268,6 +277,9 @@ class Ref:
         L.refh_digest.restype = C.c_uint64
         L.refh_digest.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.refh_clear.argtypes = [C.c_void_p]
+        L.refh_set_digest_mode.argtypes = [C.c_void_p, C.c_int]
+        L.refh_digest2.restype = C.c_uint64
+        L.refh_digest2.argtypes = [C.c_void_p]
         L.refh_abi_sizes.argtypes = [C.c_void_p]
         if protocols is None:
             arr, n = None, 0
@@ -338,6 +350,12 @@ class Ref:
         ne, npk = C.c_uint32(), C.c_uint32()
         d = self.L.refh_digest(self.h, C.byref(ne), C.byref(npk))
         return int(d), int(ne.value), int(npk.value)
+
+    def set_digest_mode(self, mode):
+        self.L.refh_set_digest_mode(self.h, mode)
+
+    def digest2(self):
+        return int(self.L.refh_digest2(self.h))
 
     def clear(self):
         self.L.refh_clear(self.h)

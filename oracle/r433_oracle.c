@@ -1463,3 +1463,40 @@ uint64_t orc_events_digest(uint8_t const *blob, size_t len, uint32_t *n_events)
         *n_events = cnt;
     return total;
 }
+
+/* Compact per-event checksum used by bench.py: FNV-1a 64 over {pkg, dev, ordinal, num_rows, free_row}
+ * and, per row, {bits, syncs, the ceil(bits/8) payload bytes}; summed over events mod 2^64.  The same
+ * function exists over a real bitbuffer_t in ref_harness.c and in the product's digest plugin. */
+uint64_t orc_events_digest2(uint8_t const *blob, size_t len, uint32_t *n_events)
+{
+    uint64_t total = 0;
+    uint32_t cnt = 0;
+    size_t at = 0;
+    while (at + sizeof(r433_evt_rec) <= len) {
+        r433_evt_rec h;
+        memcpy(&h, blob + at, sizeof(h));
+        if (h.total_bytes < sizeof(h) || at + h.total_bytes > len)
+            break;
+        uint64_t x = 1469598103934665603ull;
+        uint8_t const *k = blob + at + 4; /* pkg, dev, ordinal, num_rows, free_row = 12 bytes */
+        for (unsigned i = 0; i < 12; ++i)
+            x = (x ^ k[i]) * 1099511628211ull;
+        uint8_t const *src = blob + at + sizeof(h);
+        for (unsigned r = 0; r < h.num_rows; ++r) {
+            r433_row_rec rr;
+            memcpy(&rr, src, sizeof(rr));
+            for (unsigned i = 0; i < 4; ++i)
+                x = (x ^ src[i]) * 1099511628211ull;
+            unsigned nb = ((unsigned)rr.bits + 7) / 8;
+            for (unsigned i = 0; i < nb; ++i)
+                x = (x ^ (i < rr.nbytes ? src[sizeof(rr) + i] : 0)) * 1099511628211ull;
+            src += sizeof(rr) + ((rr.nbytes + 3u) & ~3u);
+        }
+        total += x;
+        cnt++;
+        at += h.total_bytes;
+    }
+    if (n_events)
+        *n_events = cnt;
+    return total;
+}

@@ -174,6 +174,8 @@ size_t orc_events_normalize(uint8_t *evt_blob, size_t len);
 /* FNV-1a 64 over an event stream after inflating every event to the reference bitbuffer image
  * {num_rows, free_row, bits[50], syncs[50], bb[50][128]} -- the "checksum of checksums". */
 uint64_t orc_events_digest(uint8_t const *evt_blob, size_t len, uint32_t *n_events);
+/* cheap variant over header + payload bytes only (what bench.py's decoder callback computes) */
+uint64_t orc_events_digest2(uint8_t const *evt_blob, size_t len, uint32_t *n_events);
 
 #ifdef __cplusplus
 }

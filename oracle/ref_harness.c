@@ -75,6 +75,8 @@ typedef struct harness {
     r_cfg_t *cfg;
     int call_real; /* run the reference decoders after recording */
     int record;    /* 0: digest only, 1: keep records */
+    int digest_mode; /* 0 none, 1 full 6604-byte image, 2 compact (header + payload bytes) */
+    uint64_t digest2;
     blob packages, events, returns;
     uint32_t stream, frame, pkg_count;
     uint64_t digest;
@@ -159,7 +161,19 @@ static int recording_decode(r_device *decoder, bitbuffer_t *bits)
     memcpy(key + 4, &dev, 2);
     memcpy(key + 6, &ord, 2);
     /* per-event FNV-1a, summed mod 2^64 so the total does not depend on call order */
-    h->digest += fnv(fnv(1469598103934665603ull, key, 8), bits, sizeof(*bits));
+    if (h->digest_mode == 1)
+        h->digest += fnv(fnv(1469598103934665603ull, key, 8), bits, sizeof(*bits));
+    else if (h->digest_mode == 2) {
+        uint64_t x = fnv(1469598103934665603ull, key, 8);
+        x = fnv(x, &bits->num_rows, 2);
+        x = fnv(x, &bits->free_row, 2);
+        for (unsigned r = 0; r < bits->num_rows && r < BITBUF_ROWS; ++r) {
+            x = fnv(x, &bits->bits_per_row[r], 2);
+            x = fnv(x, &bits->syncs_before_row[r], 2);
+            x = fnv(x, bits->bb[r], ((unsigned)bits->bits_per_row[r] + 7) / 8);
+        }
+        h->digest2 += x;
+    }
     h->digest_events++;
 
     if (h->record) {
@@ -221,6 +235,7 @@ void *refh_create(int const *protocols, int n_protocols, char const *flex_specs,
     h->cfg = cfg;
     h->call_real = call_real;
     h->record = record;
+    h->digest_mode = 1;
     h->digest = 0;
     cfg->report_time = REPORT_TIME_SAMPLES; /* src/rtl_433.c:1480-1483 for file input */
     cfg->report_meta = report_meta_level;
@@ -444,6 +459,16 @@ uint64_t refh_digest(void *hv, uint32_t *n_events, uint32_t *n_packages)
     return h->digest;
 }
 
+void refh_set_digest_mode(void *hv, int mode)
+{
+    ((harness *)hv)->digest_mode = mode;
+}
+
+uint64_t refh_digest2(void *hv)
+{
+    return ((harness *)hv)->digest2;
+}
+
 void refh_clear(void *hv)
 {
     harness *h = hv;
@@ -451,6 +476,7 @@ void refh_clear(void *hv)
     h->packages.count = h->events.count = 0;
     h->pkg_count = 0;
     h->digest = 0;
+    h->digest2 = 0;
     h->digest_events = 0;
 }
 

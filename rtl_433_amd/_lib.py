@@ -35,6 +35,14 @@ RDevice._fields_ = [
     ("decode_messages", C.c_uint), ("decode_fails", C.c_uint * 5), ("decode_ctx", C.c_void_p),
     ("output_ctx", C.c_void_p)]
 
+class DigestCtx(C.Structure):
+    _fields_ = [("sum", C.c_uint64), ("events", C.c_uint64)]
+
+
+class DispatchInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("stream", "package", "device", "ordinal", "package_type", "start_ago")]
+
+
 PACKAGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p)
 
 _lib = None
@@ -43,7 +51,8 @@ EXPORTS = [
     "r433_version", "r433_last_error", "r433_device_count", "r433_flow_cfg_default", "r433_level_db",
     "r433_batch_create", "r433_batch_destroy", "r433_batch_run", "r433_batch_packages", "r433_batch_events",
     "r433_batch_frame_sums", "r433_batch_device_events", "r433_batch_set_taps", "r433_batch_set_profiling",
-    "r433_batch_get_timing", "r433_batch_dispatch", "r433_envelope_detect", "r433_magnitude_est_cu8",
+    "r433_batch_get_timing", "r433_batch_dispatch", "r433_batch_dispatch_mt", "r433_dispatch_current",
+    "r433_plugin_digest_decode", "r433_envelope_detect", "r433_magnitude_est_cu8",
     "r433_magnitude_est_cs16",
 ]
 
@@ -85,6 +94,10 @@ def lib():
     L.r433_batch_get_timing.argtypes = [vp, C.POINTER(BatchTiming)]
     L.r433_batch_dispatch.restype = C.c_int
     L.r433_batch_dispatch.argtypes = [vp, vp, C.c_uint32, vp, vp]
+    L.r433_batch_dispatch_mt.restype = C.c_int
+    L.r433_batch_dispatch_mt.argtypes = [vp, vp, C.c_uint32, vp, vp, C.c_uint32]
+    L.r433_dispatch_current.restype = C.c_int
+    L.r433_dispatch_current.argtypes = [vp]
     for f in (L.r433_envelope_detect, L.r433_magnitude_est_cu8, L.r433_magnitude_est_cs16):
         f.restype = C.c_int
         f.argtypes = [vp, vp, C.c_uint32, vp, vp]

@@ -12,7 +12,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "r433_hip.h"
@@ -193,6 +195,7 @@ struct r433_batch {
     DevBuf<uint8_t> d_pkg_blob, d_events;
     PinBuf<uint32_t> h_scal, h_frame_sums;
     PinBuf<uint8_t> h_pkg_blob, h_events;
+    PinBuf<uint32_t> h_pkg_off, h_rec_off; // per package: byte offset of its first event / of its record
 
     uint32_t arena_stride = 0;
     uint32_t frames_cap = 0;
@@ -339,6 +342,8 @@ void r433_batch_destroy(r433_batch *b)
     b->h_frame_sums.release();
     b->h_pkg_blob.release();
     b->h_events.release();
+    b->h_pkg_off.release();
+    b->h_rec_off.release();
     if (b->ev_made)
         for (auto &e : b->ev)
             (void)hipEventDestroy(e);
@@ -534,7 +539,8 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
 
     if ((rc = b->d_pkg_blob.ensure(pkg_bytes + 16)) || (rc = b->h_pkg_blob.ensure(pkg_bytes + 16))
             || (rc = b->d_events.ensure(evt_bytes + 16)) || (rc = b->h_events.ensure(evt_bytes + 16))
-            || (rc = b->h_frame_sums.ensure((size_t)n_streams * frames_cap)))
+            || (rc = b->h_frame_sums.ensure((size_t)n_streams * frames_cap)) || (rc = b->h_pkg_off.ensure(max_pkgs + 1))
+            || (rc = b->h_rec_off.ensure(max_pkgs + 1)))
         return rc;
     if (total_pkgs) {
         launch_gather_packages(b->d_arena.p, b->arena_stride, b->d_dir_stream.p, b->d_dir_off.p, b->d_rec_off.p,
@@ -553,6 +559,11 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
         HIP_TRY(hipMemcpyAsync(b->h_pkg_blob.p, b->d_pkg_blob.p, pkg_bytes, hipMemcpyDeviceToHost, st));
     if (evt_bytes)
         HIP_TRY(hipMemcpyAsync(b->h_events.p, b->d_events.p, evt_bytes, hipMemcpyDeviceToHost, st));
+    if (total_pkgs) {
+        HIP_TRY(hipMemcpyAsync(b->h_rec_off.p, b->d_rec_off.p, total_pkgs * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        if (n_devs)
+            HIP_TRY(hipMemcpyAsync(b->h_pkg_off.p, b->d_pkg_off.p, total_pkgs * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(hipMemcpyAsync(b->h_frame_sums.p, b->d_frame_sums.p, (size_t)n_streams * frames_cap * sizeof(uint32_t),
             hipMemcpyDeviceToHost, st));
     if (b->profiling)
@@ -561,6 +572,11 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
     b->pkg_bytes = pkg_bytes;
     b->evt_bytes = evt_bytes;
     b->events_counted = false;
+    b->h_rec_off.p[total_pkgs] = (uint32_t)pkg_bytes;
+    b->h_pkg_off.p[total_pkgs] = (uint32_t)evt_bytes;
+    if (!n_devs)
+        for (uint32_t i = 0; i < total_pkgs; ++i)
+            b->h_pkg_off.p[i] = 0;
 
     if (b->profiling) {
         r433_batch_timing &t = b->last_timing;
@@ -669,88 +685,79 @@ void fill_levels(r433_flow_cfg const &cfg, r433_pulse_data &p)
     }
 }
 
-struct EvtRef {
-    uint32_t at; // byte offset of the record
+struct DevStats {
+    unsigned events = 0, ok = 0, messages = 0, fails[5] = {0, 0, 0, 0, 0};
 };
 
-} // namespace
+thread_local r433_dispatch_info g_current;
 
-int r433_batch_dispatch(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices, r433_package_fn pkg_cb,
-        void *user)
+// Replays packages [p0, p1).  Returns decoded event count or a negative error code.
+int dispatch_range(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices, r433_package_fn pkg_cb, void *user,
+        uint32_t p0, uint32_t p1, std::vector<DevStats> &stats, std::string &err)
 {
-    if (!b)
-        return fail(R433_EINVAL, "null batch");
-    if (n_devices != b->timing.size())
-        return fail(R433_EINVAL, "dispatch needs the %zu devices the engine was created with", b->timing.size());
-    if (!b->bits)
-        b->bits = (r433_bitbuffer *)calloc(1, sizeof(r433_bitbuffer));
-    if (!b->pulses)
-        b->pulses = (r433_pulse_data *)calloc(1, sizeof(r433_pulse_data));
-    r433_bitbuffer *bits = b->bits;
+    r433_bitbuffer *bits = (r433_bitbuffer *)calloc(1, sizeof(r433_bitbuffer));
+    r433_pulse_data *pd = pkg_cb ? (r433_pulse_data *)calloc(1, sizeof(r433_pulse_data)) : nullptr;
     uint8_t const *ev = b->h_events.p;
-    size_t const ev_len = b->evt_bytes;
     uint8_t const *pk = b->h_pkg_blob.p;
-
-    std::vector<uint32_t> first(n_devices, 0), count(n_devices, 0);
-    std::vector<uint32_t> touched;
-    std::vector<EvtRef> refs;
+    std::vector<uint32_t> first(n_devices, 0), count(n_devices, 0), touched, refs;
     int decoded = 0;
-    size_t eat = 0, pat = 0;
+    int rc = 0;
 
-    for (uint32_t pkg = 0; pkg < b->n_pkgs; ++pkg) {
+    for (uint32_t pkg = p0; pkg < p1 && rc == 0; ++pkg) {
         r433_pkg_rec ph;
-        memcpy(&ph, pk + pat, sizeof(ph));
+        memcpy(&ph, pk + b->h_rec_off.p[pkg], sizeof(ph));
         if (pkg_cb) {
-            r433_pulse_data &pd = *b->pulses;
-            memset(&pd, 0, sizeof(pd));
-            pd.offset = ph.offset;
-            pd.sample_rate = ph.sample_rate;
-            pd.start_ago = ph.start_ago;
-            pd.end_ago = ph.end_ago;
-            pd.num_pulses = ph.num_pulses;
-            int32_t const *pairs = (int32_t const *)(pk + pat + sizeof(ph));
+            memset(pd, 0, sizeof(*pd));
+            pd->offset = ph.offset;
+            pd->sample_rate = ph.sample_rate;
+            pd->start_ago = ph.start_ago;
+            pd->end_ago = ph.end_ago;
+            pd->num_pulses = ph.num_pulses;
+            int32_t const *pairs = (int32_t const *)(pk + b->h_rec_off.p[pkg] + sizeof(ph));
             for (uint32_t i = 0; i < ph.num_pulses && i < R433_MAX_PULSES; ++i) {
-                pd.pulse[i] = pairs[2 * i];
-                pd.gap[i] = pairs[2 * i + 1];
+                pd->pulse[i] = pairs[2 * i];
+                pd->gap[i] = pairs[2 * i + 1];
             }
-            pd.ook_low_estimate = ph.ook_low;
-            pd.ook_high_estimate = ph.ook_high;
-            pd.fsk_f1_est = ph.fsk_f1;
-            pd.fsk_f2_est = ph.fsk_f2;
-            fill_levels(b->cfg, pd);
-            pkg_cb(user, ph.stream, ph.type, &pd);
+            pd->ook_low_estimate = ph.ook_low;
+            pd->ook_high_estimate = ph.ook_high;
+            pd->fsk_f1_est = ph.fsk_f1;
+            pd->fsk_f2_est = ph.fsk_f2;
+            fill_levels(b->cfg, *pd);
+            pkg_cb(user, ph.stream, ph.type, pd);
         }
-        pat += ph.total_bytes;
 
         // index this package's events by device (they arrive sorted by device, then ordinal)
         refs.clear();
         touched.clear();
-        while (eat + sizeof(r433_evt_rec) <= ev_len) {
+        size_t eat = b->h_pkg_off.p[pkg];
+        size_t const eend = b->h_pkg_off.p[pkg + 1];
+        while (eat + sizeof(r433_evt_rec) <= eend) {
             r433_evt_rec eh;
             memcpy(&eh, ev + eat, sizeof(eh));
-            if (eh.pkg != pkg)
+            if (eh.pkg != pkg || eh.dev >= n_devices || eh.total_bytes < sizeof(eh) || eat + eh.total_bytes > eend) {
+                err = "corrupt event stream";
+                rc = R433_EHIP;
                 break;
-            if (eh.dev >= n_devices)
-                return fail(R433_EHIP, "event names device %u of %u", eh.dev, n_devices);
+            }
             if (count[eh.dev] == 0) {
                 first[eh.dev] = (uint32_t)refs.size();
                 touched.push_back(eh.dev);
             }
             count[eh.dev]++;
-            refs.push_back(EvtRef{(uint32_t)eat});
+            refs.push_back((uint32_t)eat);
             eat += eh.total_bytes;
         }
 
         int p_events = 0;
         for (uint32_t level : b->prio_levels) { // src/r_api.c:442-451: next level only while nothing decoded
-            if (p_events)
+            if (p_events || rc)
                 break;
             for (uint32_t dev : touched) {
-                if (b->timing[dev].priority != level)
+                if (b->timing[dev].priority != level || rc)
                     continue;
                 r433_r_device *rd = devices[dev];
                 for (uint32_t k = 0; k < count[dev]; ++k) {
-                    uint8_t const *rec = ev + refs[first[dev] + k].at;
+                    uint8_t const *rec = ev + refs[first[dev] + k];
                     r433_evt_rec eh;
                     memcpy(&eh, rec, sizeof(eh));
                     // inflate into the reference bitbuffer layout
@@ -768,23 +775,32 @@ int r433_batch_dispatch(r433_batch *b, r433_r_device *const *devices, uint32_t n
                     }
                     uint32_t used_rows = std::max<uint32_t>(eh.num_rows, eh.free_row);
 
+                    g_current.stream = ph.stream;
+                    g_current.package = pkg;
+                    g_current.device = dev;
+                    g_current.ordinal = eh.ordinal;
+                    g_current.package_type = ph.type;
+                    g_current.start_ago = ph.start_ago;
                     int ret = 0;
                     if (rd && rd->decode_fn)
                         ret = rd->decode_fn(rd, bits);
-                    if (rd) { // statistics, src/pulse_slicer.c:35-47
-                        rd->decode_events += 1;
-                        if (ret > 0) {
-                            rd->decode_ok += 1;
-                            rd->decode_messages += (unsigned)ret;
-                        }
-                        else if (ret >= R433_DECODE_FAIL_SANITY) {
-                            rd->decode_fails[-ret] += 1;
-                            ret = 0;
-                        }
-                        else {
-                            return fail(R433_EDECODER, "decoder \"%s\" gave invalid return value %d",
-                                    rd->name ? rd->name : "?", ret);
-                        }
+                    DevStats &ds = stats[dev]; // statistics, src/pulse_slicer.c:35-47
+                    ds.events += 1;
+                    if (ret > 0) {
+                        ds.ok += 1;
+                        ds.messages += (unsigned)ret;
+                    }
+                    else if (ret >= R433_DECODE_FAIL_SANITY) {
+                        ds.fails[-ret] += 1;
+                        ret = 0;
+                    }
+                    else {
+                        char buf[200];
+                        snprintf(buf, sizeof(buf), "decoder \"%s\" gave invalid return value %d",
+                                rd && rd->name ? rd->name : "?", ret);
+                        err = buf;
+                        rc = R433_EDECODER;
+                        break;
                     }
                     if (ret > 0)
                         p_events += ret;
@@ -801,7 +817,114 @@ int r433_batch_dispatch(r433_batch *b, r433_r_device *const *devices, uint32_t n
         for (uint32_t dev : touched)
             count[dev] = 0;
     }
+    free(bits);
+    free(pd);
+    return rc ? rc : decoded;
+}
+
+} // namespace
+
+int r433_dispatch_current(r433_dispatch_info *info)
+{
+    if (!info)
+        return fail(R433_EINVAL, "null argument");
+    *info = g_current;
+    return 0;
+}
+
+int r433_batch_dispatch_mt(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices, r433_package_fn pkg_cb,
+        void *user, uint32_t n_threads)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    if (n_devices != b->timing.size())
+        return fail(R433_EINVAL, "dispatch needs the %zu devices the engine was created with", b->timing.size());
+    uint32_t const np = b->n_pkgs;
+    if (n_threads < 1)
+        n_threads = 1;
+    if (n_threads > np)
+        n_threads = np ? np : 1;
+    std::vector<std::vector<DevStats>> stats(n_threads, std::vector<DevStats>(n_devices));
+    std::vector<int> results(n_threads, 0);
+    std::vector<std::string> errs(n_threads);
+    if (n_threads == 1) {
+        results[0] = dispatch_range(b, devices, n_devices, pkg_cb, user, 0, np, stats[0], errs[0]);
+    }
+    else {
+        // contiguous package ranges balanced by event bytes
+        std::vector<uint32_t> cut(n_threads + 1, np);
+        cut[0] = 0;
+        uint64_t const total = b->evt_bytes + np; // +1 per package so empty ones still spread
+        uint32_t t = 1;
+        for (uint32_t pkg = 0; pkg < np && t < n_threads; ++pkg) {
+            uint64_t w = (uint64_t)b->h_pkg_off.p[pkg] + pkg;
+            while (t < n_threads && w >= total * t / n_threads)
+                cut[t++] = pkg;
+        }
+        std::vector<std::thread> pool;
+        for (uint32_t i = 0; i < n_threads; ++i)
+            pool.emplace_back([&, i] {
+                results[i] = dispatch_range(b, devices, n_devices, pkg_cb, user, cut[i], cut[i + 1], stats[i], errs[i]);
+            });
+        for (auto &th : pool)
+            th.join();
+    }
+    int decoded = 0;
+    for (uint32_t i = 0; i < n_threads; ++i) {
+        if (results[i] < 0)
+            return fail(results[i], "%s", errs[i].c_str());
+        decoded += results[i];
+    }
+    for (uint32_t d = 0; d < n_devices; ++d) {
+        r433_r_device *rd = devices[d];
+        if (!rd)
+            continue;
+        for (uint32_t i = 0; i < n_threads; ++i) {
+            DevStats const &ds = stats[i][d];
+            rd->decode_events += ds.events;
+            rd->decode_ok += ds.ok;
+            rd->decode_messages += ds.messages;
+            for (int k = 0; k < 5; ++k)
+                rd->decode_fails[k] += ds.fails[k];
+        }
+    }
     return decoded;
+}
+
+int r433_batch_dispatch(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices, r433_package_fn pkg_cb,
+        void *user)
+{
+    return r433_batch_dispatch_mt(b, devices, n_devices, pkg_cb, user, 1);
+}
+
+// A decode_fn with the reference plugin signature that folds every bitbuffer it is handed into an
+// order-independent checksum (see r433_hip.h).  decode_ctx must point to a r433_digest_ctx.
+int r433_plugin_digest_decode(r433_r_device *decoder, r433_bitbuffer *bits)
+{
+    r433_digest_ctx *ctx = (r433_digest_ctx *)decoder->decode_ctx;
+    if (!ctx)
+        return R433_DECODE_ABORT_EARLY;
+    uint64_t x = 1469598103934665603ull;
+    auto mix = [&x](void const *p, size_t n) {
+        uint8_t const *q = (uint8_t const *)p;
+        for (size_t i = 0; i < n; ++i)
+            x = (x ^ q[i]) * 1099511628211ull;
+    };
+    uint32_t pkg = g_current.package;
+    uint16_t dev = (uint16_t)g_current.device, ord = (uint16_t)g_current.ordinal;
+    mix(&pkg, 4);
+    mix(&dev, 2);
+    mix(&ord, 2);
+    mix(&bits->num_rows, 2);
+    mix(&bits->free_row, 2);
+    for (unsigned r = 0; r < bits->num_rows && r < R433_BITBUF_ROWS; ++r) {
+        mix(&bits->bits_per_row[r], 2);
+        mix(&bits->syncs_before_row[r], 2);
+        mix(bits->bb[r], ((unsigned)bits->bits_per_row[r] + 7) / 8);
+    }
+    __atomic_fetch_add(&ctx->sum, x, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&ctx->events, 1ull, __ATOMIC_RELAXED);
+    return R433_DECODE_ABORT_LENGTH;
 }
 
 // ---- function-level seam ----

@@ -119,8 +119,36 @@ class BatchEngine:
         _lib.check(self.L.r433_batch_get_timing(self.h, C.byref(t)), "r433_batch_get_timing")
         return {n: getattr(t, n) for n, _ in t._fields_}
 
-    def dispatch(self, rdevices, pkg_cb=None, user=None):
+    def dispatch(self, rdevices, pkg_cb=None, user=None, n_threads=1):
         """rdevices: ctypes array of POINTER(RDevice) in registration order."""
         cb = C.cast(pkg_cb, C.c_void_p) if pkg_cb is not None else None
-        rc = self.L.r433_batch_dispatch(self.h, C.cast(rdevices, C.c_void_p), len(rdevices), cb, user)
-        return _lib.check(rc, "r433_batch_dispatch")
+        rc = self.L.r433_batch_dispatch_mt(self.h, C.cast(rdevices, C.c_void_p), len(rdevices), cb, user, n_threads)
+        return _lib.check(rc, "r433_batch_dispatch_mt")
+
+
+def make_rdevices(devs, decode_fn_addr=None, ctx_addr=None, names=None, protocols=None):
+    """Builds reference-layout r_device objects (include/r433_abi.h) for timing rows `devs`.
+    Returns (array of POINTER(RDevice), list of RDevice) -- keep both alive while dispatching."""
+    objs = []
+    for i, d in enumerate(devs):
+        r = _lib.RDevice()
+        r.protocol_num = int(protocols[i]) if protocols is not None else i + 1
+        r.name = (names[i] if names is not None else f"dev{i}").encode()
+        r.modulation = int(d["modulation"])
+        r.short_width = float(d["short_width"])
+        r.long_width = float(d["long_width"])
+        r.reset_limit = float(d["reset_limit"])
+        r.gap_limit = float(d["gap_limit"])
+        r.sync_width = float(d["sync_width"])
+        r.tolerance = float(d["tolerance"])
+        r.priority = int(d["priority"])
+        r.decode_fn = decode_fn_addr
+        r.decode_ctx = ctx_addr
+        objs.append(r)
+    arr = (C.POINTER(_lib.RDevice) * len(objs))(*[C.pointer(o) for o in objs])
+    return arr, objs
+
+
+def digest_plugin_addr():
+    """Address of the library's checksum decode_fn (r433_plugin_digest_decode)."""
+    return C.cast(_lib.lib().r433_plugin_digest_decode, C.c_void_p).value
