@@ -1,0 +1,39 @@
+"""Turns a rocprofv3 results .db (rocpd sqlite) into the plain-text per-kernel summary kept under profiles/."""
+import sqlite3
+import sys
+
+
+def main(db, out=None):
+    c = sqlite3.connect(db)
+    lines = []
+    cur = c.execute("select name, total_calls, total_duration, average, percentage from top_kernels")
+    lines.append(f"{'calls':>6} {'total_us':>12} {'avg_us':>12} {'pct':>7}  kernel   (durations are in microseconds)")
+    for name, calls, total, avg, pct in cur:
+        lines.append(f"{calls:>6} {total:>12.1f} {avg:>12.2f} {pct:>7.2f}  {name}")
+    try:
+        cur = c.execute("select name, min(vgpr_count), min(sgpr_count), min(lds_size), min(scratch_size), min(grid_x), min(workgroup_x) "
+                        "from kernels group by name")
+        lines.append("")
+        lines.append("per-dispatch resources: vgpr sgpr lds scratch grid_x wg_x  kernel")
+        for r in cur:
+            lines.append(f"{r[1]:>5} {r[2]:>5} {r[3]:>7} {r[4]:>6} {r[5]:>9} {r[6]:>5}  {r[0]}")
+    except sqlite3.Error as e:
+        lines.append(f"(no per-dispatch resource table: {e})")
+    try:
+        cur = c.execute("select name, count(*), avg(value), sum(value) from pmc_events group by name order by name")
+        rows = list(cur)
+        if rows:
+            lines.append("")
+            lines.append("PMC counters (name, samples, mean per dispatch, sum)")
+            for r in rows:
+                lines.append(f"{r[0]:<28} {r[1]:>6} {r[2]:>18.1f} {r[3]:>20.1f}")
+    except sqlite3.Error:
+        pass
+    text = "\n".join(lines) + "\n"
+    if out:
+        open(out, "w").write(text)
+    print(text)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
