@@ -58,13 +58,19 @@ EXPORTS = [
 
 
 def lib():
+    """The product library (HIP, gfx950).  There is no fallback: missing library == hard error."""
     global _lib
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run `python -m rtl_433_amd.build` (hipcc, gfx950). "
                            "rtl_433_amd has no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    _lib = bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def bind(L):
+    """Attach the C ABI prototypes of include/r433_hip.h to a loaded shared object."""
     vp = C.c_void_p
     L.r433_version.restype = C.c_int
     L.r433_last_error.restype = C.c_char_p
@@ -101,7 +107,6 @@ def lib():
     for f in (L.r433_envelope_detect, L.r433_magnitude_est_cu8, L.r433_magnitude_est_cs16):
         f.restype = C.c_int
         f.argtypes = [vp, vp, C.c_uint32, vp, vp]
-    _lib = L
     return L
 
 

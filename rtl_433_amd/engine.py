@@ -44,8 +44,10 @@ def flow_cfg(sample_size=2, samp_rate=250000, fpdm=0, enable_fm=1, use_mag_est=0
 
 
 class BatchEngine:
-    def __init__(self, cfg: FlowCfg, devs=None, profiling=False):
-        self.L = _lib.lib()
+    def __init__(self, cfg: FlowCfg, devs=None, profiling=False, library=None):
+        # `library` is for the test suite's emulator build of the same sources; the product always
+        # goes through _lib.lib(), which raises if librtl433hip.so is missing.
+        self.L = library if library is not None else _lib.lib()
         _lib.check(self.L.r433_device_count(), "r433_device_count")
         self.cfg = cfg
         self.devs = np.zeros(0, dtype=DEV_DTYPE) if devs is None else np.ascontiguousarray(devs, dtype=DEV_DTYPE)
@@ -67,6 +69,16 @@ class BatchEngine:
             self.close()
         except Exception:
             pass
+
+    def run_ptr(self, ptr, stride, n_streams, stream_bytes=None, stream=0):
+        """Raw form of run(): `ptr` is a device address, `stride` bytes between captures."""
+        sb = None
+        if stream_bytes is not None:
+            sb_arr = np.ascontiguousarray(stream_bytes, dtype=np.uint32)
+            assert len(sb_arr) == n_streams
+            sb = sb_arr.ctypes.data_as(C.c_void_p)
+        rc = self.L.r433_batch_run(self.h, C.c_void_p(ptr), stride, sb, n_streams, C.c_void_p(stream))
+        return _lib.check(rc, "r433_batch_run")
 
     def run(self, iq, stream_bytes=None, stream=None):
         """iq: CUDA tensor [n_streams, stride] of uint8 (cu8) or int16 (cs16), contiguous."""
