@@ -2,7 +2,7 @@
 
 Workload (BASELINE.json configs[1]): a batch of 1024 synthetic 250 kS/s cu8 OOK bursts of 65536
 samples per GPU (rtl_433_amd/synth.py, seeds rank*1024 + i), all 335 default r_device timing rows
-fanned out.  One step = one pass of the hot path over the batch: k_stream (IQ -> packages), slicer
+fanned out.  One step = one pass of the hot path over the batch: k_wave (IQ -> packages), slicer
 fan-out (count/scan/write), record copy to pinned host memory, and the host dispatch of every
 bitbuffer to the registered decode_fn plugins in reference order (the plugin is the library's checksum
 decode_fn, so a full-size run is parity-checked against the reference by one number).  Inputs are
@@ -171,9 +171,9 @@ def main():
                        "streams_per_gpu": n_streams, "samples_per_stream": n_samples, "sample_rate": 250000,
                        "decoders": len(devs), "host_dispatch_threads": threads,
                        "parallelism": f"captures sharded over {world} GPU(s), no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_stream<2> (IQ -> packages)", "achieved": round(achieved, 2),
+            "roofline": {"bound": "hbm", "kernel": "k_wave<2> (IQ -> packages)", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None},
-            "breakdown_ms": {"k_stream": round(float(np.mean(det_ms)), 3), "gpu_total_incl_d2h": round(float(np.mean(tot_ms)), 3),
+            "breakdown_ms": {"k_wave": round(float(np.mean(det_ms)), 3), "gpu_total_incl_d2h": round(float(np.mean(tot_ms)), 3),
                              "host_dispatch": round(float(np.mean(disp_s)) * 1e3, 3)},
             "packages_per_step": int(n_pkgs), "events_per_step": int(ctx.events),
         }

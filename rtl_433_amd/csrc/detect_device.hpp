@@ -1,5 +1,7 @@
-// detect_device.hpp -- OOK level-tracking pulse detector with the embedded FSK sub-detectors,
-// one capture per lane, all state in registers.
+// detect_device.hpp -- OOK level-tracking pulse detector with the embedded FSK sub-detectors:
+// the exact, general per-sample step.  One capture per wavefront: lane 0 owns the detector state and
+// runs these functions; the kernel (stream_kernels.hip) uses the whole wavefront to skip over
+// samples that provably cannot change the state machine and comes here for everything else.
 //
 // Behaviour follows the reference's pulse_detect_package() (src/pulse_detect.c:199-483),
 // pulse_detect_fsk_classic/minmax/wrap_up (src/pulse_detect_fsk.c:34-221) and pulse_data_shift
@@ -8,8 +10,8 @@
 // in the idle state, "eop on spurious pulse" is forgotten at call boundaries.
 //
 // Output: r433_pkg_rec records (include/r433_records.h) appended to a per-capture arena in HBM.
-// The open OOK package grows in place at the arena cursor; the FSK candidate lives in a
-// per-capture scratch ring because the reference keeps it alive next to the OOK package.
+// The open OOK package grows in place at the arena cursor; the FSK candidate lives in an LDS
+// ring because the reference keeps it alive next to the OOK package.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -48,7 +50,7 @@ struct DetLane {
     int eop_spurious;
     // arena
     uint8_t *arena;
-    int2 *fsk_ring;
+    int2 *fsk_ring;     // LDS, R433_PD_MAX_PULSES entries
     uint32_t arena_cap;
     uint32_t cursor;    // bytes of finished records
     uint32_t n_pkgs;
@@ -142,9 +144,7 @@ __device__ __forceinline__ int emit_ook(DetLane &d, DetCfg const &c, int len, in
     return R433_PKG_OOK;
 }
 
-// Out-of-line bulk moves take plain pointers so that DetLane never has its address taken and
-// stays in registers.
-__device__ __noinline__ void move_pairs(int2 *dst, int2 const *src, uint32_t n)
+__device__ __forceinline__ void move_pairs(int2 *dst, int2 const *src, uint32_t n)
 {
     for (uint32_t i = 0; i < n; ++i)
         dst[i] = src[i];

@@ -1,13 +1,28 @@
-// stream_kernels.hip -- the IQ -> pulse-package kernel: one capture per lane.
+// stream_kernels.hip -- the IQ -> pulse-package kernel: one capture per wavefront.
 //
-// A wavefront owns 64 captures.  Per tile it pulls 64 samples of each of its captures from HBM
-// with 16-byte-per-lane loads (one or two full 128-byte lines per capture and tile, nothing
-// fetched twice), parks them transposed in LDS, and then every lane walks its own capture
-// serially: envelope -> first-order low-pass -> FM discriminator + low-pass -> OOK/FSK pulse
-// detector, all carried in registers with the reference's exact integer semantics (the three
-// recurrences truncate, so they cannot be re-associated -- see DESIGN.md).  Packages leave as
-// r433_pkg_rec records in a per-capture arena.  The next tile's loads are issued before the
-// current tile is consumed so HBM latency hides behind the ~100 VALU ops per sample.
+// A wavefront walks its capture in tiles of 2048 samples and runs three phases per tile:
+//
+//   A  sample-parallel   16-byte-per-lane coalesced IQ loads (issued one tile ahead), envelope and FM
+//                        discriminator for 8 consecutive samples per lane, parked in LDS.
+//   B  chunk-parallel    the two truncating first-order low-passes.  Lane j owns samples
+//                        [32j, 32j+32) of the tile.  The recurrences are not associative, so instead of
+//                        a scan every lane re-runs the 96 samples before its chunk from BOTH extreme
+//                        carries: each step is a monotone map of the carry, the filter contracts, and
+//                        when the two tracks meet the carry is exact whatever the history was.  Lanes
+//                        whose tracks did not meet (constant input stalls on several fixed points) are
+//                        resolved from their left neighbour -- in O(1) when the chunk provably maps
+//                        every candidate carry to itself, by an exact re-run otherwise.  Nothing is
+//                        assumed: a lane only publishes samples computed from a proven carry.
+//   C  state machine     the OOK/FSK pulse detector.  Lane 0 owns the detector state.  The wavefront
+//                        ballots over 64 samples at a time to find the next sample that can possibly
+//                        change the state machine (a pulse start while idle, a falling edge inside a
+//                        pulse, a rising edge or the end-of-package count inside a gap); lane 0 runs a
+//                        lean recurrence over the samples in between (noise-floor chase, level and
+//                        carrier averages, counters) and the exact general step (detect_device.hpp)
+//                        on the candidates.
+//
+// Packages leave as r433_pkg_rec records in a per-capture arena.  Frame semantics of the file reader
+// (one push_sdr_flow call per 262144 input bytes) are reproduced at their exact sample positions.
 //
 // Replaces, for file input: envelope_detect / magnitude_est_* (reference src/baseband.c:36-110),
 // baseband_low_pass_filter (:145-169), baseband_demod_FM(_cs16) (:210-366), the frame loop of
@@ -19,251 +34,653 @@ namespace r433 {
 
 namespace {
 
-constexpr int kTile = 64; // samples per capture per tile
+constexpr int kChunk = 32;          // samples per lane in phase B
+constexpr int kTile = 64 * kChunk;  // samples per tile
+constexpr int kWarmChunks = 3;      // 96 warm-up samples: 0.854^96 * 2^16 < 1, 0.727^96 * 2^32 < 1
+constexpr int kRow = 512;           // samples per phase-A row (8 per lane)
+constexpr int kRows = kTile / kRow;
+constexpr int kPitch16 = kChunk * 2 + 16;  // LDS pitch of a chunk of 16-bit samples: conflict-free b128 per lane
+constexpr int kPitch32 = kChunk * 4 + 16;
 
-template <int SS> struct TileGeom {
-    static constexpr int row_bytes = kTile * SS;        // 128 (cu8) / 256 (cs16)
-    static constexpr int row_pitch = row_bytes + 16;    // +16 B: conflict-free ds_read_b128 down a column
-    static constexpr int lanes_per_row = row_bytes / 16;
-    static constexpr int rows_per_load = 64 / lanes_per_row;
-    static constexpr int n_loads = 64 / rows_per_load;  // 8 (cu8) / 16 (cs16)
-    static constexpr int vecs_per_row = row_bytes / 16;
-    static constexpr int samples_per_vec = 16 / SS;
-};
+__device__ __forceinline__ int rl0(int v)
+{
+    return __builtin_amdgcn_readlane(v, 0);
+}
 
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+__device__ __forceinline__ int wave_sum(int v)
 {
     for (int o = 32; o > 0; o >>= 1)
-        v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+        v += __shfl_xor(v, o, 64);
     return v;
 }
 
-struct LaneCtx {
-    DetLane det;
-    DetCfg cfg;
-    FmLane fm;
-    int lpf_y, lpf_x;
-    uint64_t input_pos;
-    uint32_t frame;
-    uint32_t fsum;
-    int dc;   // data_counter within the current frame
-    int flen; // length of the current frame
-};
-
-template <int SS>
-__device__ __forceinline__ void process_sample(LaneCtx &L, StreamParams const &p, uint32_t s, uint32_t idx,
-        uint32_t my_n, int vi, int vq)
+__device__ __forceinline__ int ld16(uint8_t const *buf, int i)
 {
-    if (L.dc == 0) { // a new frame == a new push_sdr_flow call
-        uint32_t remaining = my_n - idx;
-        L.flen = (int)min(remaining, p.frame_samples);
-        if (p.frame_min_high)
-            L.cfg.min_high = p.frame_min_high[(uint64_t)s * p.frames_cap + min(L.frame, p.frames_cap - 1)];
-        L.lpf_x = (int)(int16_t)L.lpf_x; // the filter state keeps x[-1] in an int16 slot (baseband.c:167)
-        L.fsum = 0;
-        det_call_entry(L.det, L.cfg, L.flen, 0);
-    }
-    uint32_t env;
-    if (SS == 2)
-        env = p.use_mag ? env_mag_cu8((uint32_t)vi, (uint32_t)vq) : env_amp_cu8((uint32_t)vi, (uint32_t)vq);
-    else
-        env = env_mag_cs16(vi, vq);
-    L.fsum += env;
-    int am = lpf_step(L.lpf_y, (int)env, L.lpf_x);
-    L.lpf_y = am;
-    L.lpf_x = (int)env;
-    int fm;
-    if (p.enable_fm)
-        fm = SS == 2 ? fm_step_cu8(L.fm, (uint32_t)vi, (uint32_t)vq, p.a16, p.b16) : fm_step_cs16(L.fm, vi, vq, p.a32, p.b32);
-    else
-        fm = (int)(int16_t)env; // buf.fm aliases the raw envelope (reference include/r_private.h:32-36)
-
-    if (p.tap_am) {
-        uint64_t o = (uint64_t)s * p.tap_stride + L.input_pos + (uint64_t)L.dc;
-        p.tap_env[o] = (uint16_t)env;
-        p.tap_am[o] = (int16_t)am;
-        p.tap_fm[o] = (int16_t)fm;
-    }
-
-    int r = det_step(L.det, L.cfg, am, fm, L.flen, L.dc, L.input_pos, L.frame);
-    if (r) { // package returned: the next call starts at the same sample, in the idle state
-        det_call_entry(L.det, L.cfg, L.flen, L.dc);
-        det_idle(L.det, L.cfg, am, L.flen, L.dc, L.input_pos);
-    }
-    L.dc += 1;
-    if (L.dc == L.flen) {
-        if (p.frame_sums && L.frame < p.frames_cap)
-            p.frame_sums[(uint64_t)s * p.frames_cap + L.frame] = L.fsum;
-        L.input_pos += (uint64_t)L.flen;
-        L.frame += 1;
-        L.dc = 0;
-    }
+    return (int)*(int16_t const *)(buf + (i >> 5) * kPitch16 + (i & 31) * 2);
 }
 
-template <int SS> __global__ __launch_bounds__(64) void k_stream(StreamParams p)
+// ---- phase B: one low-pass, both extreme tracks ----
+
+// AM and cu8-FM filters: 16-bit state, y' = (a*y + k) >> 14 narrowed to int16 (src/baseband.c:161-163, 263)
+struct Lp16 {
+    int a;
+    __device__ __forceinline__ int raw(int y, int k) const { return (a * y + k) >> 14; }
+};
+
+struct Track16 {
+    int lo, hi;
+    bool ok; // no int16 wrap on either track so far: the sandwich argument holds
+
+    __device__ __forceinline__ void step(Lp16 const &f, int k)
+    {
+        int v0 = f.raw(lo, k), v1 = f.raw(hi, k);
+        if (lo != hi) // a proven carry may wrap like the reference does; an interval may not
+            ok = ok && v0 == (int)(int16_t)v0 && v1 == (int)(int16_t)v1;
+        lo = (int)(int16_t)min(v0, v1);
+        hi = (int)(int16_t)max(v0, v1);
+    }
+    __device__ __forceinline__ bool exact() const { return ok && lo == hi; }
+};
+
+// cs16-FM filter: 32-bit state in Q30, y' = (a*y + k) >> 30 truncated to int32 (src/baseband.c:357)
+struct Lp32 {
+    long long a;
+    __device__ __forceinline__ long long raw(int y, long long k) const { return (a * (long long)y + k) >> 30; }
+};
+
+struct Track32 {
+    int lo, hi;
+    bool ok;
+
+    __device__ __forceinline__ void step(Lp32 const &f, long long k)
+    {
+        long long v0 = f.raw(lo, k), v1 = f.raw(hi, k);
+        if (lo != hi)
+            ok = ok && v0 == (long long)(int)v0 && v1 == (long long)(int)v1;
+        long long a = v0 < v1 ? v0 : v1, b = v0 < v1 ? v1 : v0;
+        lo = (int)a;
+        hi = (int)b;
+    }
+    __device__ __forceinline__ bool exact() const { return ok && lo == hi; }
+};
+
+// what a lane knows about one filter over its chunk after the first pass
+struct ChunkStatus {
+    bool start_known; // carry at chunk start proven (outputs published)
+    bool end_known;   // carry at chunk end proven
+    bool ident;       // every carry in [lo0, hi0] is a fixed point of every step of the chunk
+    int lo0, hi0;     // carry interval at chunk start
+    int y_end;
+};
+
+template <int SS> struct Geom {
+    static constexpr int f_bytes = SS == 2 ? 2 : 4;
+    static constexpr int f_pitch = SS == 2 ? kPitch16 : kPitch32;
+    static constexpr int loads = SS == 2 ? kRows : 2 * kRows; // uint4 per lane per tile
+};
+
+template <int SS> __global__ __launch_bounds__(64) void k_wave(StreamParams p)
 {
-    using G = TileGeom<SS>;
-    __shared__ __attribute__((aligned(16))) uint8_t tile[64 * G::row_pitch];
+    using G = Geom<SS>;
+    __shared__ __attribute__((aligned(16))) uint8_t s_env[64 * kPitch16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_f[64 * G::f_pitch];
+    __shared__ __attribute__((aligned(16))) uint8_t s_am[64 * kPitch16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_fm[64 * kPitch16];
+    __shared__ int2 s_ring[R433_PD_MAX_PULSES];
+    __shared__ int s_cmax[64], s_cmin[64];
 
     int const lane = (int)threadIdx.x;
-    uint32_t const s0 = blockIdx.x * 64u;
-    uint32_t const s = s0 + (uint32_t)lane;
-    bool const active = s < p.n_streams;
-    uint32_t const my_bytes = active ? (p.stream_bytes ? p.stream_bytes[s] : p.uniform_bytes) : 0u;
+    uint32_t const s = blockIdx.x;
+    uint32_t const my_bytes = p.stream_bytes ? p.stream_bytes[s] : p.uniform_bytes;
     uint32_t const my_n = my_bytes / SS;
-    uint32_t const n_tiles = (wave_max_u32(my_n) + kTile - 1) / kTile;
+    uint32_t const n_tiles = (my_n + kTile - 1) / kTile;
+    uint8_t const *const iq = p.iq + (uint64_t)s * p.stride_bytes;
+    uint32_t const F = p.frame_samples;
 
-    // ---- lane state ----
-    LaneCtx L;
-    L.cfg = p.det;
-    L.det.arena = p.arena + (uint64_t)(active ? s : 0) * p.arena_stride;
-    L.det.fsk_ring = p.fsk_ring + (uint64_t)(active ? s : 0) * R433_PD_MAX_PULSES;
-    L.det.arena_cap = p.arena_stride;
-    L.det.stream = s;
-    L.dc = 0;
-    L.flen = 0;
-    L.fsum = 0;
-    if (active && (p.flags & RUN_CONTINUE)) {
-        StreamState const &S = p.state[s];
-        L.lpf_y = S.lpf_y;
-        L.lpf_x = S.lpf_x;
-        L.fm = FmLane{S.fm_xr, S.fm_xi, S.fm_xf, S.fm_yf};
-        L.det.state = S.state;
-        L.det.run = S.run;
-        L.det.max_pulse = S.max_pulse;
-        L.det.lead_in = S.lead_in;
-        L.det.low = S.low;
-        L.det.high = S.high;
-        L.det.f_run = S.f_run;
-        L.det.f_state = S.f_state;
-        L.det.f_f1 = S.f_f1;
-        L.det.f_f2 = S.f_f2;
-        L.det.f_vmax = S.f_vmax;
-        L.det.f_vmin = S.f_vmin;
-        L.det.f_skip = S.f_skip;
-        L.det.ook_num = S.ook_num;
-        L.det.cur_pulse = S.cur_pulse;
-        L.det.ook_f1 = S.ook_f1;
-        L.det.fsk_num = S.fsk_num;
-        L.det.start_ago = S.start_ago;
-        L.det.offset = S.offset;
-        L.det.fsk_offset = S.fsk_offset;
-        L.input_pos = S.input_pos;
-        L.frame = S.frame;
-        L.det.cursor = S.cursor;
-        L.det.n_pkgs = S.n_pkgs;
-        L.det.overflow = S.overflow;
-        L.det.eop_spurious = 0;
-    }
-    else {
-        det_reset(L.det);
-        L.lpf_y = L.lpf_x = 0;
-        L.fm = FmLane{0, 0, 0, 0};
-        L.input_pos = 0;
-        L.frame = 0;
-        L.det.cursor = 0;
-        L.det.n_pkgs = 0;
-        L.det.overflow = 0;
-    }
+    // ---- detector (lane 0 is the owner; the other lanes carry dead copies) ----
+    DetLane det;
+    DetCfg cfg = p.det;
+    det_reset(det);
+    det.arena = p.arena + (uint64_t)s * p.arena_stride;
+    det.fsk_ring = s_ring;
+    det.arena_cap = p.arena_stride;
+    det.stream = s;
+    det.cursor = 0;
+    det.n_pkgs = 0;
+    det.overflow = 0;
+    // frame bookkeeping, tracked identically by every lane
+    uint64_t input_pos = 0;
+    uint32_t frame = 0;
+    int dc = 0, flen = 0;
 
-    // ---- cooperative tile loads: instruction k covers rows_per_load captures x row_bytes ----
-    int const ld_row = lane / G::lanes_per_row;
-    int const ld_col = (lane % G::lanes_per_row) * 16;
-    uint4 pf[G::n_loads];
-    auto issue_loads = [&](uint32_t t) {
+    // ---- filter carries across tiles (wave-uniform) ----
+    int carry_ya = 0, carry_xa = 0;          // AM low-pass: y[-1], x[-1]
+    int carry_yf = 0, carry_ff = 0;          // FM low-pass: y[-1], discriminator[-1]
+    int carry_i = 0, carry_q = 0;            // last IQ sample, centred
+    Lp16 const lp_am{kLpfA};
+    Lp16 const lp_fm16{p.a16};
+    Lp32 const lp_fm32{p.a32};
+
+    uint4 pf[G::loads];
+    auto issue_loads = [&](uint32_t tile) {
 #pragma unroll
-        for (int k = 0; k < G::n_loads; ++k) {
-            uint32_t row = (uint32_t)(k * G::rows_per_load + ld_row);
-            uint32_t rs = s0 + row;
-            uint64_t off = (uint64_t)t * G::row_bytes + (uint64_t)ld_col;
+        for (int k = 0; k < G::loads; ++k) {
+            uint64_t samp = (uint64_t)tile * kTile + (uint64_t)(SS == 2 ? k : k / 2) * kRow + (uint64_t)lane * 8;
+            uint64_t off = samp * SS + (SS == 2 ? 0 : (k & 1) * 16);
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (rs < p.n_streams && off + 16 <= p.stride_bytes)
-                v = *(uint4 const *)(p.iq + (uint64_t)rs * p.stride_bytes + off);
+            if (tile < n_tiles && off + 16 <= p.stride_bytes)
+                v = *(uint4 const *)(iq + off);
             pf[k] = v;
         }
     };
+    issue_loads(0);
 
-    if (n_tiles > 0)
-        issue_loads(0);
-    for (uint32_t t = 0; t < n_tiles; ++t) {
+    for (uint32_t tile = 0; tile < n_tiles; ++tile) {
+        uint32_t const t0 = tile * kTile;                     // absolute sample index of the tile
+        int const n_t = (int)min((uint32_t)kTile, my_n - t0); // valid samples in it
+
+        // ================= phase A: envelope + discriminator, 8 samples per lane and row =================
+        __syncthreads(); // previous tile's readers are done with the LDS buffers
 #pragma unroll
-        for (int k = 0; k < G::n_loads; ++k) {
-            int row = k * G::rows_per_load + ld_row;
-            *(uint4 *)(tile + row * G::row_pitch + ld_col) = pf[k];
-        }
-        __syncthreads();
-        if (t + 1 < n_tiles)
-            issue_loads(t + 1);
-
-        uint32_t const base = t * kTile;
-        if (base < my_n) {
-#pragma unroll 1
-            for (int v = 0; v < G::vecs_per_row; ++v) {
-                uint4 w = *(uint4 const *)(tile + lane * G::row_pitch + v * 16);
-#pragma unroll 1
-                for (int j = 0; j < G::samples_per_vec; ++j) {
-                    uint32_t idx = base + (uint32_t)(v * G::samples_per_vec + j);
-                    int vi, vq;
-                    if (SS == 2) { // one sample = low 16 bits; then shift the 128-bit vector down
-                        vi = (int)(w.x & 0xffu);
-                        vq = (int)((w.x >> 8) & 0xffu);
-                        w.x = __builtin_amdgcn_alignbit(w.y, w.x, 16);
-                        w.y = __builtin_amdgcn_alignbit(w.z, w.y, 16);
-                        w.z = __builtin_amdgcn_alignbit(w.w, w.z, 16);
-                        w.w >>= 16;
+        for (int r = 0; r < kRows; ++r) {
+            uint32_t wd[8];
+            if (SS == 2) {
+                uint4 w = pf[r];
+                wd[0] = w.x & 0xffffu, wd[1] = w.x >> 16, wd[2] = w.y & 0xffffu, wd[3] = w.y >> 16;
+                wd[4] = w.z & 0xffffu, wd[5] = w.z >> 16, wd[6] = w.w & 0xffffu, wd[7] = w.w >> 16;
+            }
+            else {
+                uint4 w0 = pf[2 * r], w1 = pf[2 * r + 1];
+                wd[0] = w0.x, wd[1] = w0.y, wd[2] = w0.z, wd[3] = w0.w;
+                wd[4] = w1.x, wd[5] = w1.y, wd[6] = w1.z, wd[7] = w1.w;
+            }
+            int const prev_w = __shfl_up((int)wd[7], 1, 64);
+            int pi_, pq_;
+            if (lane == 0) {
+                pi_ = carry_i;
+                pq_ = carry_q;
+            }
+            else if (SS == 2) {
+                pi_ = (prev_w & 0xff) - 128;
+                pq_ = ((prev_w >> 8) & 0xff) - 128;
+            }
+            else {
+                pi_ = (int)(int16_t)(prev_w & 0xffff);
+                pq_ = (int)(int16_t)((uint32_t)prev_w >> 16);
+            }
+            uint32_t ev[8];
+            int fv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int ci, cq; // centred sample as the FM demodulator sees it
+                if (SS == 2) {
+                    uint32_t bi = wd[j] & 0xffu, bq = (wd[j] >> 8) & 0xffu;
+                    ev[j] = p.use_mag ? env_mag_cu8(bi, bq) : env_amp_cu8(bi, bq);
+                    ci = (int)bi - 128;
+                    cq = (int)bq - 128;
+                }
+                else {
+                    ci = (int)(int16_t)(wd[j] & 0xffffu);
+                    cq = (int)(int16_t)(wd[j] >> 16);
+                    ev[j] = env_mag_cs16(ci, cq);
+                }
+                if (p.enable_fm) {
+                    if (SS == 2) {
+                        int dot = ci * pi_ + cq * pq_;
+                        int crs = cq * pi_ - ci * pq_;
+                        fv[j] = atan2_q15(crs, dot);
                     }
                     else {
-                        vi = (int)(int16_t)(w.x & 0xffffu);
-                        vq = (int)(int16_t)(w.x >> 16);
-                        w.x = w.y;
-                        w.y = w.z;
-                        w.z = w.w;
+                        long long dot = (long long)ci * pi_ + (long long)cq * pq_;
+                        long long crs = (long long)cq * pi_ - (long long)ci * pq_;
+                        fv[j] = atan2_q31((int)crs, (int)dot);
                     }
-                    if (idx < my_n)
-                        process_sample<SS>(L, p, s, idx, my_n, vi, vq);
+                }
+                else {
+                    fv[j] = 0;
+                }
+                pi_ = ci;
+                pq_ = cq;
+            }
+            // the row's last sample is the next row's (or tile's) predecessor
+            int const last_w = __builtin_amdgcn_readlane((int)wd[7], 63);
+            if (SS == 2) {
+                carry_i = (last_w & 0xff) - 128;
+                carry_q = ((last_w >> 8) & 0xff) - 128;
+            }
+            else {
+                carry_i = (int)(int16_t)(last_w & 0xffff);
+                carry_q = (int)(int16_t)((uint32_t)last_w >> 16);
+            }
+            int const chunk = r * (kRow / kChunk) + (lane >> 2);
+            int const sub = lane & 3; // 8-sample group inside the chunk
+            *(uint4 *)(s_env + chunk * kPitch16 + sub * 16) = make_uint4(ev[0] | (ev[1] << 16), ev[2] | (ev[3] << 16),
+                    ev[4] | (ev[5] << 16), ev[6] | (ev[7] << 16));
+            if (SS == 2) {
+                *(uint4 *)(s_f + chunk * G::f_pitch + sub * 16) = make_uint4(((uint32_t)fv[0] & 0xffffu) | ((uint32_t)fv[1] << 16),
+                        ((uint32_t)fv[2] & 0xffffu) | ((uint32_t)fv[3] << 16), ((uint32_t)fv[4] & 0xffffu) | ((uint32_t)fv[5] << 16),
+                        ((uint32_t)fv[6] & 0xffffu) | ((uint32_t)fv[7] << 16));
+            }
+            else {
+                *(uint4 *)(s_f + chunk * G::f_pitch + sub * 32) = make_uint4((uint32_t)fv[0], (uint32_t)fv[1], (uint32_t)fv[2], (uint32_t)fv[3]);
+                *(uint4 *)(s_f + chunk * G::f_pitch + sub * 32 + 16) = make_uint4((uint32_t)fv[4], (uint32_t)fv[5], (uint32_t)fv[6], (uint32_t)fv[7]);
+            }
+            if (p.tap_env) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    int idx = r * kRow + lane * 8 + j;
+                    if (idx < n_t)
+                        p.tap_env[(uint64_t)s * p.tap_stride + t0 + (uint32_t)idx] = (uint16_t)ev[j];
                 }
             }
         }
+        issue_loads(tile + 1); // in flight while phases B and C run
         __syncthreads();
+
+        // ================= phase B: the two low-passes, lane = chunk of 32 samples =================
+        int const cs = lane * kChunk;                       // chunk start inside the tile
+        int const cnt = max(0, min(kChunk, n_t - cs));      // valid samples of my chunk
+        int const first = max(0, lane - kWarmChunks);       // first chunk I read
+        bool const from_carry = lane <= kWarmChunks;        // my warm-up reaches the tile start: exact carry
+        Track16 ta, tf16;
+        Track32 tf32;
+        int xa1, ff1; // previous envelope / discriminator sample
+        if (from_carry) {
+            ta.lo = ta.hi = carry_ya;
+            tf16.lo = tf16.hi = carry_yf;
+            tf32.lo = tf32.hi = carry_yf;
+            xa1 = carry_xa;
+            ff1 = carry_ff;
+        }
+        else {
+            ta.lo = -32768, ta.hi = 32767;
+            tf16.lo = -32768, tf16.hi = 32767;
+            tf32.lo = INT32_MIN, tf32.hi = INT32_MAX;
+            xa1 = (int)*(uint16_t const *)(s_env + (first - 1) * kPitch16 + (kChunk - 1) * 2);
+            ff1 = SS == 2 ? (int)*(int16_t const *)(s_f + (first - 1) * G::f_pitch + (kChunk - 1) * 2)
+                          : *(int const *)(s_f + (first - 1) * G::f_pitch + (kChunk - 1) * 4);
+        }
+        ta.ok = tf16.ok = tf32.ok = true;
+
+        ChunkStatus sa, sf; // AM, FM
+        sa.start_known = sf.start_known = false;
+        sa.ident = sf.ident = true;
+        sa.lo0 = sa.hi0 = sf.lo0 = sf.hi0 = 0;
+        int csum = 0;                       // envelope sum of my chunk (frame average)
+        int cmax = -0x7fffffff, cmin = 0x7fffffff;
+
+#pragma unroll 1
+        for (int q = 0; q <= kWarmChunks; ++q) {
+            int const c = lane - kWarmChunks + q; // chunk being read
+            bool const main_run = q == kWarmChunks;
+            if (c < 0)
+                continue;
+            // a frame starts here: the AM filter state keeps x[-1] in an int16 slot (baseband.c:166-168)
+            if ((t0 + (uint32_t)c * kChunk) % F == 0)
+                xa1 = (int)(int16_t)xa1;
+            if (main_run) {
+                sa.start_known = ta.exact();
+                sa.lo0 = ta.lo, sa.hi0 = ta.hi;
+                if (SS == 2) {
+                    sf.start_known = tf16.exact();
+                    sf.lo0 = tf16.lo, sf.hi0 = tf16.hi;
+                }
+                else {
+                    sf.start_known = tf32.exact();
+                    sf.lo0 = tf32.lo, sf.hi0 = tf32.hi;
+                }
+            }
+            int const lim = main_run ? cnt : kChunk;
+#pragma unroll 1
+            for (int g = 0; g < kChunk / 8; ++g) {
+                uint4 const e4 = *(uint4 const *)(s_env + c * kPitch16 + g * 16);
+                uint32_t const ew[4] = {e4.x, e4.y, e4.z, e4.w};
+                uint4 f4a = make_uint4(0, 0, 0, 0), f4b = make_uint4(0, 0, 0, 0);
+                if (p.enable_fm) {
+                    if (SS == 2) {
+                        f4a = *(uint4 const *)(s_f + c * G::f_pitch + g * 16);
+                    }
+                    else {
+                        f4a = *(uint4 const *)(s_f + c * G::f_pitch + g * 32);
+                        f4b = *(uint4 const *)(s_f + c * G::f_pitch + g * 32 + 16);
+                    }
+                }
+                uint32_t const fw[8] = {f4a.x, f4a.y, f4a.z, f4a.w, f4b.x, f4b.y, f4b.z, f4b.w};
+                uint32_t oa[4] = {0, 0, 0, 0}, of[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    int const x = (int)((ew[u >> 1] >> ((u & 1) * 16)) & 0xffffu);
+                    bool const live = g * 8 + u < lim;
+                    if (live) {
+                        int const ka = kLpfB * (x + xa1);
+                        int const alo = ta.lo, ahi = ta.hi;
+                        ta.step(lp_am, ka);
+                        xa1 = x;
+                        int fm_out;
+                        if (p.enable_fm) {
+                            if (SS == 2) {
+                                int const f = (int)(int16_t)((fw[u >> 1] >> ((u & 1) * 16)) & 0xffffu);
+                                int const kf = p.b16 * (f + ff1);
+                                int const flo = tf16.lo, fhi = tf16.hi;
+                                tf16.step(lp_fm16, kf);
+                                ff1 = f;
+                                fm_out = tf16.lo;
+                                if (main_run)
+                                    sf.ident = sf.ident && tf16.lo == flo && tf16.hi == fhi;
+                            }
+                            else {
+                                int const f = (int)fw[u];
+                                long long const kf = p.b32 * ((long long)f + ff1);
+                                int const flo = tf32.lo, fhi = tf32.hi;
+                                tf32.step(lp_fm32, kf);
+                                ff1 = f;
+                                fm_out = (int)(int16_t)(tf32.lo >> 16);
+                                if (main_run)
+                                    sf.ident = sf.ident && tf32.lo == flo && tf32.hi == fhi;
+                            }
+                        }
+                        else {
+                            fm_out = (int)(int16_t)x; // buf.fm aliases the raw envelope (include/r_private.h:32-36)
+                        }
+                        if (main_run) {
+                            sa.ident = sa.ident && ta.lo == alo && ta.hi == ahi;
+                            csum += x;
+                            cmax = max(cmax, ta.lo);
+                            cmin = min(cmin, ta.lo);
+                            oa[u >> 1] |= ((uint32_t)ta.lo & 0xffffu) << ((u & 1) * 16);
+                            of[u >> 1] |= ((uint32_t)fm_out & 0xffffu) << ((u & 1) * 16);
+                        }
+                    }
+                }
+                if (main_run) {
+                    *(uint4 *)(s_am + lane * kPitch16 + g * 16) = make_uint4(oa[0], oa[1], oa[2], oa[3]);
+                    *(uint4 *)(s_fm + lane * kPitch16 + g * 16) = make_uint4(of[0], of[1], of[2], of[3]);
+                }
+            }
+        }
+        sa.end_known = ta.exact();
+        sa.y_end = ta.lo;
+        if (!p.enable_fm) {
+            sf.start_known = sf.end_known = true;
+            sf.y_end = 0;
+        }
+        else if (SS == 2) {
+            sf.end_known = tf16.exact();
+            sf.y_end = tf16.lo;
+        }
+        else {
+            sf.end_known = tf32.exact();
+            sf.y_end = tf32.lo;
+        }
+        if (cnt == 0) { // past the end of the capture: nothing to prove
+            sa.start_known = sf.start_known = true;
+            sa.end_known = sf.end_known = false;
+        }
+        // the fixed-point argument needs a feedback coefficient in [0, 1]: monotone map, slope <= 1
+        sa.ident = sa.ident && ta.ok;
+        sf.ident = sf.ident
+                && (SS == 2 ? (tf16.ok && p.a16 >= 0 && p.a16 <= 16384) : (tf32.ok && p.a32 >= 0 && p.a32 <= (1ll << 30)));
+
+        // ---- resolve the lanes whose warm-up did not collapse, left to right ----
+        // which: 0 = AM, 1 = FM.  Wave-uniform control flow; every round settles at least the first
+        // unresolved lane of every run (lanes 0..3 always start from the proven tile carry).
+        for (int which = 0; which < (p.enable_fm ? 2 : 1); ++which) {
+            ChunkStatus &st = which == 0 ? sa : sf;
+            for (int round = 0;; ++round) {
+                unsigned long long const open = __ballot(!st.start_known);
+                if (!open)
+                    break;
+                if (round > 64) { // cannot happen (one lane settles per round); never spin on the GPU
+                    det.overflow = 2;
+                    break;
+                }
+                int const pk = __shfl_up(st.end_known ? 1 : 0, 1, 64);
+                int const pv = __shfl_up(st.y_end, 1, 64);
+                bool const take = !st.start_known && pk != 0 && lane > 0;
+                bool rerun = false;
+                int y0 = 0;
+                if (take) {
+                    y0 = pv;
+                    st.start_known = true;
+                    if (st.ident && y0 >= st.lo0 && y0 <= st.hi0) {
+                        // every step of my chunk leaves y0 where it is: outputs are constant
+                        int const out = (which == 0 || SS == 2) ? y0 : (int)(int16_t)(y0 >> 16);
+                        uint32_t const w2 = ((uint32_t)out & 0xffffu) * 0x10001u;
+                        uint8_t *dst = (which == 0 ? s_am : s_fm) + lane * kPitch16;
+                        for (int g = 0; g < kChunk / 8; ++g)
+                            *(uint4 *)(dst + g * 16) = make_uint4(w2, w2, w2, w2);
+                        st.y_end = y0;
+                        st.end_known = true;
+                        if (which == 0)
+                            cmax = cmin = y0;
+                    }
+                    else {
+                        rerun = true;
+                    }
+                }
+                if (__ballot(rerun)) {
+                    // exact re-run of my chunk from the proven carry
+                    int x1 = 0, f1 = 0;
+                    if (rerun) {
+                        if (which == 0) {
+                            x1 = cs == 0 ? carry_xa : (int)*(uint16_t const *)(s_env + (lane - 1) * kPitch16 + (kChunk - 1) * 2);
+                            if ((t0 + (uint32_t)cs) % F == 0)
+                                x1 = (int)(int16_t)x1;
+                            cmax = -0x7fffffff, cmin = 0x7fffffff;
+                        }
+                        else {
+                            f1 = cs == 0 ? carry_ff
+                                         : (SS == 2 ? (int)*(int16_t const *)(s_f + (lane - 1) * G::f_pitch + (kChunk - 1) * 2)
+                                                    : *(int const *)(s_f + (lane - 1) * G::f_pitch + (kChunk - 1) * 4));
+                        }
+                    }
+                    int y = y0;
+#pragma unroll 1
+                    for (int i = 0; i < kChunk; ++i) {
+                        if (rerun && i < cnt) {
+                            int out;
+                            if (which == 0) {
+                                int const x = (int)*(uint16_t const *)(s_env + lane * kPitch16 + i * 2);
+                                y = (int)(int16_t)lp_am.raw(y, kLpfB * (x + x1));
+                                x1 = x;
+                                out = y;
+                                cmax = max(cmax, y);
+                                cmin = min(cmin, y);
+                            }
+                            else if (SS == 2) {
+                                int const f = (int)*(int16_t const *)(s_f + lane * G::f_pitch + i * 2);
+                                y = (int)(int16_t)lp_fm16.raw(y, p.b16 * (f + f1));
+                                f1 = f;
+                                out = y;
+                            }
+                            else {
+                                int const f = *(int const *)(s_f + lane * G::f_pitch + i * 4);
+                                y = (int)lp_fm32.raw(y, p.b32 * ((long long)f + f1));
+                                f1 = f;
+                                out = (int)(int16_t)(y >> 16);
+                            }
+                            *(int16_t *)((which == 0 ? s_am : s_fm) + lane * kPitch16 + i * 2) = (int16_t)out;
+                        }
+                    }
+                    if (rerun) {
+                        st.y_end = y;
+                        st.end_known = true;
+                    }
+                }
+            }
+        }
+
+        // carries for the next tile (only meaningful when this tile is full)
+        carry_ya = __builtin_amdgcn_readlane(sa.y_end, 63);
+        carry_yf = __builtin_amdgcn_readlane(sf.y_end, 63);
+        carry_xa = __builtin_amdgcn_readlane(xa1, 63);
+        carry_ff = __builtin_amdgcn_readlane(ff1, 63);
+        s_cmax[lane] = cmax;
+        s_cmin[lane] = cmin;
+
+        // per-frame envelope sums (u32, wraps like the reference's accumulator, baseband.c:39-44)
+        if (p.frame_sums) {
+            uint32_t const f_first = t0 / F, f_last = (t0 + (uint32_t)n_t - 1) / F;
+            uint32_t const my_frame = (t0 + (uint32_t)cs) / F;
+            for (uint32_t f = f_first; f <= f_last; ++f) {
+                int const part = wave_sum(cnt > 0 && my_frame == f ? csum : 0);
+                if (lane == 0 && f < p.frames_cap)
+                    p.frame_sums[(uint64_t)s * p.frames_cap + f] += (uint32_t)part;
+            }
+        }
+        __syncthreads();
+
+        if (p.tap_am) {
+            for (int idx = lane; idx < n_t; idx += 64) {
+                uint64_t o = (uint64_t)s * p.tap_stride + t0 + (uint32_t)idx;
+                p.tap_am[o] = (int16_t)ld16(s_am, idx);
+                p.tap_fm[o] = (int16_t)ld16(s_fm, idx);
+            }
+        }
+
+        // ================= phase C: pulse detector =================
+        int i = 0;
+        while (i < n_t) {
+            if (dc == 0) { // a new frame == a new push_sdr_flow call
+                flen = (int)min(my_n - (t0 + (uint32_t)i), F);
+                if (lane == 0)
+                    det_call_entry(det, cfg, flen, 0);
+            }
+            int const base = i & ~63;
+            int const e = min(min(n_t, base + 64), i + (flen - dc));
+            // what lane 0 knows
+            int const st = rl0(det.state);
+            int const lead = rl0(det.lead_in);
+            int const low = rl0(det.low);
+            int const high = rl0(det.high);
+            int const run = rl0(det.run);
+            int const maxp = rl0(det.max_pulse);
+            int const onum = rl0((int)det.ook_num);
+            int const eop = rl0(det.eop_spurious);
+
+            int const il = base + lane;
+            bool const in_seg = il >= i && il < e;
+            int const am_l = in_seg ? ld16(s_am, il) : 0;
+            int const bmax = max(s_cmax[base >> 5], s_cmax[(base >> 5) + 1]);
+            int const bmin = min(s_cmin[base >> 5], s_cmin[(base >> 5) + 1]);
+
+            enum { M_GENERIC, M_LEAD, M_CHASE, M_GAP, M_PULSE };
+            int mode = M_GENERIC;
+            int k = i;
+            if (st == ST_IDLE) {
+                if (lead <= 1024) { // no pulse can start during the lead-in (pulse_detect.c:310)
+                    k = min(e, i + (1025 - lead));
+                    mode = M_LEAD;
+                }
+                else {
+                    // lowest threshold the idle state can present while it chases the noise floor in this block
+                    int const l_lb = min(low, bmin) - 1;
+                    int thr = (int)(int16_t)((l_lb + min(cfg.min_high, cfg.max_high)) / 2);
+                    if (cfg.fixed_high != 0)
+                        thr = (int)(int16_t)cfg.fixed_high;
+                    int const hys = (int)(int16_t)(thr / 8);
+                    unsigned long long const m = __ballot(in_seg && am_l > thr + hys);
+                    k = m ? base + (__ffsll(m) - 1) : e;
+                    mode = M_CHASE;
+                }
+            }
+            else if (st == ST_GAP) {
+                int thr = (int)(int16_t)((low + min(high, cfg.max_high)) / 2);
+                if (cfg.fixed_high != 0)
+                    thr = (int)(int16_t)cfg.fixed_high;
+                int const hys = (int)(int16_t)(thr / 8);
+                unsigned long long const m = __ballot(in_seg && am_l > thr + hys);
+                int const ka = m ? base + (__ffsll(m) - 1) : e;
+                // first sample whose gap count ends the package (pulse_detect.c:446-450)
+                long long const lim = min(max(10ll * maxp, 10ll * cfg.per_ms), 100ll * cfg.per_ms);
+                long long const togo = eop ? 0 : max(0ll, lim - (long long)run);
+                int const ke = togo < (long long)(e - i) ? i + (int)togo : e;
+                k = min(ka, ke);
+                mode = M_GAP;
+            }
+            else if (st == ST_PULSE && onum > 0) {
+                // the level estimate cannot climb above max(high, block max); below that threshold no
+                // sample can be a falling edge
+                int const h_ub = max(high, bmax) + 1;
+                int thr = (int)(int16_t)((low + min(h_ub, cfg.max_high)) / 2);
+                if (cfg.fixed_high != 0)
+                    thr = (int)(int16_t)cfg.fixed_high;
+                int const hys = (int)(int16_t)(thr / 8);
+                unsigned long long const m = __ballot(in_seg && am_l < thr - hys);
+                k = m ? base + (__ffsll(m) - 1) : e;
+                mode = M_PULSE;
+            }
+
+            int consumed = 0;
+            if (lane == 0) {
+                int j = i;
+                if (mode == M_LEAD || mode == M_CHASE) {
+                    int lo_est = det.low;
+                    for (; j < k; ++j) { // idle arm without the (impossible) pulse start, pulse_detect.c:326-334
+                        int const dl = ld16(s_am, j) - lo_est;
+                        lo_est += dl / 1024;
+                        lo_est += dl > 0 ? 1 : -1;
+                    }
+                    if (k > i) {
+                        det.low = lo_est;
+                        det.high = max(cfg.ratio * lo_est, cfg.min_high);
+                        if (mode == M_LEAD)
+                            det.lead_in += k - i;
+                    }
+                }
+                else if (mode == M_GAP) {
+                    det.run += k - i;
+                    j = k;
+                }
+                else if (mode == M_PULSE) {
+                    int h = det.high, f1 = det.ook_f1;
+                    for (; j < k; ++j) { // pulse arm without the falling edge, pulse_detect.c:359-366
+                        int const am = ld16(s_am, j), fm = ld16(s_fm, j);
+                        h += am / 64 - h / 64;
+                        h = max(h, cfg.min_high);
+                        f1 += fm / 64 - f1 / 64;
+                    }
+                    det.high = h;
+                    det.ook_f1 = f1;
+                    det.run += k - i;
+                }
+                // the exact general step for the candidate sample and for the states that need every sample
+                if (j < e) {
+                    int local_dc = dc + (j - i);
+                    do {
+                        int const am = ld16(s_am, j), fm = ld16(s_fm, j);
+                        int const r = det_step(det, cfg, am, fm, flen, local_dc, input_pos, frame);
+                        if (r) { // package returned: the next call starts at the same sample, in the idle state
+                            det_call_entry(det, cfg, flen, local_dc);
+                            det_idle(det, cfg, am, flen, local_dc, input_pos);
+                        }
+                        ++j;
+                        ++local_dc;
+                    } while (j < e && (det.state == ST_GAP_START || (det.state == ST_PULSE && det.ook_num == 0)));
+                }
+                consumed = j - i;
+            }
+            consumed = rl0(consumed);
+            i += consumed;
+            dc += consumed;
+            if (dc == flen) {
+                input_pos += (uint64_t)flen;
+                frame += 1;
+                dc = 0;
+            }
+        }
     }
 
-    if (!active)
-        return;
-    if (!(p.flags & RUN_NOFLUSH))
-        det_flush(L.det, L.cfg, L.frame);
-
-    StreamState &S = p.state[s];
-    S.lpf_y = L.lpf_y;
-    S.lpf_x = L.lpf_x;
-    S.fm_xr = L.fm.xr;
-    S.fm_xi = L.fm.xi;
-    S.fm_xf = L.fm.xf;
-    S.fm_yf = L.fm.yf;
-    S.state = L.det.state;
-    S.run = L.det.run;
-    S.max_pulse = L.det.max_pulse;
-    S.lead_in = L.det.lead_in;
-    S.low = L.det.low;
-    S.high = L.det.high;
-    S.f_run = L.det.f_run;
-    S.f_state = L.det.f_state;
-    S.f_f1 = L.det.f_f1;
-    S.f_f2 = L.det.f_f2;
-    S.f_vmax = L.det.f_vmax;
-    S.f_vmin = L.det.f_vmin;
-    S.f_skip = L.det.f_skip;
-    S.ook_num = L.det.ook_num;
-    S.cur_pulse = L.det.cur_pulse;
-    S.ook_f1 = L.det.ook_f1;
-    S.fsk_num = L.det.fsk_num;
-    S.start_ago = L.det.start_ago;
-    S.offset = L.det.offset;
-    S.fsk_offset = L.det.fsk_offset;
-    S.input_pos = L.input_pos;
-    S.frame = L.frame;
-    S.cursor = L.det.cursor;
-    S.n_pkgs = L.det.n_pkgs;
-    S.overflow = L.det.overflow;
+    if (lane == 0) {
+        if (!(p.flags & RUN_NOFLUSH))
+            det_flush(det, cfg, frame);
+        StreamState &S = p.state[s];
+        S.cursor = det.cursor;
+        S.n_pkgs = det.n_pkgs;
+        S.overflow = det.overflow;
+        S.input_pos = input_pos;
+        S.frame = frame;
+    }
 }
 
 // ---- package directory: canonical (capture, detection order) numbering ----
@@ -353,11 +770,11 @@ void launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st)
 {
     if (p.n_streams == 0)
         return;
-    dim3 grid((p.n_streams + 63) / 64), block(64);
+    dim3 grid(p.n_streams), block(64);
     if (sample_size == 2)
-        hipLaunchKernelGGL(k_stream<2>, grid, block, 0, st, p);
+        hipLaunchKernelGGL(k_wave<2>, grid, block, 0, st, p);
     else
-        hipLaunchKernelGGL(k_stream<4>, grid, block, 0, st, p);
+        hipLaunchKernelGGL(k_wave<4>, grid, block, 0, st, p);
 }
 
 void launch_pkg_scan(StreamState const *state, uint32_t n_streams, uint32_t *pkg_base, uint32_t *scal, hipStream_t st)

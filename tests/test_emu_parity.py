@@ -1,0 +1,155 @@
+"""CPU parity of the *kernel sources*: rtl_433_amd/csrc compiled by g++ against the lock-step wave
+emulator (tests/emu) and driven through the same C ABI as the product, compared byte for byte with the
+oracle and the golden vectors taken from the real reference.  No GPU involved; the product library is
+not used here (tests/test_gpu_parity.py runs the same comparisons on the MI355X)."""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from rtl_433_amd import synth
+from tests.cases import CASES, GOLD, fpdm_for, make_case
+from tests.emu import build_emu
+
+pytestmark = pytest.mark.skipif(not build_emu.available(), reason="wave emulator needs x86-64")
+
+META = json.load(open(os.path.join(GOLD, "cases.json")))
+# the big all-random capture makes 88 packages x 335 slicers: minutes on the emulator, covered on the GPU
+EMU_CASES = [c for c in CASES if c != "random"]
+
+
+def _oracle_batch(iqs, devs, cfg):
+    pk_all, ev_all, base = b"", b"", 0
+    for s, a in enumerate(iqs):
+        o = po.oracle_flow(a, devs, cfg, stream_index=s, pkg_base=base)
+        pk_all += o["packages"]
+        ev_all += o["events"]
+        base += o["n_packages"]
+    return pk_all, ev_all, base
+
+
+@pytest.mark.parametrize("name", EMU_CASES)
+def test_case_vs_golden_and_oracle(name, default_devices):
+    from tests.emu import host
+    devs = default_devices[0]
+    iq, ss, rate, freq = make_case(name)
+    m = META[name]
+    g = host.emu_run([iq], ss, rate, devs, fpdm=fpdm_for(freq), taps=True, center_frequency=freq)
+    n = iq.nbytes // ss
+    env, am, fm = g["taps"]
+    assert zlib.crc32(am[0, :n].tobytes()) == m["am_crc"]  # golden: the real reference's -W am.s16 / fm.s16
+    assert zlib.crc32(fm[0, :n].tobytes()) == m["fm_crc"]
+    pk, npk = g["packages"]
+    ev, nev = g["events"]
+    gold_pk = open(os.path.join(GOLD, f"case_{name}.pkg.bin"), "rb").read()
+    assert npk == m["n_packages"] and po.strip_ret_pos(pk) == gold_pk
+    assert nev == m["n_events"] and str(po.events_digest(ev)[0]) == m["digest"]
+    k = (n + (262144 // ss) - 1) // (262144 // ss)
+    assert list(g["sums"][0][:k]) == m["frame_sums"][:k]
+    o = po.oracle_flow(iq, devs, po.default_flow_cfg(ss, rate, fpdm=fpdm_for(freq)), taps=True)
+    assert pk == o["packages"] and ev == o["events"]
+    assert np.array_equal(env[0, :n], o["env"])
+
+
+def test_ragged_batch(default_devices):
+    """Captures of different lengths (including 0 and non-multiples of the tile) in one launch."""
+    from tests.emu import host
+    devs = default_devices[0][:40]
+    rng = np.random.default_rng(5)
+    iqs = []
+    for s in range(24):
+        n = int(rng.integers(0, 30000)) if s else 0
+        kind = s % 4
+        if kind == 0:
+            a = synth.random_cu8(1000 + s, min(n, 6000))
+        elif kind == 1:
+            a = synth.noise_cu8(1000 + s, n, 4.0)
+        else:
+            a = synth.ook_stream(1000 + s, max(n, 1))[0][: 2 * n]
+        iqs.append(a)
+    g = host.emu_run(iqs, 2, 250000, devs)
+    pk, ev, base = _oracle_batch(iqs, devs, po.default_flow_cfg(2, 250000, fpdm=0))
+    assert g["packages"][1] == base and g["packages"][0] == pk and g["events"][0] == ev
+
+
+@pytest.mark.parametrize("variant", ["nofm", "magest", "fixed_level", "lowpass", "slow_lowpass", "short_frames"])
+def test_flow_options(variant, default_devices):
+    from tests.emu import host
+    devs = default_devices[0][:60]
+    kw, enable_fm = {}, 1
+    if variant == "nofm":
+        enable_fm = 0
+        devs = devs[devs["modulation"] < 16]
+    elif variant == "magest":
+        kw = dict(use_mag_est=1)
+    elif variant == "fixed_level":
+        kw = dict(level_limit_db=-10.0)
+    elif variant == "lowpass":
+        kw = dict(fm_low_pass=0.15)
+    elif variant == "slow_lowpass":  # feedback 0.98: the 96-sample warm-up cannot collapse, everything is resolved serially
+        kw = dict(fm_low_pass=0.006)
+    elif variant == "short_frames":  # frame boundaries inside tiles and chunks' neighbours
+        kw = dict(frame_samples=192)
+    iqs = [synth.ook_stream(40 + k, 30000)[0] for k in range(2)] + [synth.fsk_stream_cu8(50, 40000), synth.random_cu8(51, 5000)]
+    g = host.emu_run(iqs, 2, 250000, devs, enable_fm=enable_fm, taps=True, **kw)
+    okw = dict(kw)
+    cfg = po.default_flow_cfg(2, 250000, fpdm=0, enable_fm=enable_fm, **okw)
+    pk, ev, base = _oracle_batch(iqs, devs, cfg)
+    for s, a in enumerate(iqs):
+        o = po.oracle_flow(a, devs, cfg, taps=True)
+        n = a.nbytes // 2
+        assert np.array_equal(g["taps"][1][s, :n], o["am"]), f"am differs, capture {s}"
+        assert np.array_equal(g["taps"][2][s, :n], o["fm"]), f"fm differs, capture {s}"
+    assert g["packages"][0] == pk and g["events"][0] == ev
+
+
+def test_stalled_and_saturated_filters():
+    """Constant input parks the truncating low-passes on one of several fixed points (which one depends
+    on the history); full-scale input makes the AM filter's int16 x[-1] slot wrap at frame starts."""
+    from tests.emu import host
+    rng = np.random.default_rng(11)
+    n = 3 * 2048 + 777
+    parts = []
+    for v in (128, 130, 255, 0, 127):
+        parts.append(np.full(2 * n, v, dtype=np.uint8))
+        burst = rng.integers(0, 256, 2 * 300, dtype=np.uint8)  # leaves the filters on a different fixed point each time
+        parts.append(burst)
+    iq = np.concatenate(parts)
+    sat = np.full(2 * 5000, 255, dtype=np.uint8)
+    sat[::7] = 0
+    for frame_samples in (None, 64, 2048):
+        kw = {} if frame_samples is None else dict(frame_samples=frame_samples)
+        g = host.emu_run([iq, sat], 2, 250000, None, taps=True, **kw)
+        cfg = po.default_flow_cfg(2, 250000, **kw)
+        for s, a in enumerate([iq, sat]):
+            o = po.oracle_flow(a, None, cfg, taps=True)
+            m = a.nbytes // 2
+            assert np.array_equal(g["taps"][0][s, :m], o["env"])
+            assert np.array_equal(g["taps"][1][s, :m], o["am"])
+            assert np.array_equal(g["taps"][2][s, :m], o["fm"])
+            k = len(o["frame_sums"]) - 1
+            assert list(g["sums"][s][:k]) == list(o["frame_sums"][:k])
+        pk, ev, base = _oracle_batch([iq, sat], None, cfg)
+        assert g["packages"][0] == pk
+
+
+def test_cs16_stalls_and_ragged():
+    from tests.emu import host
+    rng = np.random.default_rng(12)
+    a = np.zeros(2 * 9000, dtype=np.int16)
+    a[2 * 3000:2 * 3400] = rng.integers(-20000, 20000, 800)
+    b = synth.fsk_stream_cs16(8, 20011)
+    c = np.full(2 * 4100, -32768, dtype=np.int16)
+    for fpdm in (0, 1):
+        g = host.emu_run([a, b, c], 4, 1024000, None, fpdm=fpdm, taps=True)
+        cfg = po.default_flow_cfg(4, 1024000, fpdm=fpdm)
+        for s, x in enumerate([a, b, c]):
+            o = po.oracle_flow(x, None, cfg, taps=True)
+            m = x.nbytes // 4
+            assert np.array_equal(g["taps"][1][s, :m], o["am"])
+            assert np.array_equal(g["taps"][2][s, :m], o["fm"])
+        pk, ev, base = _oracle_batch([a, b, c], None, cfg)
+        assert g["packages"][0] == pk
