@@ -449,6 +449,8 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
         sp.n_streams = n_streams;
         sp.frame_samples = b->cfg.frame_samples;
         sp.flags = 0;
+        if (char const *dbg = getenv("R433_DEBUG_FLAGS")) // phase timing experiments only (results are then incomplete)
+            sp.flags |= (uint32_t)strtoul(dbg, nullptr, 0) & (RUN_DBG_SKIP_DETECT | RUN_DBG_SKIP_FILTERS);
         sp.det = b->det;
         sp.use_mag = (int)b->cfg.use_mag_est;
         sp.enable_fm = (int)b->cfg.enable_fm;

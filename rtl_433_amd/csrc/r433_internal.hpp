@@ -33,6 +33,9 @@ struct StreamState {
 enum : uint32_t {
     RUN_CONTINUE = 1u, // resume from StreamState instead of a reset flow
     RUN_NOFLUSH = 2u,  // do not issue the end-of-input flush call
+    // profiling aids (env R433_DEBUG_FLAGS, never set by the product path): stop after a phase
+    RUN_DBG_SKIP_DETECT = 256u,
+    RUN_DBG_SKIP_FILTERS = 512u,
 };
 
 struct StreamParams {

@@ -60,66 +60,87 @@ __device__ __forceinline__ int ld16(uint8_t const *buf, int i)
 }
 
 // ---- phase B: one low-pass, both extreme tracks ----
+//
+// FAST = the host proved that no step can leave the state's integer range and that the feedback
+// coefficient is non-negative (a >= 0 and a + 2b <= one in the filter's fixed point -- true for the
+// AM filter and for every default FM filter): then each step is a monotone non-decreasing map of the
+// carry, the low track stays the low track, and narrowing is the identity.  Otherwise every step is
+// checked: an interval whose image could wrap is never trusted.
+
+__device__ __forceinline__ int mul24(int a, int b)
+{
+    return __mul24(a, b);
+}
 
 // AM and cu8-FM filters: 16-bit state, y' = (a*y + k) >> 14 narrowed to int16 (src/baseband.c:161-163, 263)
-struct Lp16 {
-    int a;
-    __device__ __forceinline__ int raw(int y, int k) const { return (a * y + k) >> 14; }
-};
-
-struct Track16 {
+template <bool FAST> struct Track16 {
     int lo, hi;
-    bool ok; // no int16 wrap on either track so far: the sandwich argument holds
+    int ok; // checked mode: no int16 wrap on an open interval so far (the sandwich argument holds)
 
-    __device__ __forceinline__ void step(Lp16 const &f, int k)
+    __device__ __forceinline__ void step(int a, int k)
     {
-        int v0 = f.raw(lo, k), v1 = f.raw(hi, k);
-        if (lo != hi) // a proven carry may wrap like the reference does; an interval may not
-            ok = ok && v0 == (int)(int16_t)v0 && v1 == (int)(int16_t)v1;
-        lo = (int)(int16_t)min(v0, v1);
-        hi = (int)(int16_t)max(v0, v1);
+        int const v0 = (mul24(a, lo) + k) >> 14, v1 = (mul24(a, hi) + k) >> 14;
+        if (FAST) {
+            lo = v0;
+            hi = v1;
+        }
+        else {
+            int const fits = (int)((uint32_t)(v0 + 32768) < 65536u) & (int)((uint32_t)(v1 + 32768) < 65536u);
+            ok &= (int)(lo == hi) | fits; // a proven carry may wrap like the reference does; an interval may not
+            lo = (int)(int16_t)min(v0, v1);
+            hi = (int)(int16_t)max(v0, v1);
+        }
     }
-    __device__ __forceinline__ bool exact() const { return ok && lo == hi; }
+    __device__ __forceinline__ bool exact() const { return (FAST || ok) && lo == hi; }
 };
 
 // cs16-FM filter: 32-bit state in Q30, y' = (a*y + k) >> 30 truncated to int32 (src/baseband.c:357)
-struct Lp32 {
-    long long a;
-    __device__ __forceinline__ long long raw(int y, long long k) const { return (a * (long long)y + k) >> 30; }
-};
-
-struct Track32 {
+template <bool FAST> struct Track32 {
     int lo, hi;
-    bool ok;
+    int ok;
 
-    __device__ __forceinline__ void step(Lp32 const &f, long long k)
+    __device__ __forceinline__ void step(long long a, long long k)
     {
-        long long v0 = f.raw(lo, k), v1 = f.raw(hi, k);
-        if (lo != hi)
-            ok = ok && v0 == (long long)(int)v0 && v1 == (long long)(int)v1;
-        long long a = v0 < v1 ? v0 : v1, b = v0 < v1 ? v1 : v0;
-        lo = (int)a;
-        hi = (int)b;
+        long long const v0 = (a * (long long)lo + k) >> 30, v1 = (a * (long long)hi + k) >> 30;
+        if (FAST) {
+            lo = (int)v0;
+            hi = (int)v1;
+        }
+        else {
+            int const fits = (int)(v0 == (long long)(int)v0) & (int)(v1 == (long long)(int)v1);
+            ok &= (int)(lo == hi) | fits;
+            lo = (int)(v0 < v1 ? v0 : v1);
+            hi = (int)(v0 < v1 ? v1 : v0);
+        }
     }
-    __device__ __forceinline__ bool exact() const { return ok && lo == hi; }
+    __device__ __forceinline__ bool exact() const { return (FAST || ok) && lo == hi; }
 };
 
 // what a lane knows about one filter over its chunk after the first pass
 struct ChunkStatus {
     bool start_known; // carry at chunk start proven (outputs published)
     bool end_known;   // carry at chunk end proven
-    bool ident;       // every carry in [lo0, hi0] is a fixed point of every step of the chunk
+    int ident;        // every carry in [lo0, hi0] is a fixed point of every step of the chunk
     int lo0, hi0;     // carry interval at chunk start
     int y_end;
 };
 
 template <int SS> struct Geom {
-    static constexpr int f_bytes = SS == 2 ? 2 : 4;
     static constexpr int f_pitch = SS == 2 ? kPitch16 : kPitch32;
     static constexpr int loads = SS == 2 ? kRows : 2 * kRows; // uint4 per lane per tile
 };
 
-template <int SS> __global__ __launch_bounds__(64) void k_wave(StreamParams p)
+// C division by 64 / 1024 (truncating toward zero) without a divider
+__device__ __forceinline__ int div64(int v)
+{
+    return (v + ((v >> 31) & 63)) >> 6;
+}
+__device__ __forceinline__ int div1024(int v)
+{
+    return (v + ((v >> 31) & 1023)) >> 10;
+}
+
+template <int SS, bool FAST> __global__ __launch_bounds__(64) void k_wave(StreamParams p)
 {
     using G = Geom<SS>;
     __shared__ __attribute__((aligned(16))) uint8_t s_env[64 * kPitch16];
@@ -137,9 +158,11 @@ template <int SS> __global__ __launch_bounds__(64) void k_wave(StreamParams p)
     uint8_t const *const iq = p.iq + (uint64_t)s * p.stride_bytes;
     uint32_t const F = p.frame_samples;
 
-    // ---- detector (lane 0 is the owner; the other lanes carry dead copies) ----
+    // ---- detector.  Every lane carries a copy of the scalar state and applies the wave-uniform fast
+    // paths to it; lane 0 additionally runs the general step (ring, arena) and its view of the fields
+    // the fast paths read is re-broadcast afterwards.
     DetLane det;
-    DetCfg cfg = p.det;
+    DetCfg const cfg = p.det;
     det_reset(det);
     det.arena = p.arena + (uint64_t)s * p.arena_stride;
     det.fsk_ring = s_ring;
@@ -148,18 +171,14 @@ template <int SS> __global__ __launch_bounds__(64) void k_wave(StreamParams p)
     det.cursor = 0;
     det.n_pkgs = 0;
     det.overflow = 0;
-    // frame bookkeeping, tracked identically by every lane
     uint64_t input_pos = 0;
     uint32_t frame = 0;
     int dc = 0, flen = 0;
 
     // ---- filter carries across tiles (wave-uniform) ----
-    int carry_ya = 0, carry_xa = 0;          // AM low-pass: y[-1], x[-1]
-    int carry_yf = 0, carry_ff = 0;          // FM low-pass: y[-1], discriminator[-1]
-    int carry_i = 0, carry_q = 0;            // last IQ sample, centred
-    Lp16 const lp_am{kLpfA};
-    Lp16 const lp_fm16{p.a16};
-    Lp32 const lp_fm32{p.a32};
+    int carry_ya = 0, carry_xa = 0; // AM low-pass: y[-1], x[-1]
+    int carry_yf = 0, carry_ff = 0; // FM low-pass: y[-1], discriminator[-1]
+    int carry_i = 0, carry_q = 0;   // last IQ sample, centred
 
     uint4 pf[G::loads];
     auto issue_loads = [&](uint32_t tile) {
@@ -276,14 +295,18 @@ template <int SS> __global__ __launch_bounds__(64) void k_wave(StreamParams p)
         }
         issue_loads(tile + 1); // in flight while phases B and C run
         __syncthreads();
+        if (p.flags & RUN_DBG_SKIP_FILTERS)
+            continue;
 
         // ================= phase B: the two low-passes, lane = chunk of 32 samples =================
         int const cs = lane * kChunk;                       // chunk start inside the tile
         int const cnt = max(0, min(kChunk, n_t - cs));      // valid samples of my chunk
         int const first = max(0, lane - kWarmChunks);       // first chunk I read
         bool const from_carry = lane <= kWarmChunks;        // my warm-up reaches the tile start: exact carry
-        Track16 ta, tf16;
-        Track32 tf32;
+        // chunks at which a frame (= a push_sdr_flow call) starts
+        unsigned long long const fs_mask = __ballot((t0 + (uint32_t)cs) % F == 0);
+        Track16<FAST> ta, tf16;
+        Track32<FAST> tf32;
         int xa1, ff1; // previous envelope / discriminator sample
         if (from_carry) {
             ta.lo = ta.hi = carry_ya;
@@ -300,13 +323,13 @@ template <int SS> __global__ __launch_bounds__(64) void k_wave(StreamParams p)
             ff1 = SS == 2 ? (int)*(int16_t const *)(s_f + (first - 1) * G::f_pitch + (kChunk - 1) * 2)
                           : *(int const *)(s_f + (first - 1) * G::f_pitch + (kChunk - 1) * 4);
         }
-        ta.ok = tf16.ok = tf32.ok = true;
+        ta.ok = tf16.ok = tf32.ok = 1;
 
         ChunkStatus sa, sf; // AM, FM
         sa.start_known = sf.start_known = false;
-        sa.ident = sf.ident = true;
+        sa.ident = sf.ident = 1;
         sa.lo0 = sa.hi0 = sf.lo0 = sf.hi0 = 0;
-        int csum = 0;                       // envelope sum of my chunk (frame average)
+        int csum = 0; // envelope sum of my chunk (frame average)
         int cmax = -0x7fffffff, cmin = 0x7fffffff;
 
 #pragma unroll 1
@@ -316,7 +339,7 @@ template <int SS> __global__ __launch_bounds__(64) void k_wave(StreamParams p)
             if (c < 0)
                 continue;
             // a frame starts here: the AM filter state keeps x[-1] in an int16 slot (baseband.c:166-168)
-            if ((t0 + (uint32_t)c * kChunk) % F == 0)
+            if ((fs_mask >> c) & 1ull)
                 xa1 = (int)(int16_t)xa1;
             if (main_run) {
                 sa.start_known = ta.exact();
@@ -330,7 +353,6 @@ template <int SS> __global__ __launch_bounds__(64) void k_wave(StreamParams p)
                     sf.lo0 = tf32.lo, sf.hi0 = tf32.hi;
                 }
             }
-            int const lim = main_run ? cnt : kChunk;
 #pragma unroll 1
             for (int g = 0; g < kChunk / 8; ++g) {
                 uint4 const e4 = *(uint4 const *)(s_env + c * kPitch16 + g * 16);
@@ -349,47 +371,44 @@ template <int SS> __global__ __launch_bounds__(64) void k_wave(StreamParams p)
                 uint32_t oa[4] = {0, 0, 0, 0}, of[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
+                    // samples past the end of the capture are stepped too (their results are never
+                    // read); only the chunk statistics have to leave them out
+                    int const lv = main_run ? (int)(g * 8 + u < cnt) : 1;
                     int const x = (int)((ew[u >> 1] >> ((u & 1) * 16)) & 0xffffu);
-                    bool const live = g * 8 + u < lim;
-                    if (live) {
-                        int const ka = kLpfB * (x + xa1);
-                        int const alo = ta.lo, ahi = ta.hi;
-                        ta.step(lp_am, ka);
-                        xa1 = x;
-                        int fm_out;
-                        if (p.enable_fm) {
-                            if (SS == 2) {
-                                int const f = (int)(int16_t)((fw[u >> 1] >> ((u & 1) * 16)) & 0xffffu);
-                                int const kf = p.b16 * (f + ff1);
-                                int const flo = tf16.lo, fhi = tf16.hi;
-                                tf16.step(lp_fm16, kf);
-                                ff1 = f;
-                                fm_out = tf16.lo;
-                                if (main_run)
-                                    sf.ident = sf.ident && tf16.lo == flo && tf16.hi == fhi;
-                            }
-                            else {
-                                int const f = (int)fw[u];
-                                long long const kf = p.b32 * ((long long)f + ff1);
-                                int const flo = tf32.lo, fhi = tf32.hi;
-                                tf32.step(lp_fm32, kf);
-                                ff1 = f;
-                                fm_out = (int)(int16_t)(tf32.lo >> 16);
-                                if (main_run)
-                                    sf.ident = sf.ident && tf32.lo == flo && tf32.hi == fhi;
-                            }
+                    int const alo = ta.lo, ahi = ta.hi;
+                    ta.step(kLpfA, mul24(kLpfB, x + xa1));
+                    xa1 = x;
+                    int fm_out;
+                    int f_same = 1;
+                    if (p.enable_fm) {
+                        if (SS == 2) {
+                            int const f = (int)(int16_t)((fw[u >> 1] >> ((u & 1) * 16)) & 0xffffu);
+                            int const flo = tf16.lo, fhi = tf16.hi;
+                            tf16.step(p.a16, mul24(p.b16, f + ff1));
+                            ff1 = f;
+                            fm_out = tf16.lo;
+                            f_same = (int)(tf16.lo == flo) & (int)(tf16.hi == fhi);
                         }
                         else {
-                            fm_out = (int)(int16_t)x; // buf.fm aliases the raw envelope (include/r_private.h:32-36)
+                            int const f = (int)fw[u];
+                            int const flo = tf32.lo, fhi = tf32.hi;
+                            tf32.step(p.a32, p.b32 * ((long long)f + ff1));
+                            ff1 = f;
+                            fm_out = (int)(int16_t)(tf32.lo >> 16);
+                            f_same = (int)(tf32.lo == flo) & (int)(tf32.hi == fhi);
                         }
-                        if (main_run) {
-                            sa.ident = sa.ident && ta.lo == alo && ta.hi == ahi;
-                            csum += x;
-                            cmax = max(cmax, ta.lo);
-                            cmin = min(cmin, ta.lo);
-                            oa[u >> 1] |= ((uint32_t)ta.lo & 0xffffu) << ((u & 1) * 16);
-                            of[u >> 1] |= ((uint32_t)fm_out & 0xffffu) << ((u & 1) * 16);
-                        }
+                    }
+                    else {
+                        fm_out = (int)(int16_t)x; // buf.fm aliases the raw envelope (include/r_private.h:32-36)
+                    }
+                    if (main_run) {
+                        sa.ident &= ((int)(ta.lo == alo) & (int)(ta.hi == ahi)) | (lv ^ 1);
+                        sf.ident &= f_same | (lv ^ 1);
+                        csum += lv ? x : 0;
+                        cmax = lv ? max(cmax, ta.lo) : cmax;
+                        cmin = lv ? min(cmin, ta.lo) : cmin;
+                        oa[u >> 1] |= ((uint32_t)ta.lo & 0xffffu) << ((u & 1) * 16);
+                        of[u >> 1] |= ((uint32_t)fm_out & 0xffffu) << ((u & 1) * 16);
                     }
                 }
                 if (main_run) {
@@ -417,9 +436,8 @@ template <int SS> __global__ __launch_bounds__(64) void k_wave(StreamParams p)
             sa.end_known = sf.end_known = false;
         }
         // the fixed-point argument needs a feedback coefficient in [0, 1]: monotone map, slope <= 1
-        sa.ident = sa.ident && ta.ok;
-        sf.ident = sf.ident
-                && (SS == 2 ? (tf16.ok && p.a16 >= 0 && p.a16 <= 16384) : (tf32.ok && p.a32 >= 0 && p.a32 <= (1ll << 30)));
+        sa.ident &= ta.ok;
+        sf.ident &= SS == 2 ? (tf16.ok & (int)(p.a16 >= 0 && p.a16 <= 16384)) : (tf32.ok & (int)(p.a32 >= 0 && p.a32 <= (1ll << 30)));
 
         // ---- resolve the lanes whose warm-up did not collapse, left to right ----
         // which: 0 = AM, 1 = FM.  Wave-uniform control flow; every round settles at least the first
@@ -464,7 +482,7 @@ template <int SS> __global__ __launch_bounds__(64) void k_wave(StreamParams p)
                     if (rerun) {
                         if (which == 0) {
                             x1 = cs == 0 ? carry_xa : (int)*(uint16_t const *)(s_env + (lane - 1) * kPitch16 + (kChunk - 1) * 2);
-                            if ((t0 + (uint32_t)cs) % F == 0)
+                            if ((fs_mask >> lane) & 1ull)
                                 x1 = (int)(int16_t)x1;
                             cmax = -0x7fffffff, cmin = 0x7fffffff;
                         }
@@ -481,7 +499,7 @@ template <int SS> __global__ __launch_bounds__(64) void k_wave(StreamParams p)
                             int out;
                             if (which == 0) {
                                 int const x = (int)*(uint16_t const *)(s_env + lane * kPitch16 + i * 2);
-                                y = (int)(int16_t)lp_am.raw(y, kLpfB * (x + x1));
+                                y = (int)(int16_t)((mul24(kLpfA, y) + mul24(kLpfB, x + x1)) >> 14);
                                 x1 = x;
                                 out = y;
                                 cmax = max(cmax, y);
@@ -489,13 +507,13 @@ template <int SS> __global__ __launch_bounds__(64) void k_wave(StreamParams p)
                             }
                             else if (SS == 2) {
                                 int const f = (int)*(int16_t const *)(s_f + lane * G::f_pitch + i * 2);
-                                y = (int)(int16_t)lp_fm16.raw(y, p.b16 * (f + f1));
+                                y = (int)(int16_t)((mul24(p.a16, y) + mul24(p.b16, f + f1)) >> 14);
                                 f1 = f;
                                 out = y;
                             }
                             else {
                                 int const f = *(int const *)(s_f + lane * G::f_pitch + i * 4);
-                                y = (int)lp_fm32.raw(y, p.b32 * ((long long)f + f1));
+                                y = (int)((p.a32 * (long long)y + p.b32 * ((long long)f + f1)) >> 30);
                                 f1 = f;
                                 out = (int)(int16_t)(y >> 16);
                             }
@@ -539,114 +557,109 @@ template <int SS> __global__ __launch_bounds__(64) void k_wave(StreamParams p)
         }
 
         // ================= phase C: pulse detector =================
-        int i = 0;
+        int i = (p.flags & RUN_DBG_SKIP_DETECT) ? n_t : 0;
+        int loaded = -1;           // block whose samples the lanes hold
+        int am_l = 0, fm_l = 0;    // my sample of that block
+        int a64_l = 0, f64_l = 0;  // am / 64, fm / 64 (C division) for the level and carrier averages
+        int bmax = 0, bmin = 0;
         while (i < n_t) {
             if (dc == 0) { // a new frame == a new push_sdr_flow call
                 flen = (int)min(my_n - (t0 + (uint32_t)i), F);
-                if (lane == 0)
-                    det_call_entry(det, cfg, flen, 0);
+                det_call_entry(det, cfg, flen, 0);
             }
             int const base = i & ~63;
             int const e = min(min(n_t, base + 64), i + (flen - dc));
-            // what lane 0 knows
-            int const st = rl0(det.state);
-            int const lead = rl0(det.lead_in);
-            int const low = rl0(det.low);
-            int const high = rl0(det.high);
-            int const run = rl0(det.run);
-            int const maxp = rl0(det.max_pulse);
-            int const onum = rl0((int)det.ook_num);
-            int const eop = rl0(det.eop_spurious);
+            if (loaded != base) {
+                int const il = base + lane;
+                am_l = il < n_t ? ld16(s_am, il) : 0;
+                fm_l = il < n_t ? ld16(s_fm, il) : 0;
+                a64_l = div64(am_l);
+                f64_l = div64(fm_l);
+                bmax = max(s_cmax[base >> 5], s_cmax[(base >> 5) + 1]);
+                bmin = min(s_cmin[base >> 5], s_cmin[(base >> 5) + 1]);
+                loaded = base;
+            }
+            bool const in_seg = base + lane >= i && base + lane < e;
+            int const st = det.state;
 
-            int const il = base + lane;
-            bool const in_seg = il >= i && il < e;
-            int const am_l = in_seg ? ld16(s_am, il) : 0;
-            int const bmax = max(s_cmax[base >> 5], s_cmax[(base >> 5) + 1]);
-            int const bmin = min(s_cmin[base >> 5], s_cmin[(base >> 5) + 1]);
-
-            enum { M_GENERIC, M_LEAD, M_CHASE, M_GAP, M_PULSE };
-            int mode = M_GENERIC;
-            int k = i;
+            int k = i; // fast paths run [i, k); the general step takes over at k
             if (st == ST_IDLE) {
-                if (lead <= 1024) { // no pulse can start during the lead-in (pulse_detect.c:310)
-                    k = min(e, i + (1025 - lead));
-                    mode = M_LEAD;
+                if (det.lead_in <= 1024) { // no pulse can start during the lead-in (pulse_detect.c:310)
+                    k = min(e, i + (1025 - det.lead_in));
+                    det.lead_in += k - i;
                 }
                 else {
                     // lowest threshold the idle state can present while it chases the noise floor in this block
-                    int const l_lb = min(low, bmin) - 1;
+                    int const l_lb = min(det.low, bmin) - 1;
                     int thr = (int)(int16_t)((l_lb + min(cfg.min_high, cfg.max_high)) / 2);
                     if (cfg.fixed_high != 0)
                         thr = (int)(int16_t)cfg.fixed_high;
                     int const hys = (int)(int16_t)(thr / 8);
                     unsigned long long const m = __ballot(in_seg && am_l > thr + hys);
                     k = m ? base + (__ffsll(m) - 1) : e;
-                    mode = M_CHASE;
+                }
+                // idle arm without the (impossible) pulse start, pulse_detect.c:326-334
+                int lo_est = det.low;
+                bool const near = max(det.low, bmax) - min(det.low, bmin) < 1000; // |am - low| < 1024 throughout
+                if (near) {
+                    for (int j = i; j < k; ++j) {
+                        int const am = __builtin_amdgcn_readlane(am_l, j - base);
+                        lo_est += am > lo_est ? 1 : -1;
+                    }
+                }
+                else {
+                    for (int j = i; j < k; ++j) {
+                        int const dl = __builtin_amdgcn_readlane(am_l, j - base) - lo_est;
+                        lo_est += div1024(dl);
+                        lo_est += dl > 0 ? 1 : -1;
+                    }
+                }
+                if (k > i) {
+                    det.low = lo_est;
+                    det.high = max(cfg.ratio * lo_est, cfg.min_high);
                 }
             }
             else if (st == ST_GAP) {
-                int thr = (int)(int16_t)((low + min(high, cfg.max_high)) / 2);
+                int thr = (int)(int16_t)((det.low + min(det.high, cfg.max_high)) / 2);
                 if (cfg.fixed_high != 0)
                     thr = (int)(int16_t)cfg.fixed_high;
                 int const hys = (int)(int16_t)(thr / 8);
                 unsigned long long const m = __ballot(in_seg && am_l > thr + hys);
                 int const ka = m ? base + (__ffsll(m) - 1) : e;
                 // first sample whose gap count ends the package (pulse_detect.c:446-450)
-                long long const lim = min(max(10ll * maxp, 10ll * cfg.per_ms), 100ll * cfg.per_ms);
-                long long const togo = eop ? 0 : max(0ll, lim - (long long)run);
+                long long const lim = min(max(10ll * det.max_pulse, 10ll * cfg.per_ms), 100ll * cfg.per_ms);
+                long long const togo = det.eop_spurious ? 0 : max(0ll, lim - (long long)det.run);
                 int const ke = togo < (long long)(e - i) ? i + (int)togo : e;
                 k = min(ka, ke);
-                mode = M_GAP;
+                det.run += k - i;
             }
-            else if (st == ST_PULSE && onum > 0) {
-                // the level estimate cannot climb above max(high, block max); below that threshold no
-                // sample can be a falling edge
-                int const h_ub = max(high, bmax) + 1;
-                int thr = (int)(int16_t)((low + min(h_ub, cfg.max_high)) / 2);
+            else if (st == ST_PULSE && det.ook_num > 0) {
+                // the level estimate cannot climb above max(high, block max); below the threshold that
+                // belongs to it no sample can be a falling edge
+                int const h_ub = max(det.high, bmax) + 1;
+                int thr = (int)(int16_t)((det.low + min(h_ub, cfg.max_high)) / 2);
                 if (cfg.fixed_high != 0)
                     thr = (int)(int16_t)cfg.fixed_high;
                 int const hys = (int)(int16_t)(thr / 8);
                 unsigned long long const m = __ballot(in_seg && am_l < thr - hys);
                 k = m ? base + (__ffsll(m) - 1) : e;
-                mode = M_PULSE;
+                int h = det.high, f1 = det.ook_f1;
+                for (int j = i; j < k; ++j) { // pulse arm without the falling edge, pulse_detect.c:359-366
+                    h += __builtin_amdgcn_readlane(a64_l, j - base) - div64(h);
+                    h = max(h, cfg.min_high);
+                    f1 += __builtin_amdgcn_readlane(f64_l, j - base) - div64(f1);
+                }
+                det.high = h;
+                det.ook_f1 = f1;
+                det.run += k - i;
             }
 
-            int consumed = 0;
-            if (lane == 0) {
-                int j = i;
-                if (mode == M_LEAD || mode == M_CHASE) {
-                    int lo_est = det.low;
-                    for (; j < k; ++j) { // idle arm without the (impossible) pulse start, pulse_detect.c:326-334
-                        int const dl = ld16(s_am, j) - lo_est;
-                        lo_est += dl / 1024;
-                        lo_est += dl > 0 ? 1 : -1;
-                    }
-                    if (k > i) {
-                        det.low = lo_est;
-                        det.high = max(cfg.ratio * lo_est, cfg.min_high);
-                        if (mode == M_LEAD)
-                            det.lead_in += k - i;
-                    }
-                }
-                else if (mode == M_GAP) {
-                    det.run += k - i;
-                    j = k;
-                }
-                else if (mode == M_PULSE) {
-                    int h = det.high, f1 = det.ook_f1;
-                    for (; j < k; ++j) { // pulse arm without the falling edge, pulse_detect.c:359-366
-                        int const am = ld16(s_am, j), fm = ld16(s_fm, j);
-                        h += am / 64 - h / 64;
-                        h = max(h, cfg.min_high);
-                        f1 += fm / 64 - f1 / 64;
-                    }
-                    det.high = h;
-                    det.ook_f1 = f1;
-                    det.run += k - i;
-                }
-                // the exact general step for the candidate sample and for the states that need every sample
-                if (j < e) {
-                    int local_dc = dc + (j - i);
+            int consumed = k - i;
+            if (k < e) { // the exact general step: candidate samples, and the states that need every sample
+                int taken = 0;
+                if (lane == 0) {
+                    int j = k;
+                    int local_dc = dc + (k - i);
                     do {
                         int const am = ld16(s_am, j), fm = ld16(s_fm, j);
                         int const r = det_step(det, cfg, am, fm, flen, local_dc, input_pos, frame);
@@ -657,10 +670,18 @@ template <int SS> __global__ __launch_bounds__(64) void k_wave(StreamParams p)
                         ++j;
                         ++local_dc;
                     } while (j < e && (det.state == ST_GAP_START || (det.state == ST_PULSE && det.ook_num == 0)));
+                    taken = j - k;
                 }
-                consumed = j - i;
+                consumed += rl0(taken);
+                det.state = rl0(det.state);
+                det.run = rl0(det.run);
+                det.max_pulse = rl0(det.max_pulse);
+                det.lead_in = rl0(det.lead_in);
+                det.low = rl0(det.low);
+                det.high = rl0(det.high);
+                det.ook_num = (uint32_t)rl0((int)det.ook_num);
+                det.eop_spurious = rl0(det.eop_spurious);
             }
-            consumed = rl0(consumed);
             i += consumed;
             dc += consumed;
             if (dc == flen) {
@@ -771,10 +792,26 @@ void launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st)
     if (p.n_streams == 0)
         return;
     dim3 grid(p.n_streams), block(64);
+    // FAST: no filter step can wrap and both feedback coefficients are non-negative (see Track16).
+    // The AM filter always qualifies (13993 + 2*1195 <= 16384); the FM filter does for every cutoff
+    // up to half the Nyquist rate, which includes the defaults.
+    bool fast;
     if (sample_size == 2)
-        hipLaunchKernelGGL(k_wave<2>, grid, block, 0, st, p);
+        fast = !p.enable_fm || (p.a16 >= 0 && p.b16 >= 0 && p.a16 + 2 * p.b16 <= 16384);
     else
-        hipLaunchKernelGGL(k_wave<4>, grid, block, 0, st, p);
+        fast = !p.enable_fm || (p.a32 >= 0 && p.b32 >= 0 && p.a32 + 2 * p.b32 <= (1ll << 30));
+    if (sample_size == 2) {
+        if (fast)
+            hipLaunchKernelGGL((k_wave<2, true>), grid, block, 0, st, p);
+        else
+            hipLaunchKernelGGL((k_wave<2, false>), grid, block, 0, st, p);
+    }
+    else {
+        if (fast)
+            hipLaunchKernelGGL((k_wave<4, true>), grid, block, 0, st, p);
+        else
+            hipLaunchKernelGGL((k_wave<4, false>), grid, block, 0, st, p);
+    }
 }
 
 void launch_pkg_scan(StreamState const *state, uint32_t n_streams, uint32_t *pkg_base, uint32_t *scal, hipStream_t st)
