@@ -1,0 +1,69 @@
+"""The drop-in boundary: struct layouts equal the compiled reference's, the shared library exports
+every entry point include/r433_hip.h declares, and nothing computes without a HIP device."""
+import ctypes as C
+import json
+import os
+import re
+
+import pytest
+
+from rtl_433_amd import _lib
+from rtl_433_amd.engine import DEFAULT_DEVICE_TABLE
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "r433_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b(r433_[a-z0-9_]+)\s*\(", text))
+    names -= set(re.findall(r"\(\*\s*(r433_[a-z0-9_]+)\s*\)", text))  # function-pointer typedefs
+    return sorted(names)
+
+
+def test_header_and_binding_table_agree():
+    assert _declared() == sorted(_lib.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("librtl433hip.so not built yet (python -m rtl_433_amd.build)")
+    L = C.CDLL(_lib.LIB_PATH)
+    missing = [n for n in _declared() if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_struct_layouts_equal_the_compiled_reference():
+    sizes = json.load(open(DEFAULT_DEVICE_TABLE))["abi_sizes"]  # sizeof/offsetof from the reference build
+    bitbuffer, pulse_data, r_device, off_decode_fn, off_priority, off_ctx, off_pulse, off_low = sizes
+    assert (bitbuffer, pulse_data, r_device) == (6604, 9672, 152)
+    assert C.sizeof(_lib.RDevice) == r_device
+    assert _lib.RDevice.decode_fn.offset == off_decode_fn
+    assert _lib.RDevice.priority.offset == off_priority
+    assert _lib.RDevice.decode_ctx.offset == off_ctx
+    hdr = open(os.path.join(ROOT, "include", "r433_abi.h")).read()
+    for n in (bitbuffer, pulse_data, r_device, off_pulse, off_low, off_decode_fn, off_priority, off_ctx):
+        assert f"== {n}" in hdr, f"static_assert for {n} missing from r433_abi.h"
+
+
+def test_no_cpu_fallback_without_a_device():
+    """On a box without a GPU every compute entry point must refuse (R433_ENODEV), never compute."""
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("librtl433hip.so not built yet")
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    L = _lib.lib()
+    assert L.r433_device_count() == -2  # R433_ENODEV
+    cfg = _lib.FlowCfg()
+    L.r433_flow_cfg_default(C.byref(cfg), 2, 250000)
+    assert not L.r433_batch_create(C.byref(cfg), None, 0)
+    assert L.r433_envelope_detect(None, None, 0, None, None) == -2
+    assert b"HIP" in L.r433_last_error() or b"device" in L.r433_last_error()
+
+
+def test_missing_library_is_a_hard_error(monkeypatch):
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/librtl433hip.so")
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()
