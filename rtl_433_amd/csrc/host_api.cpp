@@ -13,6 +13,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -175,6 +178,99 @@ template <typename T> struct PinBuf {
     }
 };
 
+
+// Persistent host workers for the decoder dispatch (spawning 32 threads per batch costs more than
+// dispatching a small batch).
+class Pool {
+  public:
+    ~Pool() { stop(); }
+    void run(unsigned n, std::function<void(unsigned)> const &job)
+    {
+        if (n <= 1) {
+            job(0);
+            return;
+        }
+        grow(n - 1);
+        {
+            std::lock_guard<std::mutex> g(m_);
+            job_ = &job;
+            want_ = n - 1;
+            pending_ = n - 1;
+            ++epoch_;
+        }
+        cv_.notify_all();
+        job(0);
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [&] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+  private:
+    void grow(unsigned n)
+    {
+        while (threads_.size() < n) {
+            unsigned id = (unsigned)threads_.size();
+            threads_.emplace_back([this, id] { loop(id); });
+        }
+    }
+    void loop(unsigned id)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            std::function<void(unsigned)> const *job = nullptr;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return quit_ || (epoch_ != seen && id < want_); });
+                if (quit_)
+                    return;
+                seen = epoch_;
+                job = job_;
+            }
+            (*job)(id + 1);
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (--pending_ == 0)
+                    done_.notify_all();
+            }
+        }
+    }
+    void stop()
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : threads_)
+            t.join();
+        threads_.clear();
+    }
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> threads_;
+    std::function<void(unsigned)> const *job_ = nullptr;
+    unsigned want_ = 0, pending_ = 0;
+    uint64_t epoch_ = 0;
+    bool quit_ = false;
+};
+
+// The checksum plugin accumulates per thread and publishes once per dispatch: a shared counter hit by
+// every bitbuffer from 32 threads is a cache-line ping-pong that costs more than the decoding.
+struct DigestLocal {
+    r433_digest_ctx *ctx = nullptr;
+    uint64_t sum = 0, events = 0;
+};
+thread_local DigestLocal g_digest;
+
+void digest_publish()
+{
+    if (g_digest.ctx && g_digest.events) {
+        __atomic_fetch_add(&g_digest.ctx->sum, g_digest.sum, __ATOMIC_RELAXED);
+        __atomic_fetch_add(&g_digest.ctx->events, g_digest.events, __ATOMIC_RELAXED);
+    }
+    g_digest = DigestLocal();
+}
+
 } // namespace
 
 struct r433_batch {
@@ -215,6 +311,7 @@ struct r433_batch {
     // dispatch scratch
     r433_bitbuffer *bits = nullptr;
     r433_pulse_data *pulses = nullptr;
+    Pool pool;
 };
 
 extern "C" {
@@ -851,25 +948,23 @@ int r433_batch_dispatch_mt(r433_batch *b, r433_r_device *const *devices, uint32_
     std::vector<std::string> errs(n_threads);
     if (n_threads == 1) {
         results[0] = dispatch_range(b, devices, n_devices, pkg_cb, user, 0, np, stats[0], errs[0]);
+        digest_publish();
     }
     else {
-        // contiguous package ranges balanced by event bytes
-        std::vector<uint32_t> cut(n_threads + 1, np);
-        cut[0] = 0;
-        uint64_t const total = b->evt_bytes + np; // +1 per package so empty ones still spread
-        uint32_t t = 1;
-        for (uint32_t pkg = 0; pkg < np && t < n_threads; ++pkg) {
-            uint64_t w = (uint64_t)b->h_pkg_off.p[pkg] + pkg;
-            while (t < n_threads && w >= total * t / n_threads)
-                cut[t++] = pkg;
-        }
-        std::vector<std::thread> pool;
-        for (uint32_t i = 0; i < n_threads; ++i)
-            pool.emplace_back([&, i] {
-                results[i] = dispatch_range(b, devices, n_devices, pkg_cb, user, cut[i], cut[i + 1], stats[i], errs[i]);
-            });
-        for (auto &th : pool)
-            th.join();
+        // packages are handed out in small contiguous runs from a shared cursor: event counts per
+        // package vary by orders of magnitude, static ranges leave most workers idle at the end
+        uint32_t const grain = std::max<uint32_t>(1, std::min<uint32_t>(16, np / (n_threads * 8)));
+        std::atomic<uint32_t> cursor{0};
+        b->pool.run(n_threads, [&](unsigned w) {
+            for (;;) {
+                uint32_t p0 = cursor.fetch_add(grain, std::memory_order_relaxed);
+                if (p0 >= np || results[w] < 0)
+                    break;
+                int r = dispatch_range(b, devices, n_devices, pkg_cb, user, p0, std::min(np, p0 + grain), stats[w], errs[w]);
+                results[w] = r < 0 ? r : results[w] + r;
+            }
+            digest_publish();
+        });
     }
     int decoded = 0;
     for (uint32_t i = 0; i < n_threads; ++i) {
@@ -924,8 +1019,12 @@ int r433_plugin_digest_decode(r433_r_device *decoder, r433_bitbuffer *bits)
         mix(&bits->syncs_before_row[r], 2);
         mix(bits->bb[r], ((unsigned)bits->bits_per_row[r] + 7) / 8);
     }
-    __atomic_fetch_add(&ctx->sum, x, __ATOMIC_RELAXED);
-    __atomic_fetch_add(&ctx->events, 1ull, __ATOMIC_RELAXED);
+    if (g_digest.ctx != ctx) {
+        digest_publish();
+        g_digest.ctx = ctx;
+    }
+    g_digest.sum += x; // published by the dispatcher when this thread is done with the batch
+    g_digest.events += 1;
     return R433_DECODE_ABORT_LENGTH;
 }
 
