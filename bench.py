@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1024, help="captures per GPU")
     ap.add_argument("--samples", type=int, default=65536, help="samples per capture")
     ap.add_argument("--threads", type=int, default=0, help="host dispatch threads per rank (0 = auto)")
+    ap.add_argument("--engines", type=int, default=3, help="batch engines in the software pipeline (>= 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -116,22 +117,23 @@ def main():
     # path over the batch, and all K of them finish inside the timed region.
     from concurrent.futures import ThreadPoolExecutor
     from rtl_433_amd import shard
-    engines = [eng, BatchEngine(flow_cfg(2, 250000), devs, profiling=True)]
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-    gpu_thread = ThreadPoolExecutor(1)
+    n_eng = max(2, args.engines)
+    engines = [eng] + [BatchEngine(flow_cfg(2, 250000), devs, profiling=True) for _ in range(n_eng - 1)]
+    streams = [torch.cuda.Stream() for _ in range(n_eng)]
+    gpu_threads = ThreadPoolExecutor(n_eng - 1)
     dev = torch.device("cuda", local_rank)
 
     def gpu_leg(k):
         torch.cuda.set_device(local_rank)
-        e = engines[k & 1]
-        return e.run(d_iq, stream=streams[k & 1].cuda_stream), e.timing()
+        e = engines[k % n_eng]
+        return e.run(d_iq, stream=streams[k % n_eng].cuda_stream), e.timing()
 
     state = {}
 
     def host_leg(k, n_pkgs):
         ctx.sum = 0
         ctx.events = 0
-        engines[k & 1].dispatch(rdev_arr, n_threads=threads)
+        engines[k % n_eng].dispatch(rdev_arr, n_threads=threads)
         if dist:  # the only collective: per-rank decode results to rank 0 (RCCL over xGMI)
             rec = np.array([rank, n_pkgs, ctx.events, ctx.sum & 0xFFFFFFFF, ctx.sum >> 32], dtype=np.uint64).tobytes()
             got = shard.gather_bytes(rec, dst=0, device=dev)
@@ -139,15 +141,18 @@ def main():
                 state["ranks"] = [np.frombuffer(g, dtype=np.uint64) for g in got]
 
     def run_steps(n):
+        """n complete passes; up to n_eng-1 GPU legs run ahead of the host leg (in-order hand-off)."""
+        from collections import deque
         det, tot, host = [], [], []
-        if n == 0:
-            return det, tot, host, 0
-        fut = gpu_thread.submit(gpu_leg, 0)
-        n_pkgs = 0
+        futs, nxt, n_pkgs = deque(), 0, 0
+        while nxt < min(n, n_eng - 1):
+            futs.append(gpu_threads.submit(gpu_leg, nxt))
+            nxt += 1
         for k in range(n):
-            n_pkgs, tm = fut.result()
-            if k + 1 < n:
-                fut = gpu_thread.submit(gpu_leg, k + 1)
+            n_pkgs, tm = futs.popleft().result()
+            if nxt < n:  # engine (k-1) % n_eng: its host leg is done
+                futs.append(gpu_threads.submit(gpu_leg, nxt))
+                nxt += 1
             t1 = time.perf_counter()
             host_leg(k, n_pkgs)
             host.append(time.perf_counter() - t1)
@@ -155,6 +160,10 @@ def main():
             tot.append(tm["total_ms"])
         return det, tot, host, n_pkgs
 
+    # kernel timing for the roofline block: one pass alone on the device (HIP events on its stream)
+    solo = [gpu_leg(0)[1] for _ in range(3)]
+    solo_det_ms = min(t["detect_ms"] for t in solo)
+    solo_tot_ms = min(t["total_ms"] for t in solo)
     run_steps(args.warmup)
     if dist:
         dist.barrier()
@@ -173,7 +182,7 @@ def main():
     if rank == 0:
         total_samples = world * n_streams * n_samples * args.steps
         value = total_samples / elapsed / 1e6
-        det_s = float(np.mean(det_ms)) / 1e3
+        det_s = solo_det_ms / 1e3
         alg_bytes = 2.0 * n_streams * n_samples  # 2 B per cu8 IQ sample, read once
         achieved = alg_bytes / det_s / 1e9
         out = {
@@ -196,9 +205,10 @@ def main():
                        "parallelism": f"captures sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "k_wave<2> (IQ -> packages)", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None},
-            "breakdown_ms": {"k_wave": round(float(np.mean(det_ms)), 3), "gpu_total_incl_d2h": round(float(np.mean(tot_ms)), 3),
-                             "host_dispatch": round(float(np.mean(disp_s)) * 1e3, 3),
-                             "note": "GPU leg of step k+1 overlaps the host leg of step k (two engines, two HIP streams)"},
+            "breakdown_ms": {"k_wave_alone": round(solo_det_ms, 3), "gpu_leg_alone_incl_d2h": round(solo_tot_ms, 3),
+                             "gpu_leg_overlapped": round(float(np.mean(tot_ms)), 3),
+                             "host_dispatch": round(float(np.mean(disp_s)) * 1e3, 3), "engines": n_eng,
+                             "note": "steps are software-pipelined: up to engines-1 GPU legs (own HIP streams) run under the host leg of an earlier step"},
             "packages_per_step": int(n_pkgs), "events_per_step": int(ctx.events),
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -212,7 +222,7 @@ def main():
         print(json.dumps(out), flush=True)
     for e in engines:
         e.close()
-    gpu_thread.shutdown()
+    gpu_threads.shutdown()
     if dist:
         dist.destroy_process_group()
 

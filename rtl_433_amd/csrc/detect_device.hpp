@@ -10,8 +10,8 @@
 // in the idle state, "eop on spurious pulse" is forgotten at call boundaries.
 //
 // Output: r433_pkg_rec records (include/r433_records.h) appended to a per-capture arena in HBM.
-// The open OOK package grows in place at the arena cursor; the FSK candidate lives in an LDS
-// ring because the reference keeps it alive next to the OOK package.
+// The open OOK package grows in place at the arena cursor; the FSK candidate lives in a
+// per-capture scratch ring because the reference keeps it alive next to the OOK package.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -50,7 +50,7 @@ struct DetLane {
     int eop_spurious;
     // arena
     uint8_t *arena;
-    int2 *fsk_ring;     // LDS, R433_PD_MAX_PULSES entries
+    int2 *fsk_ring;     // per-capture scratch, R433_PD_MAX_PULSES entries
     uint32_t arena_cap;
     uint32_t cursor;    // bytes of finished records
     uint32_t n_pkgs;

@@ -147,7 +147,6 @@ template <int SS, bool FAST> __global__ __launch_bounds__(64) void k_wave(Stream
     __shared__ __attribute__((aligned(16))) uint8_t s_f[64 * G::f_pitch];
     __shared__ __attribute__((aligned(16))) uint8_t s_am[64 * kPitch16];
     __shared__ __attribute__((aligned(16))) uint8_t s_fm[64 * kPitch16];
-    __shared__ int2 s_ring[R433_PD_MAX_PULSES];
     __shared__ int s_cmax[64], s_cmin[64];
 
     int const lane = (int)threadIdx.x;
@@ -165,7 +164,7 @@ template <int SS, bool FAST> __global__ __launch_bounds__(64) void k_wave(Stream
     DetCfg const cfg = p.det;
     det_reset(det);
     det.arena = p.arena + (uint64_t)s * p.arena_stride;
-    det.fsk_ring = s_ring;
+    det.fsk_ring = p.fsk_ring + (uint64_t)s * R433_PD_MAX_PULSES; // HBM scratch, touched by lane 0 on FSK pulses only
     det.arena_cap = p.arena_stride;
     det.stream = s;
     det.cursor = 0;
