@@ -142,6 +142,45 @@ template <bool WRITE> struct BitSink {
         }
     }
 
+    // n calls of add_bit(bit), a word at a time: the long constant runs of the PCM-type slicers
+    // (a 500 us pulse against a 5 us bit period is 100 bits) otherwise serialise a whole wavefront
+    // behind one lane.  Stops exactly where add_bit would start refusing bits.
+    __device__ __forceinline__ void add_run(int bit, int n)
+    {
+        if (n <= 0)
+            return;
+        touch();
+        while (n > 0) {
+            if (cur_bits == 65535u)
+                return;
+            if (cur_bits > 0 && (cur_bits & 1023u) == 0) {
+                if (free_row < R433_BB_ROWS)
+                    free_row++;
+                else
+                    return;
+            }
+            uint32_t const room = 32u - (cur_bits & 31u);
+            uint32_t take = min(min((uint32_t)n, room), 65535u - cur_bits);
+            if (bit) {
+                uint32_t const ones = take == 32u ? 0xffffffffu : ((1u << take) - 1u);
+                acc |= ones << (room - take);
+            }
+            cur_bits += take;
+            n -= (int)take;
+            if (num_rows == 1)
+                row0_bits = cur_bits;
+            if (cur_bits > extent)
+                extent = cur_bits;
+            if ((cur_bits & 31u) == 0) {
+                uint32_t k = (cur_bits >> 5) - 1;
+                store_word(k, acc);
+                if (k >= written)
+                    written = k + 1;
+                acc = 0;
+            }
+        }
+    }
+
     __device__ __forceinline__ void add_row()
     {
         touch();
@@ -303,11 +342,9 @@ template <bool W> __device__ __forceinline__ void slice_pcm(PulseView const &p, 
         int pu = p.pulse(n), ga = p.gap(n);
         int highs = round_f(pu, f_sh);
         int lows = round_f(ga + t.s_short - t.s_long, f_lo);
-        for (int i = 0; i < highs; ++i)
-            s.add_bit(1);
+        s.add_run(1, highs);
         lows = min(lows, max_zeros);
-        for (int i = 0; i < lows; ++i)
-            s.add_bit(0);
+        s.add_run(0, lows);
         if (rz && abs(pu - t.s_short) > tol)
             s.clear();
         else if (ga > gap_limit && ga <= t.s_reset)
@@ -491,8 +528,7 @@ template <bool W> __device__ __forceinline__ void slice_piwm_raw(PulseView const
             s.add_row();
         }
         else if (abs(sym - w * t.s_short) < t.s_tol) {
-            for (; w > 0; --w)
-                s.add_bit(1 - (int)(k & 1));
+            s.add_run(1 - (int)(k & 1), w);
         }
         else if (sym < t.s_reset && s.num_rows > 0 && s.last_row_bits() > 0) {
             s.add_row();
@@ -529,8 +565,7 @@ template <bool W> __device__ __forceinline__ void slice_nrzs(PulseView const &p,
             if (lim <= 0)
                 return; // the reference would divide by zero; no registered device has short_width == 0
             int ones = w / lim;
-            for (int i = 0; i < ones; ++i)
-                s.add_bit(1);
+            s.add_run(1, ones);
             s.add_bit(0);
         }
         else if (w < lim) {
@@ -605,8 +640,7 @@ template <bool W> __device__ __forceinline__ void slice_rzi(PulseView const &p, 
         int w = p.pulse(n);
         int ones = fresh ? (w + t.s_long / 2) / t.s_long : (w - base + t.s_long / 2) / t.s_long;
         fresh = false;
-        for (int k = 0; k < ones; ++k)
-            s.add_bit(1);
+        s.add_run(1, ones);
         if (p.gap(n) > t.s_reset || n == p.num - 1) {
             if (s.row0_bits > 0)
                 s.fire();
