@@ -27,6 +27,8 @@
 // Replaces, for file input: envelope_detect / magnitude_est_* (reference src/baseband.c:36-110),
 // baseband_low_pass_filter (:145-169), baseband_demod_FM(_cs16) (:210-366), the frame loop of
 // push_sdr_flow (src/r_flow.c:149-244) and pulse_detect_package (src/pulse_detect.c:199-483).
+#include <type_traits>
+
 #include "dsp_device.hpp"
 #include "r433_internal.hpp"
 
@@ -140,7 +142,7 @@ __device__ __forceinline__ int div1024(int v)
     return (v + ((v >> 31) & 1023)) >> 10;
 }
 
-template <int SS, bool FAST> __global__ __launch_bounds__(64) void k_wave(StreamParams p)
+template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wave(StreamParams p)
 {
     using G = Geom<SS>;
     __shared__ __attribute__((aligned(16))) uint8_t s_env[64 * kPitch16];
@@ -242,7 +244,7 @@ template <int SS, bool FAST> __global__ __launch_bounds__(64) void k_wave(Stream
                     cq = (int)(int16_t)(wd[j] >> 16);
                     ev[j] = env_mag_cs16(ci, cq);
                 }
-                if (p.enable_fm) {
+                if (FM) {
                     if (SS == 2) {
                         int dot = ci * pi_ + cq * pq_;
                         int crs = cq * pi_ - ci * pq_;
@@ -331,16 +333,13 @@ template <int SS, bool FAST> __global__ __launch_bounds__(64) void k_wave(Stream
         int csum = 0; // envelope sum of my chunk (frame average)
         int cmax = -0x7fffffff, cmin = 0x7fffffff;
 
-#pragma unroll 1
-        for (int q = 0; q <= kWarmChunks; ++q) {
-            int const c = lane - kWarmChunks + q; // chunk being read
-            bool const main_run = q == kWarmChunks;
-            if (c < 0)
-                continue;
+        // one chunk of 32 steps for both filters; MAIN = my own chunk (publish, statistics)
+        auto chunk_pass = [&](int c, auto main_tag) {
+            constexpr bool MAIN = decltype(main_tag)::value;
             // a frame starts here: the AM filter state keeps x[-1] in an int16 slot (baseband.c:166-168)
             if ((fs_mask >> c) & 1ull)
                 xa1 = (int)(int16_t)xa1;
-            if (main_run) {
+            if (MAIN) {
                 sa.start_known = ta.exact();
                 sa.lo0 = ta.lo, sa.hi0 = ta.hi;
                 if (SS == 2) {
@@ -357,7 +356,7 @@ template <int SS, bool FAST> __global__ __launch_bounds__(64) void k_wave(Stream
                 uint4 const e4 = *(uint4 const *)(s_env + c * kPitch16 + g * 16);
                 uint32_t const ew[4] = {e4.x, e4.y, e4.z, e4.w};
                 uint4 f4a = make_uint4(0, 0, 0, 0), f4b = make_uint4(0, 0, 0, 0);
-                if (p.enable_fm) {
+                if (FM) {
                     if (SS == 2) {
                         f4a = *(uint4 const *)(s_f + c * G::f_pitch + g * 16);
                     }
@@ -372,14 +371,14 @@ template <int SS, bool FAST> __global__ __launch_bounds__(64) void k_wave(Stream
                 for (int u = 0; u < 8; ++u) {
                     // samples past the end of the capture are stepped too (their results are never
                     // read); only the chunk statistics have to leave them out
-                    int const lv = main_run ? (int)(g * 8 + u < cnt) : 1;
+                    int const lv = MAIN ? (int)(g * 8 + u < cnt) : 1;
                     int const x = (int)((ew[u >> 1] >> ((u & 1) * 16)) & 0xffffu);
                     int const alo = ta.lo, ahi = ta.hi;
                     ta.step(kLpfA, mul24(kLpfB, x + xa1));
                     xa1 = x;
                     int fm_out;
                     int f_same = 1;
-                    if (p.enable_fm) {
+                    if (FM) {
                         if (SS == 2) {
                             int const f = (int)(int16_t)((fw[u >> 1] >> ((u & 1) * 16)) & 0xffffu);
                             int const flo = tf16.lo, fhi = tf16.hi;
@@ -400,7 +399,7 @@ template <int SS, bool FAST> __global__ __launch_bounds__(64) void k_wave(Stream
                     else {
                         fm_out = (int)(int16_t)x; // buf.fm aliases the raw envelope (include/r_private.h:32-36)
                     }
-                    if (main_run) {
+                    if (MAIN) {
                         sa.ident &= ((int)(ta.lo == alo) & (int)(ta.hi == ahi)) | (lv ^ 1);
                         sf.ident &= f_same | (lv ^ 1);
                         csum += lv ? x : 0;
@@ -410,15 +409,22 @@ template <int SS, bool FAST> __global__ __launch_bounds__(64) void k_wave(Stream
                         of[u >> 1] |= ((uint32_t)fm_out & 0xffffu) << ((u & 1) * 16);
                     }
                 }
-                if (main_run) {
+                if (MAIN) {
                     *(uint4 *)(s_am + lane * kPitch16 + g * 16) = make_uint4(oa[0], oa[1], oa[2], oa[3]);
                     *(uint4 *)(s_fm + lane * kPitch16 + g * 16) = make_uint4(of[0], of[1], of[2], of[3]);
                 }
             }
+        };
+#pragma unroll 1
+        for (int q = 0; q < kWarmChunks; ++q) {
+            int const c = lane - kWarmChunks + q; // chunk being read
+            if (c >= 0)
+                chunk_pass(c, std::false_type{});
         }
+        chunk_pass(lane, std::true_type{});
         sa.end_known = ta.exact();
         sa.y_end = ta.lo;
-        if (!p.enable_fm) {
+        if (!FM) {
             sf.start_known = sf.end_known = true;
             sf.y_end = 0;
         }
@@ -441,7 +447,7 @@ template <int SS, bool FAST> __global__ __launch_bounds__(64) void k_wave(Stream
         // ---- resolve the lanes whose warm-up did not collapse, left to right ----
         // which: 0 = AM, 1 = FM.  Wave-uniform control flow; every round settles at least the first
         // unresolved lane of every run (lanes 0..3 always start from the proven tile carry).
-        for (int which = 0; which < (p.enable_fm ? 2 : 1); ++which) {
+        for (int which = 0; which < (FM ? 2 : 1); ++which) {
             ChunkStatus &st = which == 0 ? sa : sf;
             for (int round = 0;; ++round) {
                 unsigned long long const open = __ballot(!st.start_known);
@@ -599,12 +605,29 @@ template <int SS, bool FAST> __global__ __launch_bounds__(64) void k_wave(Stream
                 }
                 // idle arm without the (impossible) pulse start, pulse_detect.c:326-334
                 int lo_est = det.low;
+                int const n_st = k - i;
                 bool const near = max(det.low, bmax) - min(det.low, bmin) < 1000; // |am - low| < 1024 throughout
-                if (near) {
-                    for (int j = i; j < k; ++j) {
-                        int const am = __builtin_amdgcn_readlane(am_l, j - base);
-                        lo_est += am > lo_est ? 1 : -1;
+                if (near && bmax == bmin) {
+                    // constant block (digital silence): walk to the level, then alternate a, a-1
+                    int const a = bmax;
+                    if (lo_est < a) {
+                        int const t_up = a - lo_est;
+                        lo_est = n_st <= t_up ? lo_est + n_st : a - ((n_st - t_up) & 1);
                     }
+                    else {
+                        int const t_dn = lo_est - (a - 1);
+                        lo_est = n_st <= t_dn ? lo_est - n_st : a - 1 + ((n_st - t_dn) & 1);
+                    }
+                }
+                else if (near) {
+                    int j = i;
+                    for (; j + 8 <= k; j += 8) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            lo_est += __builtin_amdgcn_readlane(am_l, j - base + u) > lo_est ? 1 : -1;
+                    }
+                    for (; j < k; ++j)
+                        lo_est += __builtin_amdgcn_readlane(am_l, j - base) > lo_est ? 1 : -1;
                 }
                 else {
                     for (int j = i; j < k; ++j) {
@@ -643,7 +666,16 @@ template <int SS, bool FAST> __global__ __launch_bounds__(64) void k_wave(Stream
                 unsigned long long const m = __ballot(in_seg && am_l < thr - hys);
                 k = m ? base + (__ffsll(m) - 1) : e;
                 int h = det.high, f1 = det.ook_f1;
-                for (int j = i; j < k; ++j) { // pulse arm without the falling edge, pulse_detect.c:359-366
+                int j = i; // pulse arm without the falling edge, pulse_detect.c:359-366
+                for (; j + 4 <= k; j += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        h += __builtin_amdgcn_readlane(a64_l, j - base + u) - div64(h);
+                        h = max(h, cfg.min_high);
+                        f1 += __builtin_amdgcn_readlane(f64_l, j - base + u) - div64(f1);
+                    }
+                }
+                for (; j < k; ++j) {
                     h += __builtin_amdgcn_readlane(a64_l, j - base) - div64(h);
                     h = max(h, cfg.min_high);
                     f1 += __builtin_amdgcn_readlane(f64_l, j - base) - div64(f1);
@@ -651,6 +683,41 @@ template <int SS, bool FAST> __global__ __launch_bounds__(64) void k_wave(Stream
                 det.high = h;
                 det.ook_f1 = f1;
                 det.run += k - i;
+            }
+            else if (st == ST_GAP_START && det.ook_num > 0) {
+                // debouncing the end of a pulse (pulse_detect.c:376-421) once the FSK candidate is out of
+                // the picture: either the signal comes back before the count reaches 10, or the gap begins
+                int thr = (int)(int16_t)((det.low + min(det.high, cfg.max_high)) / 2);
+                if (cfg.fixed_high != 0)
+                    thr = (int)(int16_t)cfg.fixed_high;
+                int const hys = (int)(int16_t)(thr / 8);
+                unsigned long long const m = __ballot(in_seg && am_l > thr + hys);
+                int const ka = m ? base + (__ffsll(m) - 1) : e;   // first sample above the threshold again
+                int const kg = i + max(0, 9 - det.run);            // sample at which the count reaches 10
+                if (ka <= kg && ka < e) {
+                    det.run += (ka - i) + 1 + det.cur_pulse;
+                    det.state = ST_PULSE;
+                    k = ka + 1;
+                }
+                else if (kg < e) {
+                    det.run += (kg - i) + 1;
+                    det.state = ST_GAP;
+                    k = kg + 1;
+                }
+                else {
+                    det.run += e - i;
+                    k = e;
+                }
+                // everything up to k is done: skip the general step this round
+                int const done = k - i;
+                i += done;
+                dc += done;
+                if (dc == flen) {
+                    input_pos += (uint64_t)flen;
+                    frame += 1;
+                    dc = 0;
+                }
+                continue;
             }
 
             int consumed = k - i;
@@ -680,6 +747,7 @@ template <int SS, bool FAST> __global__ __launch_bounds__(64) void k_wave(Stream
                 det.high = rl0(det.high);
                 det.ook_num = (uint32_t)rl0((int)det.ook_num);
                 det.eop_spurious = rl0(det.eop_spurious);
+                det.cur_pulse = rl0(det.cur_pulse);
             }
             i += consumed;
             dc += consumed;
@@ -799,18 +867,23 @@ void launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st)
         fast = !p.enable_fm || (p.a16 >= 0 && p.b16 >= 0 && p.a16 + 2 * p.b16 <= 16384);
     else
         fast = !p.enable_fm || (p.a32 >= 0 && p.b32 >= 0 && p.a32 + 2 * p.b32 <= (1ll << 30));
-    if (sample_size == 2) {
-        if (fast)
-            hipLaunchKernelGGL((k_wave<2, true>), grid, block, 0, st, p);
-        else
-            hipLaunchKernelGGL((k_wave<2, false>), grid, block, 0, st, p);
-    }
-    else {
-        if (fast)
-            hipLaunchKernelGGL((k_wave<4, true>), grid, block, 0, st, p);
-        else
-            hipLaunchKernelGGL((k_wave<4, false>), grid, block, 0, st, p);
-    }
+    bool const fm = p.enable_fm != 0;
+#define R433_LAUNCH_WAVE(SS)                                                                                           \
+    do {                                                                                                               \
+        if (fast && fm)                                                                                                \
+            hipLaunchKernelGGL((k_wave<SS, true, true>), grid, block, 0, st, p);                                       \
+        else if (fast)                                                                                                 \
+            hipLaunchKernelGGL((k_wave<SS, true, false>), grid, block, 0, st, p);                                      \
+        else if (fm)                                                                                                   \
+            hipLaunchKernelGGL((k_wave<SS, false, true>), grid, block, 0, st, p);                                      \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_wave<SS, false, false>), grid, block, 0, st, p);                                     \
+    } while (0)
+    if (sample_size == 2)
+        R433_LAUNCH_WAVE(2);
+    else
+        R433_LAUNCH_WAVE(4);
+#undef R433_LAUNCH_WAVE
 }
 
 void launch_pkg_scan(StreamState const *state, uint32_t n_streams, uint32_t *pkg_base, uint32_t *scal, hipStream_t st)
