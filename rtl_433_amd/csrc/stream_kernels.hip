@@ -445,21 +445,37 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
         sf.ident &= SS == 2 ? (tf16.ok & (int)(p.a16 >= 0 && p.a16 <= 16384)) : (tf32.ok & (int)(p.a32 >= 0 && p.a32 <= (1ll << 30)));
 
         // ---- resolve the lanes whose warm-up did not collapse, left to right ----
-        // which: 0 = AM, 1 = FM.  Wave-uniform control flow; every round settles at least the first
-        // unresolved lane of every run (lanes 0..3 always start from the proven tile carry).
+        // which: 0 = AM, 1 = FM.  Wave-uniform control flow; every round settles everything up to and
+        // including the first lane of each run that needs an exact re-run (lanes 0..3 always start from
+        // the proven tile carry).
         for (int which = 0; which < (FM ? 2 : 1); ++which) {
             ChunkStatus &st = which == 0 ? sa : sf;
             for (int round = 0;; ++round) {
                 unsigned long long const open = __ballot(!st.start_known);
                 if (!open)
                     break;
-                if (round > 64) { // cannot happen (one lane settles per round); never spin on the GPU
+                if (round > 64) { // cannot happen (the first open lane settles every round); never spin on the GPU
                     det.overflow = 2;
                     break;
                 }
-                int const pk = __shfl_up(st.end_known ? 1 : 0, 1, 64);
-                int const pv = __shfl_up(st.y_end, 1, 64);
-                bool const take = !st.start_known && pk != 0 && lane > 0;
+                // What does the carry look like when it leaves each lane?  CONST(y_end) where the end is
+                // proven, PASS where the chunk maps every candidate to itself, BLOCK where only a re-run
+                // can tell.  An inclusive scan of these transfers (PASS o x = x) carries proven values
+                // across whole runs of stalled lanes in six shuffle steps.
+                enum { T_PASS = 0, T_CONST = 1, T_BLOCK = 2 };
+                int tk = st.end_known ? T_CONST : (st.ident ? T_PASS : T_BLOCK);
+                int tv = st.y_end;
+                for (int o = 1; o < 64; o <<= 1) {
+                    int const qk = __shfl_up(tk, o, 64);
+                    int const qv = __shfl_up(tv, o, 64);
+                    if (lane >= o && tk == T_PASS) {
+                        tk = qk;
+                        tv = qv;
+                    }
+                }
+                int const pk = __shfl_up(tk, 1, 64);
+                int const pv = __shfl_up(tv, 1, 64);
+                bool const take = !st.start_known && pk == T_CONST && lane > 0;
                 bool rerun = false;
                 int y0 = 0;
                 if (take) {
@@ -478,6 +494,8 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                             cmax = cmin = y0;
                     }
                     else {
+                        if (st.ident)
+                            det.overflow = 3; // a proven interval that does not hold the carry: refuse the result
                         rerun = true;
                     }
                 }
