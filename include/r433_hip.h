@@ -97,6 +97,9 @@ typedef struct r433_batch_timing {
     float total_ms;
 } r433_batch_timing;
 int r433_batch_set_profiling(r433_batch *b, int on);
+/* Debugging aid: raw per-capture kernel state of the last run (n_streams records; returns the record size).
+ * With env R433_DEBUG_FLAGS=1024 the detection kernel leaves per-phase clock ticks in it (tools/kbench.py). */
+int r433_batch_debug_state(r433_batch *b, void *host_buf, size_t bytes);
 int r433_batch_get_timing(r433_batch *b, r433_batch_timing *t);
 
 /* ------------------------------------------------------------------------------------------------

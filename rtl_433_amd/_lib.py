@@ -51,7 +51,7 @@ EXPORTS = [
     "r433_version", "r433_last_error", "r433_device_count", "r433_flow_cfg_default", "r433_level_db",
     "r433_batch_create", "r433_batch_destroy", "r433_batch_run", "r433_batch_packages", "r433_batch_events",
     "r433_batch_frame_sums", "r433_batch_device_events", "r433_batch_set_taps", "r433_batch_set_profiling",
-    "r433_batch_get_timing", "r433_batch_dispatch", "r433_batch_dispatch_mt", "r433_dispatch_current",
+    "r433_batch_get_timing", "r433_batch_debug_state", "r433_batch_dispatch", "r433_batch_dispatch_mt", "r433_dispatch_current",
     "r433_plugin_digest_decode", "r433_envelope_detect", "r433_magnitude_est_cu8",
     "r433_magnitude_est_cs16",
 ]
@@ -98,6 +98,8 @@ def bind(L):
     L.r433_batch_set_profiling.argtypes = [vp, C.c_int]
     L.r433_batch_get_timing.restype = C.c_int
     L.r433_batch_get_timing.argtypes = [vp, C.POINTER(BatchTiming)]
+    L.r433_batch_debug_state.restype = C.c_int
+    L.r433_batch_debug_state.argtypes = [vp, vp, C.c_size_t]
     L.r433_batch_dispatch.restype = C.c_int
     L.r433_batch_dispatch.argtypes = [vp, vp, C.c_uint32, vp, vp]
     L.r433_batch_dispatch_mt.restype = C.c_int

@@ -547,7 +547,7 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
         sp.frame_samples = b->cfg.frame_samples;
         sp.flags = 0;
         if (char const *dbg = getenv("R433_DEBUG_FLAGS")) // phase timing experiments only (results are then incomplete)
-            sp.flags |= (uint32_t)strtoul(dbg, nullptr, 0) & (RUN_DBG_SKIP_DETECT | RUN_DBG_SKIP_FILTERS);
+            sp.flags |= (uint32_t)strtoul(dbg, nullptr, 0) & (RUN_DBG_SKIP_DETECT | RUN_DBG_SKIP_FILTERS | RUN_DBG_TIMING);
         sp.det = b->det;
         sp.use_mag = (int)b->cfg.use_mag_est;
         sp.enable_fm = (int)b->cfg.enable_fm;
@@ -739,6 +739,15 @@ int r433_batch_frame_sums(r433_batch *b, uint32_t const **sums, uint32_t *frames
     if (frames_cap)
         *frames_cap = b->frames_cap;
     return 0;
+}
+
+int r433_batch_debug_state(r433_batch *b, void *host_buf, size_t bytes)
+{
+    if (!b || !host_buf)
+        return fail(R433_EINVAL, "null argument");
+    size_t have = (size_t)b->n_streams * sizeof(StreamState);
+    HIP_TRY(hipMemcpy(host_buf, b->d_state.p, bytes < have ? bytes : have, hipMemcpyDeviceToHost));
+    return (int)sizeof(StreamState);
 }
 
 int r433_batch_device_events(r433_batch *b, void const **d_events, size_t *len)

@@ -36,6 +36,7 @@ enum : uint32_t {
     // profiling aids (env R433_DEBUG_FLAGS, never set by the product path): stop after a phase
     RUN_DBG_SKIP_DETECT = 256u,
     RUN_DBG_SKIP_FILTERS = 512u,
+    RUN_DBG_TIMING = 1024u, // per-phase shader-clock ticks into unused StreamState slots (r433_batch_debug_state)
 };
 
 struct StreamParams {

@@ -181,6 +181,11 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
     int carry_yf = 0, carry_ff = 0; // FM low-pass: y[-1], discriminator[-1]
     int carry_i = 0, carry_q = 0;   // last IQ sample, centred
 
+    // profiling aid (RUN_DBG_TIMING): shader-clock ticks per phase, returned in unused StreamState slots
+    bool const timing = (p.flags & RUN_DBG_TIMING) != 0;
+    long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // A+B, idle, gap, pulse, gap-start, general step, resolve, iterations
+    auto now = [&]() -> long long { return timing ? (long long)clock64() : 0ll; };
+
     uint4 pf[G::loads];
     auto issue_loads = [&](uint32_t tile) {
 #pragma unroll
@@ -200,6 +205,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
         int const n_t = (int)min((uint32_t)kTile, my_n - t0); // valid samples in it
 
         // ================= phase A: envelope + discriminator, 8 samples per lane and row =================
+        long long const t_tile = now();
         __syncthreads(); // previous tile's readers are done with the LDS buffers
 #pragma unroll
         for (int r = 0; r < kRows; ++r) {
@@ -579,13 +585,73 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
             }
         }
 
+        tk[0] += now() - t_tile;
         // ================= phase C: pulse detector =================
         int i = (p.flags & RUN_DBG_SKIP_DETECT) ? n_t : 0;
         int loaded = -1;           // block whose samples the lanes hold
         int am_l = 0, fm_l = 0;    // my sample of that block
         int a64_l = 0, f64_l = 0;  // am / 64, fm / 64 (C division) for the level and carrier averages
         int bmax = 0, bmin = 0;
+        // Lazy noise floor.  While the detector idles over samples that cannot start a pulse, every
+        // step moves `low` by exactly +-1 towards the sample (pulse_detect.c:326-329 with |am-low| < 1024),
+        // so (a) its parity after n steps is known without walking, (b) it never leaves
+        // [min(low0, samples) - 1, max(low0, samples) + 1], and (c) two walks of the same parity keep
+        // their order and close in by two whenever a sample falls between them.  The steps are therefore
+        // only counted; when the exact value is needed (a pulse may start, the tile ends) the last 128
+        // samples are walked from both extremes of the right parity and must meet -- else the whole
+        // stretch is walked.  lz_n pending steps start at lz_from; lz_min/lz_max bound their samples.
+        int lz_n = 0, lz_from = 0, lz_min = 0x7fffffff, lz_max = -0x7fffffff;
+        auto resolve_low = [&](int upto) {
+            if (lz_n == 0)
+                return;
+            int lo_est = det.low;
+            bool done = false;
+            if (lz_n > 160) {
+                int const w0 = upto - 128;
+                int const par = (det.low + (w0 - lz_from)) & 1;
+                int a = min(det.low, lz_min) - 1, b = max(det.low, lz_max) + 1;
+                a += (a ^ par) & 1; // lowest / highest candidate of that parity
+                b -= (b ^ par) & 1;
+                for (int j = w0; j < upto; j += 8) {
+                    int v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        v[u] = ld16(s_am, j + u);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        a += v[u] > a ? 1 : -1;
+                        b += v[u] > b ? 1 : -1;
+                    }
+                }
+                if (a == b) {
+                    lo_est = a;
+                    done = true;
+                }
+            }
+            if (!done) {
+                int j = lz_from;
+                for (; j + 8 <= upto; j += 8) {
+                    int v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        v[u] = ld16(s_am, j + u);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        lo_est += v[u] > lo_est ? 1 : -1;
+                }
+                for (; j < upto; ++j)
+                    lo_est += ld16(s_am, j) > lo_est ? 1 : -1;
+            }
+            det.low = lo_est;
+            det.high = max(cfg.ratio * lo_est, cfg.min_high);
+            lz_n = 0;
+            lz_min = 0x7fffffff;
+            lz_max = -0x7fffffff;
+        };
         while (i < n_t) {
+            long long const t_it = now();
+            int const st_it = det.state;
+            tk[7] += 1;
             if (dc == 0) { // a new frame == a new push_sdr_flow call
                 flen = (int)min(my_n - (t0 + (uint32_t)i), F);
                 det_call_entry(det, cfg, flen, 0);
@@ -610,53 +676,47 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                 if (det.lead_in <= 1024) { // no pulse can start during the lead-in (pulse_detect.c:310)
                     k = min(e, i + (1025 - det.lead_in));
                     det.lead_in += k - i;
-                }
-                else {
-                    // lowest threshold the idle state can present while it chases the noise floor in this block
-                    int const l_lb = min(det.low, bmin) - 1;
-                    int thr = (int)(int16_t)((l_lb + min(cfg.min_high, cfg.max_high)) / 2);
-                    if (cfg.fixed_high != 0)
-                        thr = (int)(int16_t)cfg.fixed_high;
-                    int const hys = (int)(int16_t)(thr / 8);
-                    unsigned long long const m = __ballot(in_seg && am_l > thr + hys);
-                    k = m ? base + (__ffsll(m) - 1) : e;
-                }
-                // idle arm without the (impossible) pulse start, pulse_detect.c:326-334
-                int lo_est = det.low;
-                int const n_st = k - i;
-                bool const near = max(det.low, bmax) - min(det.low, bmin) < 1000; // |am - low| < 1024 throughout
-                if (near && bmax == bmin) {
-                    // constant block (digital silence): walk to the level, then alternate a, a-1
-                    int const a = bmax;
-                    if (lo_est < a) {
-                        int const t_up = a - lo_est;
-                        lo_est = n_st <= t_up ? lo_est + n_st : a - ((n_st - t_up) & 1);
-                    }
-                    else {
-                        int const t_dn = lo_est - (a - 1);
-                        lo_est = n_st <= t_dn ? lo_est - n_st : a - 1 + ((n_st - t_dn) & 1);
-                    }
-                }
-                else if (near) {
-                    int j = i;
-                    for (; j + 8 <= k; j += 8) {
-#pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            lo_est += __builtin_amdgcn_readlane(am_l, j - base + u) > lo_est ? 1 : -1;
-                    }
-                    for (; j < k; ++j)
-                        lo_est += __builtin_amdgcn_readlane(am_l, j - base) > lo_est ? 1 : -1;
-                }
-                else {
+                    int lo_est = det.low; // idle arm, pulse_detect.c:326-334
                     for (int j = i; j < k; ++j) {
                         int const dl = __builtin_amdgcn_readlane(am_l, j - base) - lo_est;
                         lo_est += div1024(dl);
                         lo_est += dl > 0 ? 1 : -1;
                     }
-                }
-                if (k > i) {
                     det.low = lo_est;
                     det.high = max(cfg.ratio * lo_est, cfg.min_high);
+                }
+                else {
+                    // lowest threshold the idle state can present while it chases the noise floor in this block
+                    int const l_lo = min(det.low, min(lz_min, bmin)) - 1;
+                    int const l_hi = max(det.low, max(lz_max, bmax)) + 1;
+                    int thr = (int)(int16_t)((l_lo + min(cfg.min_high, cfg.max_high)) / 2);
+                    if (cfg.fixed_high != 0)
+                        thr = (int)(int16_t)cfg.fixed_high;
+                    int const hys = (int)(int16_t)(thr / 8);
+                    unsigned long long const m = __ballot(in_seg && am_l > thr + hys);
+                    k = m ? base + (__ffsll(m) - 1) : e;
+                    if (l_hi - l_lo < 1000) { // |am - low| < 1024 over everything pending: count, do not walk
+                        if (lz_n == 0)
+                            lz_from = i;
+                        lz_n += k - i;
+                        lz_min = min(lz_min, bmin);
+                        lz_max = max(lz_max, bmax);
+                    }
+                    else {
+                        resolve_low(i);
+                        int lo_est = det.low; // idle arm without the (impossible) pulse start, pulse_detect.c:326-334
+                        for (int j = i; j < k; ++j) {
+                            int const dl = __builtin_amdgcn_readlane(am_l, j - base) - lo_est;
+                            lo_est += div1024(dl);
+                            lo_est += dl > 0 ? 1 : -1;
+                        }
+                        if (k > i) {
+                            det.low = lo_est;
+                            det.high = max(cfg.ratio * lo_est, cfg.min_high);
+                        }
+                    }
+                    if (k < e)
+                        resolve_low(k); // a pulse may start at k: the general step needs the exact floor
                 }
             }
             else if (st == ST_GAP) {
@@ -735,9 +795,12 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                     frame += 1;
                     dc = 0;
                 }
+                tk[4] += now() - t_it;
                 continue;
             }
 
+            long long const t_fast = now();
+            tk[st_it == ST_IDLE ? 1 : st_it == ST_GAP ? 2 : st_it == ST_PULSE ? 3 : 4] += t_fast - t_it;
             int consumed = k - i;
             if (k < e) { // the exact general step: candidate samples, and the states that need every sample
                 int taken = 0;
@@ -774,7 +837,11 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                 frame += 1;
                 dc = 0;
             }
+            tk[5] += now() - t_fast;
         }
+        long long const t_res = now();
+        resolve_low(n_t);
+        tk[6] += now() - t_res; // the samples leave LDS with the tile
     }
 
     if (lane == 0) {
@@ -786,6 +853,10 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
         S.overflow = det.overflow;
         S.input_pos = input_pos;
         S.frame = frame;
+        if (timing) {
+            S.lpf_y = (int)(tk[0] >> 6), S.lpf_x = (int)(tk[1] >> 6), S.fm_xr = (int)(tk[2] >> 6), S.fm_xi = (int)(tk[3] >> 6);
+            S.fm_xf = (int)(tk[4] >> 6), S.fm_yf = (int)(tk[5] >> 6), S.state = (int)(tk[6] >> 6), S.run = (int)tk[7];
+        }
     }
 }
 

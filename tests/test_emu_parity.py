@@ -153,3 +153,26 @@ def test_cs16_stalls_and_ragged():
             assert np.array_equal(g["taps"][2][s, :m], o["fm"])
         pk, ev, base = _oracle_batch([a, b, c], None, cfg)
         assert g["packages"][0] == pk
+
+
+def test_noise_floor_tracking():
+    """The idle noise-floor estimate is evaluated lazily (parity + two-sided walk over the last 128
+    samples, full walk when the two sides do not meet, plain walk when |am - low| may reach 1024).
+    Bursts riding on noise floors of very different widths exercise all three, and the estimate is
+    visible in every package header (ook_low_estimate) and in every threshold decision."""
+    from tests.emu import host
+    iqs = []
+    for k, sigma in enumerate((0.0, 1.0, 3.0, 6.0, 9.0, 12.0, 16.0, 24.0)):
+        rng = np.random.default_rng(700 + k)
+        segs = [(6000 + 777 * k, False)]
+        for rep in range(3):
+            bits = rng.integers(0, 2, 24).astype(np.uint8)
+            segs += synth.ook_segments(bits, "pwm", 100, 200, repeats=1) + [(9000 + 1111 * rep, False)]
+        n = sum(x[0] for x in segs)
+        mask = synth._segments_to_mask(segs, n)
+        iqs.append(synth.modulate_cu8(mask, rng, 250000, 20e3, 110.0, sigma))
+    g = host.emu_run(iqs, 2, 250000, None, taps=False)
+    cfg = po.default_flow_cfg(2, 250000)
+    pk, ev, base = _oracle_batch(iqs, None, cfg)
+    assert base >= 8
+    assert g["packages"][0] == pk

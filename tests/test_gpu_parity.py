@@ -126,3 +126,26 @@ def test_flow_options_vs_oracle(variant, default_devices):
         base += o["n_packages"]
     assert g["packages"][0] == pk_all
     assert g["events"][0] == ev_all
+
+
+def test_noise_floor_tracking():
+    """Same captures as tests/test_emu_parity.py::test_noise_floor_tracking, on the GPU."""
+    from rtl_433_amd import synth
+    iqs = []
+    for k, sigma in enumerate((0.0, 1.0, 3.0, 6.0, 9.0, 12.0, 16.0, 24.0)):
+        rng = np.random.default_rng(700 + k)
+        segs = [(6000 + 777 * k, False)]
+        for rep in range(3):
+            bits = rng.integers(0, 2, 24).astype(np.uint8)
+            segs += synth.ook_segments(bits, "pwm", 100, 200, repeats=1) + [(9000 + 1111 * rep, False)]
+        n = sum(x[0] for x in segs)
+        mask = synth._segments_to_mask(segs, n)
+        iqs.append(synth.modulate_cu8(mask, rng, 250000, 20e3, 110.0, sigma))
+    g = _gpu_run(iqs, 2, 250000, 433920000, None)
+    cfg = po.default_flow_cfg(2, 250000)
+    pk_all, base = b"", 0
+    for s, a in enumerate(iqs):
+        o = po.oracle_flow(a, None, cfg, stream_index=s, pkg_base=base)
+        pk_all += o["packages"]
+        base += o["n_packages"]
+    assert base >= 8 and g["packages"][0] == pk_all

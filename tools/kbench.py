@@ -24,3 +24,23 @@ for r in range(a.reps):
 best = min(ts, key=lambda t: t["detect_ms"])
 print(f"flags={os.environ.get('R433_DEBUG_FLAGS','0')} streams={a.streams} samples={a.samples} pkgs={n} " +
       " ".join(f"{k}={v:.3f}" for k, v in best.items()))
+
+if int(os.environ.get("R433_DEBUG_FLAGS", "0"), 0) & 1024:
+    import ctypes as C
+    rec = 34 * 4  # sizeof(StreamState) upper bound; the real size comes back from the call
+    buf = np.zeros(a.streams * 64, dtype=np.int32)
+    sz = eng.L.r433_batch_debug_state(eng.h, C.c_void_p(buf.ctypes.data), buf.nbytes)
+    st = buf[: a.streams * sz // 4].reshape(a.streams, sz // 4)
+    names = ["A+B", "idle", "gap", "pulse", "gapstart", "general", "resolve", "iters"]
+    cols = st[:, [0, 1, 2, 3, 4, 5, 6, 7]].astype(np.int64)
+    cols[:, :7] *= 64
+    tot = cols[:, :7].sum(axis=1)
+    order = np.argsort(tot)
+    print("ticks per capture (shader clock), mean / max-capture:")
+    worst = order[-1]
+    for j, nm in enumerate(names):
+        print(f"  {nm:9s} mean={cols[:, j].mean():12.0f}  slowest-capture={cols[worst, j]:12d}")
+    print(f"  total     mean={tot.mean():12.0f}  slowest={tot[worst]} (capture {worst})  fastest={tot[order[0]]}")
+    metas = [synth.ook_stream(int(s))[1] for s in order[-5:]]
+    for s, m in zip(order[-5:], metas):
+        print("  slow capture", int(s), {k: m[k] for k in ("family", "nbits", "short", "amp", "sigma", "repeats", "used")})
