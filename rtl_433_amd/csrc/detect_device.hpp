@@ -1,7 +1,9 @@
 // detect_device.hpp -- OOK level-tracking pulse detector with the embedded FSK sub-detectors:
-// the exact, general per-sample step.  One capture per wavefront: lane 0 owns the detector state and
-// runs these functions; the kernel (stream_kernels.hip) uses the whole wavefront to skip over
-// samples that provably cannot change the state machine and comes here for everything else.
+// the exact, general per-sample step.  One capture per wavefront, executed WAVE-UNIFORMLY: every
+// lane carries the same detector state and takes the same (scalar) branches; only the lane flagged
+// `writer` touches memory (package arena, FSK candidate ring) and what it reads back from the ring
+// is broadcast.  The kernel (stream_kernels.hip) uses the whole wavefront to skip over samples that
+// provably cannot change the state machine and comes here for everything else.
 //
 // Behaviour follows the reference's pulse_detect_package() (src/pulse_detect.c:199-483),
 // pulse_detect_fsk_classic/minmax/wrap_up (src/pulse_detect_fsk.c:34-221) and pulse_data_shift
@@ -51,6 +53,7 @@ struct DetLane {
     // arena
     uint8_t *arena;
     int2 *fsk_ring;     // per-capture scratch, R433_PD_MAX_PULSES entries
+    bool writer;        // the one lane that performs the memory accesses
     uint32_t arena_cap;
     uint32_t cursor;    // bytes of finished records
     uint32_t n_pkgs;
@@ -88,6 +91,22 @@ __device__ __forceinline__ void det_reset(DetLane &d)
     d.eop_spurious = 0;
 }
 
+// ---- FSK candidate ring: element k is pulse (k even) / gap (k odd) of pair k/2 ----
+
+__device__ __forceinline__ int ring_get(DetLane const &d, uint32_t k)
+{
+    int v = 0;
+    if (d.writer)
+        v = ((int const *)d.fsk_ring)[k];
+    return __builtin_amdgcn_readfirstlane(v); // the writer is lane 0
+}
+
+__device__ __forceinline__ void ring_set(DetLane const &d, uint32_t k, int v)
+{
+    if (d.writer)
+        ((int *)d.fsk_ring)[k] = v;
+}
+
 // ---- arena helpers ----
 
 __device__ __forceinline__ bool arena_room(DetLane &d, uint32_t pairs_after)
@@ -101,7 +120,7 @@ __device__ __forceinline__ bool arena_room(DetLane &d, uint32_t pairs_after)
 
 __device__ __forceinline__ void ook_push_pair(DetLane &d, int gap)
 {
-    if (arena_room(d, d.ook_num + 1)) {
+    if (arena_room(d, d.ook_num + 1) && d.writer) {
         int2 *pairs = (int2 *)(d.arena + d.cursor + sizeof(r433_pkg_rec));
         pairs[d.ook_num] = make_int2(d.cur_pulse, gap);
     }
@@ -116,22 +135,24 @@ __device__ __forceinline__ void write_header(DetLane &d, uint32_t type, uint32_t
         return;
     uint32_t *h = (uint32_t *)(d.arena + d.cursor);
     uint32_t total = (uint32_t)sizeof(r433_pkg_rec) + 8u * num;
-    h[0] = total;
-    h[1] = d.stream;
-    h[2] = type;
-    h[3] = num;
-    h[4] = frame;
-    h[5] = ret_pos;
-    h[6] = (uint32_t)offset;
-    h[7] = (uint32_t)(offset >> 32);
-    h[8] = d.start_ago;
-    h[9] = end_ago;
-    h[10] = (uint32_t)d.low;
-    h[11] = (uint32_t)d.high;
-    h[12] = (uint32_t)f1;
-    h[13] = (uint32_t)f2;
-    h[14] = c.rate;
-    h[15] = 0;
+    if (d.writer) {
+        h[0] = total;
+        h[1] = d.stream;
+        h[2] = type;
+        h[3] = num;
+        h[4] = frame;
+        h[5] = ret_pos;
+        h[6] = (uint32_t)offset;
+        h[7] = (uint32_t)(offset >> 32);
+        h[8] = d.start_ago;
+        h[9] = end_ago;
+        h[10] = (uint32_t)d.low;
+        h[11] = (uint32_t)d.high;
+        h[12] = (uint32_t)f1;
+        h[13] = (uint32_t)f2;
+        h[14] = c.rate;
+        h[15] = 0;
+    }
     d.cursor += total;
     d.n_pkgs += 1;
 }
@@ -153,7 +174,8 @@ __device__ __forceinline__ void move_pairs(int2 *dst, int2 const *src, uint32_t 
 // src/pulse_data.c:27-34
 __device__ __forceinline__ void fsk_drop_half(DetLane &d)
 {
-    move_pairs(d.fsk_ring, d.fsk_ring + R433_PD_MAX_PULSES / 2, R433_PD_MAX_PULSES / 2);
+    if (d.writer)
+        move_pairs(d.fsk_ring, d.fsk_ring + R433_PD_MAX_PULSES / 2, R433_PD_MAX_PULSES / 2);
     d.fsk_num -= R433_PD_MAX_PULSES / 2;
     d.fsk_offset += R433_PD_MAX_PULSES / 2;
 }
@@ -161,20 +183,19 @@ __device__ __forceinline__ void fsk_drop_half(DetLane &d)
 // src/pulse_detect.c:239-253 / 387-410 with pulse_detect_fsk_wrap_up (src/pulse_detect_fsk.c:143-156)
 __device__ __forceinline__ int emit_fsk(DetLane &d, DetCfg const &c, int len, int pos, uint32_t frame, uint32_t ret_pos)
 {
-    int *ring = (int *)d.fsk_ring;
     if (c.fpdm == 0 && d.fsk_num < R433_PD_MAX_PULSES) {
         d.f_run += 1;
         if (d.f_state == 1) {
-            ring[2 * d.fsk_num] = (int)d.f_run;
-            ring[2 * d.fsk_num + 1] = 0;
+            ring_set(d, 2 * d.fsk_num, (int)d.f_run);
+            ring_set(d, 2 * d.fsk_num + 1, 0);
         }
         else {
-            ring[2 * d.fsk_num + 1] = (int)d.f_run;
+            ring_set(d, 2 * d.fsk_num + 1, (int)d.f_run);
         }
         d.fsk_num += 1;
     }
     d.state = ST_IDLE;
-    if (arena_room(d, d.fsk_num))
+    if (arena_room(d, d.fsk_num) && d.writer)
         move_pairs((int2 *)(d.arena + d.cursor + sizeof(r433_pkg_rec)), d.fsk_ring, d.fsk_num);
     write_header(d, R433_PKG_FSK, d.fsk_num, d.fsk_offset, (uint32_t)(len - pos), d.f_f1, d.f_f2, c, frame, ret_pos);
     return R433_PKG_FSK;
@@ -185,7 +206,6 @@ __device__ __forceinline__ int emit_fsk(DetLane &d, DetCfg const &c, int len, in
 // src/pulse_detect_fsk.c:34-141
 __device__ __forceinline__ void fsk_classic(DetLane &d, int v)
 {
-    int *ring = (int *)d.fsk_ring;
     int d1 = abs(v - d.f_f1);
     int d2 = abs(v - d.f_f2);
     d.f_run += 1;
@@ -198,15 +218,15 @@ __device__ __forceinline__ void fsk_classic(DetLane &d, int v)
                 d.f_state = 1;
                 d.f_f2 = d.f_f1;
                 d.f_f1 = v;
-                ring[0] = 0;
-                ring[1] = (int)d.f_run;
+                ring_set(d, 0, 0);
+                ring_set(d, 1, (int)d.f_run);
                 d.fsk_num += 1;
                 d.f_run = 0;
             }
             else {
                 d.f_state = 2;
                 d.f_f2 = v;
-                ring[0] = (int)d.f_run;
+                ring_set(d, 0, (int)d.f_run);
                 d.f_run = 0;
             }
         }
@@ -218,13 +238,13 @@ __device__ __forceinline__ void fsk_classic(DetLane &d, int v)
         if (d1 > d2) {
             d.f_state = 2;
             if (d.f_run >= 10u) {
-                ring[2 * d.fsk_num] = (int)d.f_run;
+                ring_set(d, 2 * d.fsk_num, (int)d.f_run);
                 d.f_run = 0;
             }
             else {
-                d.f_run += (uint32_t)ring[2 * (d.fsk_num - 1) + 1];
+                d.f_run += (uint32_t)ring_get(d, 2 * (d.fsk_num - 1) + 1);
                 d.fsk_num -= 1;
-                if (d.fsk_num == 0 && ring[0] == 0) {
+                if (d.fsk_num == 0 && ring_get(d, 0) == 0) {
                     d.f_f1 = d.f_f2;
                     d.f_state = 0;
                 }
@@ -241,14 +261,14 @@ __device__ __forceinline__ void fsk_classic(DetLane &d, int v)
         if (d2 > d1) {
             d.f_state = 1;
             if (d.f_run >= 10u) {
-                ring[2 * d.fsk_num + 1] = (int)d.f_run;
+                ring_set(d, 2 * d.fsk_num + 1, (int)d.f_run);
                 d.fsk_num += 1;
                 d.f_run = 0;
                 if (d.fsk_num >= R433_PD_MAX_PULSES)
                     fsk_drop_half(d);
             }
             else {
-                d.f_run += (uint32_t)ring[2 * d.fsk_num];
+                d.f_run += (uint32_t)ring_get(d, 2 * d.fsk_num);
                 if (d.fsk_num == 0)
                     d.f_state = 0;
             }
@@ -266,7 +286,6 @@ __device__ __forceinline__ void fsk_classic(DetLane &d, int v)
 __device__ __forceinline__ void fsk_minmax(DetLane &d, int v)
 {
     if (d.f_skip == 0) {
-        int *ring = (int *)d.fsk_ring;
         d.f_vmax = max(v, d.f_vmax);
         d.f_vmin = min(v, d.f_vmin);
         int mid = (int)(int16_t)((d.f_vmax + d.f_vmin) / 2);
@@ -281,7 +300,7 @@ __device__ __forceinline__ void fsk_minmax(DetLane &d, int v)
         else if (d.f_state == 1) {
             if (v < mid) {
                 d.f_state = 2;
-                ring[2 * d.fsk_num] = (int)d.f_run;
+                ring_set(d, 2 * d.fsk_num, (int)d.f_run);
                 d.f_run = 0;
             }
             d.f_f2 += v / 64 - d.f_f2 / 64; // (sic) the reference updates f2 while high
@@ -289,7 +308,7 @@ __device__ __forceinline__ void fsk_minmax(DetLane &d, int v)
         else if (d.f_state == 2) {
             if (v > mid) {
                 d.f_state = 1;
-                ring[2 * d.fsk_num + 1] = (int)d.f_run;
+                ring_set(d, 2 * d.fsk_num + 1, (int)d.f_run);
                 d.fsk_num += 1;
                 d.f_run = 0;
                 if (d.fsk_num >= R433_PD_MAX_PULSES)
@@ -339,7 +358,8 @@ __device__ __forceinline__ void det_idle(DetLane &d, DetCfg const &c, int am, in
         d.run = 0;
         d.max_pulse = 0;
         fsk_reset(d);
-        d.fsk_ring[0] = make_int2(0, 0);
+        ring_set(d, 0, 0);
+        ring_set(d, 1, 0);
         d.state = ST_PULSE;
     }
     else {

@@ -13,13 +13,13 @@
 //                        resolved from their left neighbour -- in O(1) when the chunk provably maps
 //                        every candidate carry to itself, by an exact re-run otherwise.  Nothing is
 //                        assumed: a lane only publishes samples computed from a proven carry.
-//   C  state machine     the OOK/FSK pulse detector.  Lane 0 owns the detector state.  The wavefront
-//                        ballots over 64 samples at a time to find the next sample that can possibly
-//                        change the state machine (a pulse start while idle, a falling edge inside a
-//                        pulse, a rising edge or the end-of-package count inside a gap); lane 0 runs a
-//                        lean recurrence over the samples in between (noise-floor chase, level and
-//                        carrier averages, counters) and the exact general step (detect_device.hpp)
-//                        on the candidates.
+//   C  state machine     the OOK/FSK pulse detector, wave-uniform (every lane carries the same scalar
+//                        state, so it lives in SGPRs).  The wavefront ballots over 64 samples at a time
+//                        to find the next sample that can possibly change the state machine (a pulse
+//                        start while idle, a falling edge inside a pulse, a rising edge or the
+//                        end-of-package count inside a gap), runs lean recurrences over the samples in
+//                        between (noise floor -- evaluated lazily --, level and carrier averages,
+//                        counters) and the exact general step (detect_device.hpp) on the candidates.
 //
 // Packages leave as r433_pkg_rec records in a per-capture arena.  Frame semantics of the file reader
 // (one push_sdr_flow call per 262144 input bytes) are reproduced at their exact sample positions.
@@ -47,6 +47,13 @@ constexpr int kPitch32 = kChunk * 4 + 16;
 __device__ __forceinline__ int rl0(int v)
 {
     return __builtin_amdgcn_readlane(v, 0);
+}
+
+// A value every lane holds identically, but that the compiler cannot prove uniform (it came out of
+// LDS): pin it to an SGPR so that everything computed from it stays on the scalar unit.
+__device__ __forceinline__ int uni(int v)
+{
+    return __builtin_amdgcn_readfirstlane(v);
 }
 
 __device__ __forceinline__ int wave_sum(int v)
@@ -159,9 +166,9 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
     uint8_t const *const iq = p.iq + (uint64_t)s * p.stride_bytes;
     uint32_t const F = p.frame_samples;
 
-    // ---- detector.  Every lane carries a copy of the scalar state and applies the wave-uniform fast
-    // paths to it; lane 0 additionally runs the general step (ring, arena) and its view of the fields
-    // the fast paths read is re-broadcast afterwards.
+    // ---- detector: wave-uniform.  Every lane carries the same scalar state and takes the same
+    // branches, in the fast paths and in the general step alike; lane 0 alone touches the arena and
+    // the FSK ring (detect_device.hpp).
     DetLane det;
     DetCfg const cfg = p.det;
     det_reset(det);
@@ -169,6 +176,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
     det.fsk_ring = p.fsk_ring + (uint64_t)s * R433_PD_MAX_PULSES; // HBM scratch, touched by lane 0 on FSK pulses only
     det.arena_cap = p.arena_stride;
     det.stream = s;
+    det.writer = lane == 0;
     det.cursor = 0;
     det.n_pkgs = 0;
     det.overflow = 0;
@@ -482,7 +490,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                 int const pk = __shfl_up(tk, 1, 64);
                 int const pv = __shfl_up(tv, 1, 64);
                 bool const take = !st.start_known && pk == T_CONST && lane > 0;
-                bool rerun = false;
+                bool rerun = false, bad = false;
                 int y0 = 0;
                 if (take) {
                     y0 = pv;
@@ -500,11 +508,12 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                             cmax = cmin = y0;
                     }
                     else {
-                        if (st.ident)
-                            det.overflow = 3; // a proven interval that does not hold the carry: refuse the result
+                        bad = st.ident != 0; // a proven interval that does not hold the carry
                         rerun = true;
                     }
                 }
+                if (__ballot(bad))
+                    det.overflow = 3; // refuse the result (the host reports it)
                 if (__ballot(rerun)) {
                     // exact re-run of my chunk from the proven carry
                     int x1 = 0, f1 = 0;
@@ -612,16 +621,18 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                 int a = min(det.low, lz_min) - 1, b = max(det.low, lz_max) + 1;
                 a += (a ^ par) & 1; // lowest / highest candidate of that parity
                 b -= (b ^ par) & 1;
-                for (int j = w0; j < upto; j += 8) {
-                    int v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        v[u] = ld16(s_am, j + u);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        a += v[u] > a ? 1 : -1;
-                        b += v[u] > b ? 1 : -1;
-                    }
+                int const v0 = ld16(s_am, w0 + lane), v1 = ld16(s_am, w0 + 64 + lane); // w0 + 127 < upto <= n_t
+#pragma unroll 8
+                for (int u = 0; u < 64; ++u) {
+                    int const x = __builtin_amdgcn_readlane(v0, u);
+                    a += x > a ? 1 : -1;
+                    b += x > b ? 1 : -1;
+                }
+#pragma unroll 8
+                for (int u = 0; u < 64; ++u) {
+                    int const x = __builtin_amdgcn_readlane(v1, u);
+                    a += x > a ? 1 : -1;
+                    b += x > b ? 1 : -1;
                 }
                 if (a == b) {
                     lo_est = a;
@@ -629,18 +640,12 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                 }
             }
             if (!done) {
-                int j = lz_from;
-                for (; j + 8 <= upto; j += 8) {
-                    int v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        v[u] = ld16(s_am, j + u);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        lo_est += v[u] > lo_est ? 1 : -1;
+                for (int j0 = lz_from; j0 < upto; j0 += 64) {
+                    int const v = j0 + lane < upto ? ld16(s_am, j0 + lane) : 0;
+                    int const cntj = min(64, upto - j0);
+                    for (int u = 0; u < cntj; ++u)
+                        lo_est += __builtin_amdgcn_readlane(v, u) > lo_est ? 1 : -1;
                 }
-                for (; j < upto; ++j)
-                    lo_est += ld16(s_am, j) > lo_est ? 1 : -1;
             }
             det.low = lo_est;
             det.high = max(cfg.ratio * lo_est, cfg.min_high);
@@ -656,6 +661,22 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                 flen = (int)min(my_n - (t0 + (uint32_t)i), F);
                 det_call_entry(det, cfg, flen, 0);
             }
+            // Every lane holds the same values here, but they have been through per-lane-looking code
+            // (LDS, the general step); pin what the fast paths loop on to SGPRs so that those loops run
+            // on the scalar unit with scalar branches.
+            i = uni(i);
+            dc = uni(dc);
+            flen = uni(flen);
+            det.state = uni(det.state);
+            det.lead_in = uni(det.lead_in);
+            det.low = uni(det.low);
+            det.high = uni(det.high);
+            det.run = uni(det.run);
+            det.max_pulse = uni(det.max_pulse);
+            det.ook_num = (uint32_t)uni((int)det.ook_num);
+            det.eop_spurious = uni(det.eop_spurious);
+            det.cur_pulse = uni(det.cur_pulse);
+            det.ook_f1 = uni(det.ook_f1);
             int const base = i & ~63;
             int const e = min(min(n_t, base + 64), i + (flen - dc));
             if (loaded != base) {
@@ -664,8 +685,8 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                 fm_l = il < n_t ? ld16(s_fm, il) : 0;
                 a64_l = div64(am_l);
                 f64_l = div64(fm_l);
-                bmax = max(s_cmax[base >> 5], s_cmax[(base >> 5) + 1]);
-                bmin = min(s_cmin[base >> 5], s_cmin[(base >> 5) + 1]);
+                bmax = uni(max(s_cmax[base >> 5], s_cmax[(base >> 5) + 1]));
+                bmin = uni(min(s_cmin[base >> 5], s_cmin[(base >> 5) + 1]));
                 loaded = base;
             }
             bool const in_seg = base + lane >= i && base + lane < e;
@@ -803,32 +824,19 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
             tk[st_it == ST_IDLE ? 1 : st_it == ST_GAP ? 2 : st_it == ST_PULSE ? 3 : 4] += t_fast - t_it;
             int consumed = k - i;
             if (k < e) { // the exact general step: candidate samples, and the states that need every sample
-                int taken = 0;
-                if (lane == 0) {
-                    int j = k;
-                    int local_dc = dc + (k - i);
-                    do {
-                        int const am = ld16(s_am, j), fm = ld16(s_fm, j);
-                        int const r = det_step(det, cfg, am, fm, flen, local_dc, input_pos, frame);
-                        if (r) { // package returned: the next call starts at the same sample, in the idle state
-                            det_call_entry(det, cfg, flen, local_dc);
-                            det_idle(det, cfg, am, flen, local_dc, input_pos);
-                        }
-                        ++j;
-                        ++local_dc;
-                    } while (j < e && (det.state == ST_GAP_START || (det.state == ST_PULSE && det.ook_num == 0)));
-                    taken = j - k;
-                }
-                consumed += rl0(taken);
-                det.state = rl0(det.state);
-                det.run = rl0(det.run);
-                det.max_pulse = rl0(det.max_pulse);
-                det.lead_in = rl0(det.lead_in);
-                det.low = rl0(det.low);
-                det.high = rl0(det.high);
-                det.ook_num = (uint32_t)rl0((int)det.ook_num);
-                det.eop_spurious = rl0(det.eop_spurious);
-                det.cur_pulse = rl0(det.cur_pulse);
+                int j = k;
+                int local_dc = dc + (k - i);
+                do {
+                    int const am = __builtin_amdgcn_readlane(am_l, j - base), fm = __builtin_amdgcn_readlane(fm_l, j - base);
+                    int const r = det_step(det, cfg, am, fm, flen, local_dc, input_pos, frame);
+                    if (r) { // package returned: the next call starts at the same sample, in the idle state
+                        det_call_entry(det, cfg, flen, local_dc);
+                        det_idle(det, cfg, am, flen, local_dc, input_pos);
+                    }
+                    ++j;
+                    ++local_dc;
+                } while (j < e && (det.state == ST_GAP_START || (det.state == ST_PULSE && det.ook_num == 0)));
+                consumed += j - k;
             }
             i += consumed;
             dc += consumed;
@@ -844,9 +852,9 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
         tk[6] += now() - t_res; // the samples leave LDS with the tile
     }
 
+    if (!(p.flags & RUN_NOFLUSH))
+        det_flush(det, cfg, frame);
     if (lane == 0) {
-        if (!(p.flags & RUN_NOFLUSH))
-            det_flush(det, cfg, frame);
         StreamState &S = p.state[s];
         S.cursor = det.cursor;
         S.n_pkgs = det.n_pkgs;
