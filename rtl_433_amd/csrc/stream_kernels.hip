@@ -139,6 +139,20 @@ template <int SS> struct Geom {
     static constexpr int loads = SS == 2 ? kRows : 2 * kRows; // uint4 per lane per tile
 };
 
+// two int16 lanes in one register (v_pk_*_i16)
+typedef short v2s __attribute__((vector_size(4)));
+__device__ __forceinline__ v2s as_v2s(int w)
+{
+    v2s r;
+    __builtin_memcpy(&r, &w, 4);
+    return r;
+}
+__device__ __forceinline__ v2s pk_max(v2s a, v2s b)
+{
+    v2s const m = a > b; // -1 where a is larger
+    return (a & m) | (b & ~m);
+}
+
 // C division by 64 / 1024 (truncating toward zero) without a divider
 __device__ __forceinline__ int div64(int v)
 {
@@ -600,6 +614,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
         int loaded = -1;           // block whose samples the lanes hold
         int am_l = 0, fm_l = 0;    // my sample of that block
         int a64_l = 0, f64_l = 0;  // am / 64, fm / 64 (C division) for the level and carrier averages
+        int in_pk_l = 0;           // the two of them packed as 16-bit halves
         int bmax = 0, bmin = 0;
         // Lazy noise floor.  While the detector idles over samples that cannot start a pulse, every
         // step moves `low` by exactly +-1 towards the sample (pulse_detect.c:326-329 with |am-low| < 1024),
@@ -685,6 +700,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                 fm_l = il < n_t ? ld16(s_fm, il) : 0;
                 a64_l = div64(am_l);
                 f64_l = div64(fm_l);
+                in_pk_l = (a64_l & 0xffff) | (f64_l << 16);
                 bmax = uni(max(s_cmax[base >> 5], s_cmax[(base >> 5) + 1]));
                 bmin = uni(min(s_cmin[base >> 5], s_cmin[(base >> 5) + 1]));
                 loaded = base;
@@ -765,19 +781,37 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                 unsigned long long const m = __ballot(in_seg && am_l < thr - hys);
                 k = m ? base + (__ffsll(m) - 1) : e;
                 int h = det.high, f1 = det.ook_f1;
-                int j = i; // pulse arm without the falling edge, pulse_detect.c:359-366
-                for (; j + 4 <= k; j += 4) {
+                // pulse arm without the falling edge, pulse_detect.c:359-366: the level and carrier
+                // averages v += in/64 - v/64 (C division).  Both live in 16 bits (an average never leaves
+                // the hull of its start value and its inputs), so one packed instruction stream advances
+                // the two of them together.
+                if (h >= 0 && h <= 32767 && cfg.min_high >= 0 && cfg.min_high <= 32767) {
+                    v2s hv = {(short)h, (short)f1};
+                    v2s const floor_v = {(short)cfg.min_high, (short)-32768};
+                    v2s const m63 = {63, 63};
+                    int j = i;
+                    for (; j + 8 <= k; j += 8) { // taken branches are the expensive instruction here
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        h += __builtin_amdgcn_readlane(a64_l, j - base + u) - div64(h);
-                        h = max(h, cfg.min_high);
-                        f1 += __builtin_amdgcn_readlane(f64_l, j - base + u) - div64(f1);
+                        for (int u = 0; u < 8; ++u) {
+                            v2s const in = as_v2s(__builtin_amdgcn_readlane(in_pk_l, j - base + u));
+                            v2s const q = (hv + ((hv >> 15) & m63)) >> 6; // hv / 64, truncating toward zero
+                            hv = pk_max(hv - q + in, floor_v);
+                        }
                     }
+                    for (; j < k; ++j) {
+                        v2s const in = as_v2s(__builtin_amdgcn_readlane(in_pk_l, j - base));
+                        v2s const q = (hv + ((hv >> 15) & m63)) >> 6;
+                        hv = pk_max(hv - q + in, floor_v);
+                    }
+                    h = hv[0];
+                    f1 = hv[1];
                 }
-                for (; j < k; ++j) {
-                    h += __builtin_amdgcn_readlane(a64_l, j - base) - div64(h);
-                    h = max(h, cfg.min_high);
-                    f1 += __builtin_amdgcn_readlane(f64_l, j - base) - div64(f1);
+                else {
+                    for (int j = i; j < k; ++j) {
+                        h += __builtin_amdgcn_readlane(a64_l, j - base) - div64(h);
+                        h = max(h, cfg.min_high);
+                        f1 += __builtin_amdgcn_readlane(f64_l, j - base) - div64(f1);
+                    }
                 }
                 det.high = h;
                 det.ook_f1 = f1;
