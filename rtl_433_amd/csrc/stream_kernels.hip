@@ -774,44 +774,62 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                 // the level estimate cannot climb above max(high, block max); below the threshold that
                 // belongs to it no sample can be a falling edge
                 int const h_ub = max(det.high, bmax) + 1;
-                int thr = (int)(int16_t)((det.low + min(h_ub, cfg.max_high)) / 2);
+                int thr_ub = (int)(int16_t)((det.low + min(h_ub, cfg.max_high)) / 2);
                 if (cfg.fixed_high != 0)
-                    thr = (int)(int16_t)cfg.fixed_high;
-                int const hys = (int)(int16_t)(thr / 8);
-                unsigned long long const m = __ballot(in_seg && am_l < thr - hys);
-                k = m ? base + (__ffsll(m) - 1) : e;
+                    thr_ub = (int)(int16_t)cfg.fixed_high;
+                int const hys_ub = (int)(int16_t)(thr_ub / 8);
+                unsigned long long cand = __ballot(in_seg && am_l < thr_ub - hys_ub);
                 int h = det.high, f1 = det.ook_f1;
-                // pulse arm without the falling edge, pulse_detect.c:359-366: the level and carrier
-                // averages v += in/64 - v/64 (C division).  Both live in 16 bits (an average never leaves
-                // the hull of its start value and its inputs), so one packed instruction stream advances
-                // the two of them together.
-                if (h >= 0 && h <= 32767 && cfg.min_high >= 0 && cfg.min_high <= 32767) {
-                    v2s hv = {(short)h, (short)f1};
-                    v2s const floor_v = {(short)cfg.min_high, (short)-32768};
-                    v2s const m63 = {63, 63};
-                    int j = i;
-                    for (; j + 8 <= k; j += 8) { // taken branches are the expensive instruction here
+                bool const packed = h >= 0 && h <= 32767 && cfg.min_high >= 0 && cfg.min_high <= 32767;
+                int j = i;
+                for (;;) {
+                    k = cand ? base + (__ffsll(cand) - 1) : e;
+                    // pulse arm without the falling edge, pulse_detect.c:359-366: the level and carrier
+                    // averages v += in/64 - v/64 (C division).  Both live in 16 bits (an average never
+                    // leaves the hull of its start value and its inputs), so one packed instruction
+                    // stream advances the two of them together.
+                    if (packed) {
+                        v2s hv = {(short)h, (short)f1};
+                        v2s const floor_v = {(short)cfg.min_high, (short)-32768};
+                        v2s const m63 = {63, 63};
+                        for (; j + 8 <= k; j += 8) { // taken branches are the expensive instruction here
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            v2s const in = as_v2s(__builtin_amdgcn_readlane(in_pk_l, j - base + u));
-                            v2s const q = (hv + ((hv >> 15) & m63)) >> 6; // hv / 64, truncating toward zero
+                            for (int u = 0; u < 8; ++u) {
+                                v2s const in = as_v2s(__builtin_amdgcn_readlane(in_pk_l, j - base + u));
+                                v2s const q = (hv + ((hv >> 15) & m63)) >> 6; // hv / 64, truncating toward zero
+                                hv = pk_max(hv - q + in, floor_v);
+                            }
+                        }
+                        for (; j < k; ++j) {
+                            v2s const in = as_v2s(__builtin_amdgcn_readlane(in_pk_l, j - base));
+                            v2s const q = (hv + ((hv >> 15) & m63)) >> 6;
                             hv = pk_max(hv - q + in, floor_v);
                         }
+                        h = hv[0];
+                        f1 = hv[1];
                     }
-                    for (; j < k; ++j) {
-                        v2s const in = as_v2s(__builtin_amdgcn_readlane(in_pk_l, j - base));
-                        v2s const q = (hv + ((hv >> 15) & m63)) >> 6;
-                        hv = pk_max(hv - q + in, floor_v);
+                    else {
+                        for (; j < k; ++j) {
+                            h += __builtin_amdgcn_readlane(a64_l, j - base) - div64(h);
+                            h = max(h, cfg.min_high);
+                            f1 += __builtin_amdgcn_readlane(f64_l, j - base) - div64(f1);
+                        }
                     }
-                    h = hv[0];
-                    f1 = hv[1];
-                }
-                else {
-                    for (int j = i; j < k; ++j) {
-                        h += __builtin_amdgcn_readlane(a64_l, j - base) - div64(h);
-                        h = max(h, cfg.min_high);
-                        f1 += __builtin_amdgcn_readlane(f64_l, j - base) - div64(f1);
-                    }
+                    if (k >= e)
+                        break;
+                    // candidate: decide with the exact level.  Not an edge -> it is one more pulse sample.
+                    int thr = (int)(int16_t)((det.low + min(h, cfg.max_high)) / 2);
+                    if (cfg.fixed_high != 0)
+                        thr = (int)(int16_t)cfg.fixed_high;
+                    int const hys = (int)(int16_t)(thr / 8);
+                    int const am_k = __builtin_amdgcn_readlane(am_l, k - base);
+                    if (am_k < thr - hys)
+                        break; // falling edge: the general step takes it from here
+                    h += __builtin_amdgcn_readlane(a64_l, k - base) - div64(h);
+                    h = max(h, cfg.min_high);
+                    f1 += __builtin_amdgcn_readlane(f64_l, k - base) - div64(f1);
+                    j = k + 1;
+                    cand &= cand - 1; // next candidate
                 }
                 det.high = h;
                 det.ook_f1 = f1;
@@ -869,7 +887,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                     }
                     ++j;
                     ++local_dc;
-                } while (j < e && (det.state == ST_GAP_START || (det.state == ST_PULSE && det.ook_num == 0)));
+                } while (j < e && det.ook_num == 0 && (det.state == ST_GAP_START || det.state == ST_PULSE));
                 consumed += j - k;
             }
             i += consumed;
