@@ -112,11 +112,11 @@ def bind(L):
     return L
 
 
-def last_error():
-    return lib().r433_last_error().decode(errors="replace")
+def last_error(L=None):
+    return (L or lib()).r433_last_error().decode(errors="replace")
 
 
-def check(rc, what):
+def check(rc, what, L=None):
     if rc < 0:
-        raise RuntimeError(f"{what} failed ({rc}): {last_error()}")
+        raise RuntimeError(f"{what} failed ({rc}): {last_error(L)}")
     return rc

@@ -48,15 +48,15 @@ class BatchEngine:
         # `library` is for the test suite's emulator build of the same sources; the product always
         # goes through _lib.lib(), which raises if librtl433hip.so is missing.
         self.L = library if library is not None else _lib.lib()
-        _lib.check(self.L.r433_device_count(), "r433_device_count")
+        _lib.check(self.L.r433_device_count(), "r433_device_count", self.L)
         self.cfg = cfg
         self.devs = np.zeros(0, dtype=DEV_DTYPE) if devs is None else np.ascontiguousarray(devs, dtype=DEV_DTYPE)
         ptr = self.devs.ctypes.data_as(C.c_void_p) if len(self.devs) else None
         self.h = self.L.r433_batch_create(C.byref(cfg), ptr, len(self.devs))
         if not self.h:
-            raise RuntimeError("r433_batch_create failed: " + _lib.last_error())
+            raise RuntimeError("r433_batch_create failed: " + _lib.last_error(self.L))
         if profiling:
-            _lib.check(self.L.r433_batch_set_profiling(self.h, 1), "r433_batch_set_profiling")
+            _lib.check(self.L.r433_batch_set_profiling(self.h, 1), "r433_batch_set_profiling", self.L)
         self._taps = None
 
     def close(self):
@@ -78,7 +78,7 @@ class BatchEngine:
             assert len(sb_arr) == n_streams
             sb = sb_arr.ctypes.data_as(C.c_void_p)
         rc = self.L.r433_batch_run(self.h, C.c_void_p(ptr), stride, sb, n_streams, C.c_void_p(stream))
-        return _lib.check(rc, "r433_batch_run")
+        return _lib.check(rc, "r433_batch_run", self.L)
 
     def run(self, iq, stream_bytes=None, stream=None):
         """iq: CUDA tensor [n_streams, stride] of uint8 (cu8) or int16 (cs16), contiguous."""
@@ -93,7 +93,7 @@ class BatchEngine:
             sb = sb_arr.ctypes.data_as(C.c_void_p)
         st = torch.cuda.current_stream().cuda_stream if stream is None else stream
         rc = self.L.r433_batch_run(self.h, C.c_void_p(iq.data_ptr()), stride, sb, n_streams, C.c_void_p(st))
-        return _lib.check(rc, "r433_batch_run")
+        return _lib.check(rc, "r433_batch_run", self.L)
 
     def enable_taps(self, n_streams, n_samples):
         import torch
@@ -111,7 +111,7 @@ class BatchEngine:
 
     def _blob(self, fn):
         p, n, c = C.c_void_p(), C.c_size_t(), C.c_uint32()
-        _lib.check(fn(self.h, C.byref(p), C.byref(n), C.byref(c)), fn.__name__)
+        _lib.check(fn(self.h, C.byref(p), C.byref(n), C.byref(c)), fn.__name__, self.L)
         return (C.string_at(p, n.value) if n.value else b""), c.value
 
     def packages(self):
@@ -122,20 +122,20 @@ class BatchEngine:
 
     def frame_sums(self, n_streams):
         p, cap = C.c_void_p(), C.c_uint32()
-        _lib.check(self.L.r433_batch_frame_sums(self.h, C.byref(p), C.byref(cap)), "r433_batch_frame_sums")
+        _lib.check(self.L.r433_batch_frame_sums(self.h, C.byref(p), C.byref(cap)), "r433_batch_frame_sums", self.L)
         a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n_streams * cap.value,))
         return a.reshape(n_streams, cap.value).copy()
 
     def timing(self):
         t = _lib.BatchTiming()
-        _lib.check(self.L.r433_batch_get_timing(self.h, C.byref(t)), "r433_batch_get_timing")
+        _lib.check(self.L.r433_batch_get_timing(self.h, C.byref(t)), "r433_batch_get_timing", self.L)
         return {n: getattr(t, n) for n, _ in t._fields_}
 
     def dispatch(self, rdevices, pkg_cb=None, user=None, n_threads=1):
         """rdevices: ctypes array of POINTER(RDevice) in registration order."""
         cb = C.cast(pkg_cb, C.c_void_p) if pkg_cb is not None else None
         rc = self.L.r433_batch_dispatch_mt(self.h, C.cast(rdevices, C.c_void_p), len(rdevices), cb, user, n_threads)
-        return _lib.check(rc, "r433_batch_dispatch_mt")
+        return _lib.check(rc, "r433_batch_dispatch_mt", self.L)
 
 
 def make_rdevices(devs, decode_fn_addr=None, ctx_addr=None, names=None, protocols=None):

@@ -1,0 +1,163 @@
+"""Decoder dispatch (r433_batch_dispatch / _mt) against the reference's rules (src/r_api.c:438-550,
+src/pulse_slicer.c:26-66): packages in detection order, priority levels ascending and only while no
+earlier level produced an event, devices in registration order inside a level, bitbuffers in pulse
+order, reference-layout bitbuffer_t contents, statistics, invalid return codes are fatal.  Runs on the
+emulator build of the library (the dispatch code is plain host C++, identical in the product)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from rtl_433_amd import _lib, synth
+from rtl_433_amd.engine import BatchEngine, flow_cfg, make_rdevices
+from tests.emu import build_emu
+
+pytestmark = pytest.mark.skipif(not build_emu.available(), reason="wave emulator needs x86-64")
+
+
+class BitBuffer(C.Structure):  # bitbuffer_t, reference include/bitbuffer.h:34-40
+    _fields_ = [("num_rows", C.c_uint16), ("free_row", C.c_uint16), ("bits_per_row", C.c_uint16 * 50),
+                ("syncs_before_row", C.c_uint16 * 50), ("bb", (C.c_uint8 * 128) * 50)]
+
+
+def _setup(devs, iqs, **cfg_kw):
+    from tests.emu import host
+    lib = host.emu_lib()
+    n = len(iqs)
+    lens = np.array([a.nbytes for a in iqs], dtype=np.uint32)
+    stride = int((lens.max() + 15) // 16 * 16)
+    buf = np.zeros(n * stride + 64, dtype=np.uint8)
+    off = (-buf.ctypes.data) % 16
+    arena = buf[off:off + n * stride].reshape(n, stride)
+    for i, a in enumerate(iqs):
+        arena[i, :a.nbytes] = a
+    eng = BatchEngine(flow_cfg(2, 250000, **cfg_kw), devs, library=lib)
+    eng.run_ptr(arena.ctypes.data, stride, n, lens)
+    return eng, arena
+
+
+def _devices():
+    devs = np.zeros(6, dtype=po.DEV_DTYPE)
+    #          mod  short  long  reset  gap   sync  tol  prio
+    devs[0] = (6, 400.0, 800.0, 6000.0, 2000.0, 0.0, 150.0, 0)    # OOK_PWM
+    devs[1] = (5, 400.0, 800.0, 6000.0, 0.0, 0.0, 150.0, 10)      # OOK_PPM, low priority (runs late)
+    devs[2] = (3, 400.0, 0.0, 6000.0, 0.0, 0.0, 0.0, 0)           # OOK_MC_ZEROBIT
+    devs[3] = (4, 400.0, 400.0, 6000.0, 0.0, 0.0, 0.0, 5)         # OOK_PCM, middle priority
+    devs[4] = (6, 200.0, 400.0, 3000.0, 1000.0, 0.0, 80.0, 0)     # OOK_PWM, other timing
+    devs[5] = (16, 100.0, 100.0, 3000.0, 0.0, 0.0, 0.0, 0)        # FSK_PCM: never sees OOK packages
+    return devs
+
+
+def _expected_order(ev_blob, n_pkgs, prios, hit_dev):
+    """Reference order of decode_fn calls given that device hit_dev returns 1 and everything else -1."""
+    evs = po.parse_events(ev_blob)
+    calls = []
+    for pkg in range(n_pkgs):
+        mine = [e for e in evs if e["pkg"] == pkg]
+        got = False
+        for level in sorted(set(prios)):
+            if got:
+                break
+            for dev in range(len(prios)):
+                if prios[dev] != level:
+                    continue
+                for e in (x for x in mine if x["dev"] == dev):
+                    calls.append((pkg, dev, e["ordinal"]))
+                    got = got or dev == hit_dev
+    return calls
+
+
+@pytest.mark.parametrize("threads", [1, 3])
+@pytest.mark.parametrize("hit_dev", [0, 3, None])
+def test_dispatch_order_priority_and_contents(threads, hit_dev):
+    devs = _devices()
+    iqs = [synth.ook_stream(900 + k, 30000)[0] for k in range(5)]
+    eng, keep = _setup(devs, iqs)
+    ev_blob, _ = eng.events()
+    pk_blob, n_pkgs = eng.packages()
+    by_key = {(e["pkg"], e["dev"], e["ordinal"]): e for e in po.parse_events(ev_blob)}
+    calls, bad = [], []
+    L = eng.L
+
+    @_lib.DECODE_FN
+    def decode(rdev, bits_p):
+        info = _lib.DispatchInfo()  # per call: callbacks of several dispatch threads interleave
+        L.r433_dispatch_current(C.byref(info))
+        key = (info.package, info.device, info.ordinal)
+        calls.append(key)
+        bb = C.cast(bits_p, C.POINTER(BitBuffer)).contents
+        e = by_key[key]
+        if bb.num_rows != e["num_rows"] or bb.free_row != e["free_row"]:
+            bad.append(("rows", key))
+        for r, (bits, syncs, data) in enumerate(e["rows"][:50]):
+            if bb.bits_per_row[r] != bits or bb.syncs_before_row[r] != syncs:
+                bad.append(("hdr", key, r))
+            flat = bytes(C.cast(bb.bb[r], C.POINTER(C.c_uint8 * len(data))).contents) if data else b""
+            if flat != data:
+                bad.append(("data", key, r))
+        return 1 if info.device == hit_dev else -1
+
+    rdevs, objs = make_rdevices(devs, C.cast(decode, C.c_void_p).value, None)
+    n_ok = eng.dispatch(rdevs, n_threads=threads)
+    assert not bad, bad[:5]
+    prios = [int(d["priority"]) for d in devs]
+    want = _expected_order(ev_blob, n_pkgs, prios, hit_dev)
+    if threads == 1:
+        assert calls == want
+    else:  # packages are spread over threads: order holds inside each package
+        assert sorted(calls) == sorted(want)
+        for pkg in range(n_pkgs):
+            assert [c for c in calls if c[0] == pkg] == [c for c in want if c[0] == pkg]
+    hits = sum(1 for c in want if c[1] == hit_dev)
+    assert n_ok == hits
+    for d, o in enumerate(objs):  # statistics as account_event keeps them
+        mine = [c for c in want if c[1] == d]
+        assert o.decode_events == len(mine)
+        assert o.decode_ok == (len(mine) if d == hit_dev else 0)
+        assert o.decode_fails[1] == (0 if d == hit_dev else len(mine))  # DECODE_ABORT_LENGTH == -1
+    eng.close()
+
+
+def test_invalid_decoder_return_is_fatal():
+    devs = _devices()[:1]
+    eng, keep = _setup(devs, [synth.ook_stream(901, 30000)[0]])
+
+    @_lib.DECODE_FN
+    def decode(rdev, bits_p):
+        return -7  # below DECODE_FAIL_SANITY: the reference exits (src/pulse_slicer.c:44-47)
+
+    rdevs, objs = make_rdevices(devs, C.cast(decode, C.c_void_p).value, None)
+    with pytest.raises(RuntimeError, match="invalid return value"):
+        eng.dispatch(rdevs)
+    eng.close()
+
+
+def test_package_callback_levels():
+    """pkg_cb receives a reference-layout pulse_data_t with calc_rssi_snr applied (src/r_flow.c:35-64)."""
+    devs = _devices()[:1]
+    iq = np.fromfile("tests/golden/nice_250k.cu8", dtype=np.uint8)
+    # `rtl_433 -R 169` registers no FSK decoder, so FM demodulation is off and the detector reads the raw
+    # envelope where it expects FM samples (include/r_private.h:32-36): the CLI's freq 433.955 comes from that
+    eng, keep = _setup(devs, [iq], enable_fm=0)
+    seen = []
+
+    class PulseData(C.Structure):  # pulse_data_t, include/pulse_data.h:30-50
+        _fields_ = [("offset", C.c_uint64), ("sample_rate", C.c_uint32), ("depth_bits", C.c_uint), ("start_ago", C.c_uint),
+                    ("end_ago", C.c_uint), ("num_pulses", C.c_uint), ("pulse", C.c_int * 1200), ("gap", C.c_int * 1200),
+                    ("ook_low_estimate", C.c_int), ("ook_high_estimate", C.c_int), ("fsk_f1_est", C.c_int),
+                    ("fsk_f2_est", C.c_int), ("freq1_hz", C.c_float), ("freq2_hz", C.c_float), ("centerfreq_hz", C.c_float),
+                    ("range_db", C.c_float), ("rssi_db", C.c_float), ("snr_db", C.c_float), ("noise_db", C.c_float)]
+    assert C.sizeof(PulseData) == 9672
+
+    @_lib.PACKAGE_FN
+    def on_pkg(user, stream, typ, pd_p):
+        pd = C.cast(pd_p, C.POINTER(PulseData)).contents
+        seen.append((stream, typ, pd.num_pulses, pd.pulse[0], pd.gap[0], round(pd.rssi_db, 3), round(pd.snr_db, 3), round(pd.noise_db, 3),
+                     round(pd.freq1_hz / 1e6, 3)))
+
+    rdevs, objs = make_rdevices(devs, None, None)
+    eng.dispatch(rdevs, pkg_cb=on_pkg)
+    # the reference CLI on this capture: rssi -2.312 snr 39.833 noise -42.144 freq 433.955 (tests/golden/kat.json)
+    assert seen == [(0, 1, 53, 131, 123, -2.312, 39.833, -42.144, 433.955)]
+    eng.close()
