@@ -770,7 +770,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                 k = min(ka, ke);
                 det.run += k - i;
             }
-            else if (st == ST_PULSE && det.ook_num > 0) {
+            else if (st == ST_PULSE) {
                 // the level estimate cannot climb above max(high, block max); below the threshold that
                 // belongs to it no sample can be a falling edge
                 int const h_ub = max(det.high, bmax) + 1;
@@ -780,7 +780,8 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                 int const hys_ub = (int)(int16_t)(thr_ub / 8);
                 unsigned long long cand = __ballot(in_seg && am_l < thr_ub - hys_ub);
                 int h = det.high, f1 = det.ook_f1;
-                bool const packed = h >= 0 && h <= 32767 && cfg.min_high >= 0 && cfg.min_high <= 32767;
+                bool const feed = det.ook_num == 0; // first pulse of a package: the FSK sub-detector listens (pulse_detect.c:368-375)
+                bool const packed = !feed && h >= 0 && h <= 32767 && cfg.min_high >= 0 && cfg.min_high <= 32767;
                 int j = i;
                 for (;;) {
                     k = cand ? base + (__ffsll(cand) - 1) : e;
@@ -813,6 +814,8 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                             h += __builtin_amdgcn_readlane(a64_l, j - base) - div64(h);
                             h = max(h, cfg.min_high);
                             f1 += __builtin_amdgcn_readlane(f64_l, j - base) - div64(f1);
+                            if (feed)
+                                fsk_feed(det, cfg, __builtin_amdgcn_readlane(fm_l, j - base));
                         }
                     }
                     if (k >= e)
@@ -828,6 +831,8 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                     h += __builtin_amdgcn_readlane(a64_l, k - base) - div64(h);
                     h = max(h, cfg.min_high);
                     f1 += __builtin_amdgcn_readlane(f64_l, k - base) - div64(f1);
+                    if (feed)
+                        fsk_feed(det, cfg, __builtin_amdgcn_readlane(fm_l, k - base));
                     j = k + 1;
                     cand &= cand - 1; // next candidate
                 }

@@ -12,11 +12,18 @@ ap.add_argument("--streams", type=int, default=1024)
 ap.add_argument("--samples", type=int, default=65536)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--nodevs", action="store_true")
+ap.add_argument("--cs16", action="store_true", help="config 3 style: 1024 kS/s cs16 FSK Manchester bursts, minmax detector")
 a = ap.parse_args()
-host = synth.ook_batch(a.streams, a.samples, 250000, seed0=0)
+if a.cs16:
+    host = np.stack([synth.fsk_stream_cs16(s, a.samples) for s in range(min(a.streams, 64))])
+    host = np.tile(host, ((a.streams + len(host) - 1) // len(host), 1))[: a.streams]
+    cfg = flow_cfg(4, 1024000, fpdm=1, center_frequency=868000000)
+else:
+    host = synth.ook_batch(a.streams, a.samples, 250000, seed0=0)
+    cfg = flow_cfg(2, 250000)
 d = torch.from_numpy(host).cuda()
 devs = None if a.nodevs else load_device_table()[0]
-eng = BatchEngine(flow_cfg(2, 250000), devs, profiling=True)
+eng = BatchEngine(cfg, devs, profiling=True)
 ts = []
 for r in range(a.reps):
     n = eng.run(d)
