@@ -394,13 +394,28 @@ r433_batch *r433_batch_create(r433_flow_cfg const *cfg, r433_dev_timing const *d
             return x.is_fsk < y.is_fsk;
         return x.modulation < y.modulation;
     });
+    { // pad every (fsk, modulation) group to a multiple of 64 rows: one slicer per wavefront
+        std::vector<DevRow> padded;
+        DevRow pad;
+        memset(&pad, 0, sizeof(pad));
+        pad.orig = -1;
+        for (size_t i = 0; i < b->rows.size(); ++i) {
+            if (i > 0 && (b->rows[i].is_fsk != b->rows[i - 1].is_fsk || b->rows[i].modulation != b->rows[i - 1].modulation))
+                while (padded.size() % 64)
+                    padded.push_back(pad);
+            padded.push_back(b->rows[i]);
+        }
+        while (padded.size() % 64)
+            padded.push_back(pad);
+        b->rows.swap(padded);
+    }
     for (uint32_t i = 0; i < n_devs; ++i)
         b->prio_levels.push_back(devs[i].priority);
     std::sort(b->prio_levels.begin(), b->prio_levels.end());
     b->prio_levels.erase(std::unique(b->prio_levels.begin(), b->prio_levels.end()), b->prio_levels.end());
     if (n_devs) {
-        if (b->d_rows.ensure(n_devs) != 0
-                || hipMemcpy(b->d_rows.p, b->rows.data(), n_devs * sizeof(DevRow), hipMemcpyHostToDevice) != hipSuccess) {
+        if (b->d_rows.ensure(b->rows.size()) != 0
+                || hipMemcpy(b->d_rows.p, b->rows.data(), b->rows.size() * sizeof(DevRow), hipMemcpyHostToDevice) != hipSuccess) {
             if (g_err.empty())
                 fail(R433_EHIP, "device table upload failed");
             r433_batch_destroy(b);
@@ -585,7 +600,7 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
     b->n_pkgs = total_pkgs;
     b->n_events = 0;
     b->pkg_bytes = b->evt_bytes = 0;
-    uint32_t const n_devs = (uint32_t)b->rows.size();
+    uint32_t const n_devs = (uint32_t)b->timing.size();
     uint32_t const max_pkgs = std::max<uint32_t>(total_pkgs, 1);
 
     if ((rc = b->d_dir_stream.ensure(max_pkgs)) || (rc = b->d_dir_off.ensure(max_pkgs))
@@ -609,6 +624,7 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
     lp.dir_off = b->d_dir_off.p;
     lp.n_pkgs = b->d_scal.p;
     lp.devs = b->d_rows.p;
+    lp.n_rows = (uint32_t)b->rows.size();
     lp.n_devs = n_devs;
     lp.sizes = b->d_sizes.p;
     lp.pkg_bytes = b->d_pkg_bytes.p;

@@ -76,7 +76,7 @@ struct DevRow {
     int s_short, s_long, s_reset, s_gap, s_sync, s_tol;
     float f_short, f_long;
     int valid;    // 0: "sample rate too low" early return, or degenerate timing
-    int orig;     // index in registration order
+    int orig;     // index in registration order; -1 = padding row
     int is_fsk;
 };
 
@@ -86,8 +86,9 @@ struct SliceParams {
     uint32_t const *dir_stream; // per package: capture index
     uint32_t const *dir_off;    // per package: byte offset of its record in that capture's arena
     uint32_t const *n_pkgs;     // device scalar: total packages
-    DevRow const *devs;         // sorted by modulation
-    uint32_t n_devs;
+    DevRow const *devs;         // n_rows slicer rows: grouped by modulation, every group padded to whole wavefronts
+    uint32_t n_rows;
+    uint32_t n_devs;            // registered devices (width of `sizes`)
     uint32_t *sizes;            // [pkg][orig dev] bytes of event records
     uint32_t *pkg_bytes;        // [pkg] total
     uint32_t const *pkg_off;    // [pkg] exclusive scan of pkg_bytes

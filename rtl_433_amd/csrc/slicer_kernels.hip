@@ -2,8 +2,9 @@
 //
 // Work item = (package, chunk of 64 devices); one wavefront per item.  The package's (pulse, gap)
 // pairs are staged once in LDS (<= 9.6 KB, coalesced 8-byte loads) and every lane runs the slicer
-// of its own device over them (LDS broadcast reads).  Devices are pre-sorted by modulation so a
-// wavefront mostly executes one slicer.  Two passes over the same code (COUNT, WRITE) around an
+// of its own device over them (LDS broadcast reads).  Devices are grouped by modulation and every
+// group is padded to whole wavefronts, so a wavefront executes exactly one slicer: the slowest lane
+// of a mixed wavefront used to pay for every slicer present in it.  Two passes over the same code (COUNT, WRITE) around an
 // exclusive scan give a dense event stream in canonical (package, device, event) order without
 // atomics on the payload.
 //
@@ -38,7 +39,7 @@ template <bool WRITE> __global__ __launch_bounds__(64) void k_slice(SliceParams 
     __shared__ uint32_t prefix[WRITE ? kMaxDevs : 1];
 
     uint32_t const n_pkgs = min(*p.n_pkgs, p.max_pkgs);
-    uint32_t const chunks = (p.n_devs + 63) / 64;
+    uint32_t const chunks = p.n_rows / 64;
     uint32_t const lane = threadIdx.x;
 
     for (uint32_t work = blockIdx.x; work < n_pkgs * chunks; work += gridDim.x) {
@@ -67,8 +68,8 @@ template <bool WRITE> __global__ __launch_bounds__(64) void k_slice(SliceParams 
 
         uint32_t const di = chunk * 64 + lane;
         uint32_t my_bytes = 0;
-        if (di < p.n_devs) {
-            DevRow const t = p.devs[di];
+        DevRow const t = p.devs[di];
+        if (t.orig >= 0) { // not a padding row
             bool const run = t.valid && (t.is_fsk != 0) == (type == R433_PKG_FSK);
             BitSink<WRITE> sink;
             uint8_t *out = nullptr;
@@ -130,9 +131,9 @@ __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t const *in, uint32_t 
         *total = carry;
 }
 
-uint32_t slice_grid(uint32_t grid_pkgs, uint32_t n_devs)
+uint32_t slice_grid(uint32_t grid_pkgs, uint32_t n_rows)
 {
-    uint64_t items = (uint64_t)grid_pkgs * ((n_devs + 63) / 64);
+    uint64_t items = (uint64_t)grid_pkgs * (n_rows / 64);
     if (items < 1)
         items = 1;
     // 256 CUs x 8 wavefront slots per SIMD pair is plenty; the kernel grid-strides beyond this
@@ -143,7 +144,7 @@ uint32_t slice_grid(uint32_t grid_pkgs, uint32_t n_devs)
 
 void launch_slice_count(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_slice<false>, dim3(slice_grid(grid_pkgs, p.n_devs)), dim3(64), 0, st, p);
+    hipLaunchKernelGGL(k_slice<false>, dim3(slice_grid(grid_pkgs, p.n_rows)), dim3(64), 0, st, p);
 }
 
 void launch_scan_u32(uint32_t const *in, uint32_t *out, uint32_t const *n_ptr, uint32_t n_cap, uint32_t *total,
@@ -154,7 +155,7 @@ void launch_scan_u32(uint32_t const *in, uint32_t *out, uint32_t const *n_ptr, u
 
 void launch_slice_write(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_slice<true>, dim3(slice_grid(grid_pkgs, p.n_devs)), dim3(64), 0, st, p);
+    hipLaunchKernelGGL(k_slice<true>, dim3(slice_grid(grid_pkgs, p.n_rows)), dim3(64), 0, st, p);
 }
 
 } // namespace r433
