@@ -63,7 +63,58 @@ template <int KIND> __global__ __launch_bounds__(256) void k_envelope(uint8_t co
         atomicAdd(sum, part[0] + part[1] + part[2] + part[3]);
 }
 
+// Per (capture, frame) envelope sums only: what -Y autolevel needs before the detector may run
+// (reference src/r_flow.c:150-189: avg_db of the frame decides the detection level of that same frame).
+// One block per (capture, frame); HBM-bound, the IQ stream is read once and nothing is written back.
+template <int KIND> __global__ __launch_bounds__(256) void k_frame_sums(uint8_t const *iq, uint64_t stride_bytes,
+        uint32_t const *stream_bytes, uint32_t uniform_bytes, uint32_t frame_samples, uint32_t frames_cap, uint32_t *sums)
+{
+    constexpr int SS = KIND == ENV_MAG_CS16 ? 4 : 2;
+    constexpr int SPV = 16 / SS;
+    uint32_t const s = blockIdx.x / frames_cap, f = blockIdx.x % frames_cap;
+    uint32_t const my_n = (stream_bytes ? stream_bytes[s] : uniform_bytes) / SS;
+    uint64_t const start = (uint64_t)f * frame_samples;
+    uint32_t acc = 0;
+    if (start < my_n) {
+        uint32_t const cnt = (uint32_t)min((uint64_t)frame_samples, (uint64_t)my_n - start);
+        uint8_t const *base = iq + (uint64_t)s * stride_bytes + start * SS; // 16-byte aligned: frames are multiples of 64 samples
+        uint32_t const n_vec = cnt / SPV;
+        for (uint32_t v = threadIdx.x; v < n_vec; v += 256) {
+            uint4 w = ((uint4 const *)base)[v];
+            if (SS == 2)
+                acc += env_one<KIND>(w.x & 0xffffu) + env_one<KIND>(w.x >> 16) + env_one<KIND>(w.y & 0xffffu) + env_one<KIND>(w.y >> 16)
+                        + env_one<KIND>(w.z & 0xffffu) + env_one<KIND>(w.z >> 16) + env_one<KIND>(w.w & 0xffffu) + env_one<KIND>(w.w >> 16);
+            else
+                acc += env_one<KIND>(w.x) + env_one<KIND>(w.y) + env_one<KIND>(w.z) + env_one<KIND>(w.w);
+        }
+        uint32_t const i = n_vec * SPV + threadIdx.x;
+        if (i < cnt)
+            acc += env_one<KIND>(SS == 2 ? ((uint16_t const *)base)[i] : ((uint32_t const *)base)[i]);
+    }
+    for (int o = 32; o > 0; o >>= 1)
+        acc += (uint32_t)__shfl_down((int)acc, o, 64);
+    __shared__ uint32_t part[4];
+    if ((threadIdx.x & 63) == 0)
+        part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
 } // namespace
+
+void launch_frame_sums(int kind, void const *d_iq, uint64_t stride_bytes, uint32_t const *stream_bytes, uint32_t uniform_bytes,
+        uint32_t n_streams, uint32_t frame_samples, uint32_t frames_cap, uint32_t *sums, hipStream_t st)
+{
+    dim3 grid(n_streams * frames_cap), block(256);
+    uint8_t const *iq = (uint8_t const *)d_iq;
+    if (kind == ENV_AMP_CU8)
+        hipLaunchKernelGGL(k_frame_sums<ENV_AMP_CU8>, grid, block, 0, st, iq, stride_bytes, stream_bytes, uniform_bytes, frame_samples, frames_cap, sums);
+    else if (kind == ENV_MAG_CU8)
+        hipLaunchKernelGGL(k_frame_sums<ENV_MAG_CU8>, grid, block, 0, st, iq, stride_bytes, stream_bytes, uniform_bytes, frame_samples, frames_cap, sums);
+    else
+        hipLaunchKernelGGL(k_frame_sums<ENV_MAG_CS16>, grid, block, 0, st, iq, stride_bytes, stream_bytes, uniform_bytes, frame_samples, frames_cap, sums);
+}
 
 void launch_envelope(int kind, void const *d_iq, uint16_t *d_env, uint32_t n, uint32_t *d_sum, hipStream_t st)
 {

@@ -287,6 +287,8 @@ struct r433_batch {
     DevBuf<int2> d_ring;
     DevBuf<StreamState> d_state;
     DevBuf<uint32_t> d_frame_sums, d_stream_bytes, d_pkg_base, d_scal;
+    DevBuf<int> d_frame_min_high;
+    std::vector<int> h_frame_min_high;
     DevBuf<uint32_t> d_dir_stream, d_dir_off, d_rec_bytes, d_rec_off, d_sizes, d_pkg_bytes, d_pkg_off;
     DevBuf<uint8_t> d_pkg_blob, d_events;
     PinBuf<uint32_t> h_scal, h_frame_sums;
@@ -438,6 +440,7 @@ void r433_batch_destroy(r433_batch *b)
     b->d_ring.release();
     b->d_state.release();
     b->d_frame_sums.release();
+    b->d_frame_min_high.release();
     b->d_stream_bytes.release();
     b->d_pkg_base.release();
     b->d_scal.release();
@@ -548,6 +551,54 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
 
     if (b->profiling)
         HIP_TRY(hipEventRecord(b->ev[0], st));
+
+    // -Y autolevel (reference src/r_flow.c:166-186): the detection level of a frame follows the noise
+    // estimate, which follows the mean envelope of the frames so far -- a short recurrence in host
+    // floats (same libm as the reference) over per-frame sums that one HBM-bound pass provides.
+    int const *d_min_high = nullptr;
+    if (b->cfg.auto_level > 0) {
+        if ((rc = b->d_frame_min_high.ensure((size_t)n_streams * frames_cap)) || (rc = b->h_frame_sums.ensure((size_t)n_streams * frames_cap)))
+            return rc;
+        int const kind = ss == 4 ? ENV_MAG_CS16 : b->cfg.use_mag_est ? ENV_MAG_CU8 : ENV_AMP_CU8;
+        launch_frame_sums(kind, d_iq, stride_bytes, stream_bytes ? b->d_stream_bytes.p : nullptr, (uint32_t)stride_bytes, n_streams,
+                b->cfg.frame_samples, frames_cap, b->d_frame_sums.p, st);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(b->h_frame_sums.p, b->d_frame_sums.p, (size_t)n_streams * frames_cap * sizeof(uint32_t),
+                hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        b->h_frame_min_high.assign((size_t)n_streams * frames_cap, b->det.min_high);
+        int const is_mag = ss == 4 || b->cfg.use_mag_est;
+        for (uint32_t s = 0; s < n_streams; ++s) {
+            uint32_t const n = (stream_bytes ? stream_bytes[s] : (uint32_t)stride_bytes) / ss;
+            float noise_level = 0.0f, min_level_auto = 0.0f;
+            DetCfg lv = b->det;
+            for (uint32_t f = 0; f < frames_cap; ++f) {
+                uint64_t const start = (uint64_t)f * b->cfg.frame_samples;
+                if (start < n) {
+                    uint32_t const cnt = (uint32_t)std::min<uint64_t>(b->cfg.frame_samples, n - start);
+                    float const avg_db = r433_level_db(b->h_frame_sums.p[(size_t)s * frames_cap + f], cnt, is_mag);
+                    if (min_level_auto == 0.0f)
+                        min_level_auto = b->cfg.min_level_db;
+                    if (noise_level == 0.0f)
+                        noise_level = min_level_auto - 3.0f;
+                    if (avg_db < noise_level + 3.0f) {
+                        noise_level = (noise_level * 7 + avg_db) / 8;
+                        if (noise_level < b->cfg.min_level_db - 3.0f && fabsf(min_level_auto - noise_level - 3.0f) > 1.0f) {
+                            min_level_auto = noise_level + 3.0f;
+                            levels_from_db(lv, (int)b->cfg.use_mag_est, b->cfg.level_limit_db, min_level_auto, b->cfg.min_snr_db);
+                        }
+                    }
+                    else {
+                        noise_level = (noise_level * 31 + avg_db) / 32;
+                    }
+                }
+                b->h_frame_min_high[(size_t)s * frames_cap + f] = lv.min_high;
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(b->d_frame_min_high.p, b->h_frame_min_high.data(), b->h_frame_min_high.size() * sizeof(int),
+                hipMemcpyHostToDevice, st));
+        d_min_high = b->d_frame_min_high.p;
+    }
     uint32_t total_pkgs = 0;
     for (int attempt = 0;; ++attempt) {
         if ((rc = b->d_arena.ensure((size_t)n_streams * b->arena_stride)))
@@ -576,7 +627,7 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
         sp.state = b->d_state.p;
         sp.frame_sums = b->d_frame_sums.p;
         sp.frames_cap = frames_cap;
-        sp.frame_min_high = nullptr;
+        sp.frame_min_high = d_min_high;
         sp.tap_env = (uint16_t *)b->tap_env;
         sp.tap_am = (int16_t *)b->tap_am;
         sp.tap_fm = (int16_t *)b->tap_fm;

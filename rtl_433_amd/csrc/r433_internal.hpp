@@ -115,6 +115,8 @@ void launch_slice_write(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st
 
 // ---- function-level baseband kernels (device pointers) ----
 enum { ENV_AMP_CU8 = 0, ENV_MAG_CU8 = 1, ENV_MAG_CS16 = 2 };
+void launch_frame_sums(int kind, void const *d_iq, uint64_t stride_bytes, uint32_t const *stream_bytes, uint32_t uniform_bytes,
+        uint32_t n_streams, uint32_t frame_samples, uint32_t frames_cap, uint32_t *sums, hipStream_t st);
 void launch_envelope(int kind, void const *d_iq, uint16_t *d_env, uint32_t n, uint32_t *d_sum, hipStream_t st);
 
 } // namespace r433

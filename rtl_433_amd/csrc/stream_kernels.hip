@@ -184,7 +184,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
     // branches, in the fast paths and in the general step alike; lane 0 alone touches the arena and
     // the FSK ring (detect_device.hpp).
     DetLane det;
-    DetCfg const cfg = p.det;
+    DetCfg cfg = p.det; // min_high follows p.frame_min_high per frame when -Y autolevel is on
     det_reset(det);
     det.arena = p.arena + (uint64_t)s * p.arena_stride;
     det.fsk_ring = p.fsk_ring + (uint64_t)s * R433_PD_MAX_PULSES; // HBM scratch, touched by lane 0 on FSK pulses only
@@ -674,6 +674,8 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
             tk[7] += 1;
             if (dc == 0) { // a new frame == a new push_sdr_flow call
                 flen = (int)min(my_n - (t0 + (uint32_t)i), F);
+                if (p.frame_min_high) // pulse_detect_set_levels before this frame's detection, r_flow.c:180-186
+                    cfg.min_high = uni(p.frame_min_high[(uint64_t)s * p.frames_cap + min(frame, p.frames_cap - 1)]);
                 det_call_entry(det, cfg, flen, 0);
             }
             // Every lane holds the same values here, but they have been through per-lane-looking code

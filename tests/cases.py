@@ -53,3 +53,16 @@ def make_case(name):
 def fpdm_for(freq):
     """FSK detector resolution for AUTO mode, reference src/rtl_433.c:1094-1102."""
     return 1 if freq > 800000000 else 0
+
+
+def autolevel_capture(seed=31, n_frames=5, amp=15.0, sigma=1.0):
+    """Several reference frames of quiet noise with OOK bursts too weak for the default -12 dB level:
+    only -Y autolevel (which lowers the level frame by frame as the noise estimate settles) sees them."""
+    rng = np.random.default_rng(seed)
+    n = n_frames * 131072 + 4321
+    segs = [(30000, False)]
+    while sum(s[0] for s in segs) < n - 40000:
+        bits = rng.integers(0, 2, 32).astype(np.uint8)
+        segs += synth.ook_segments(bits, "pwm", 120, 240, repeats=1) + [(int(rng.integers(50000, 90000)), False)]
+    mask = synth._segments_to_mask(segs, n)
+    return synth.modulate_cu8(mask, rng, 250000, 15e3, amp, sigma)

@@ -176,3 +176,19 @@ def test_noise_floor_tracking():
     pk, ev, base = _oracle_batch(iqs, None, cfg)
     assert base >= 8
     assert g["packages"][0] == pk
+
+
+def test_autolevel(default_devices):
+    """-Y autolevel: per-frame detection level from the running noise estimate (src/r_flow.c:166-186)."""
+    from tests.cases import autolevel_capture
+    from tests.emu import host
+    devs = default_devices[0][:30]
+    iq = autolevel_capture()
+    cfg_on = po.default_flow_cfg(2, 250000, auto_level=1.0)
+    o_on = po.oracle_flow(iq, devs, cfg_on)
+    o_off = po.oracle_flow(iq, devs, po.default_flow_cfg(2, 250000))
+    assert o_on["n_packages"] > o_off["n_packages"], "the capture must need autolevel to be decoded"
+    g = host.emu_run([iq, iq[: 2 * 200000]], 2, 250000, devs, auto_level=1.0)
+    o2 = po.oracle_flow(iq[: 2 * 200000], devs, cfg_on, stream_index=1, pkg_base=o_on["n_packages"])
+    assert g["packages"][0] == o_on["packages"] + o2["packages"]
+    assert g["events"][0] == o_on["events"] + o2["events"]

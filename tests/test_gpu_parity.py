@@ -149,3 +149,17 @@ def test_noise_floor_tracking():
         pk_all += o["packages"]
         base += o["n_packages"]
     assert base >= 8 and g["packages"][0] == pk_all
+
+
+def test_autolevel(default_devices):
+    """-Y autolevel on the GPU: frame-sum pre-pass, host level recurrence, per-frame detection level."""
+    from tests.cases import autolevel_capture
+    devs = default_devices[0]
+    iq = autolevel_capture()
+    g = _gpu_run([iq, iq[: 2 * 200000]], 2, 250000, 433920000, devs, auto_level=1.0)
+    cfg = po.default_flow_cfg(2, 250000, auto_level=1.0)
+    o1 = po.oracle_flow(iq, devs, cfg)
+    o2 = po.oracle_flow(iq[: 2 * 200000], devs, cfg, stream_index=1, pkg_base=o1["n_packages"])
+    assert o1["n_packages"] >= 4
+    assert g["packages"][0] == o1["packages"] + o2["packages"]
+    assert g["events"][0] == o1["events"] + o2["events"]
