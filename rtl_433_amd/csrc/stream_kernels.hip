@@ -616,6 +616,16 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
         int a64_l = 0, f64_l = 0;  // am / 64, fm / 64 (C division) for the level and carrier averages
         int in_pk_l = 0;           // the two of them packed as 16-bit halves
         int bmax = 0, bmin = 0;
+        // chunk statistics (lane = chunk) and their suffix extrema, for jumping over whole chunks
+        int const my_cmax = s_cmax[lane], my_cmin = s_cmin[lane];
+        int sfx_max = my_cmax, sfx_min = my_cmin;
+        for (int o = 1; o < 64; o <<= 1) {
+            int const qa = __shfl_down(sfx_max, o, 64), qb = __shfl_down(sfx_min, o, 64);
+            if (lane + o < 64) {
+                sfx_max = max(sfx_max, qa);
+                sfx_min = min(sfx_min, qb);
+            }
+        }
         // Lazy noise floor.  While the detector idles over samples that cannot start a pulse, every
         // step moves `low` by exactly +-1 towards the sample (pulse_detect.c:326-329 with |am-low| < 1024),
         // so (a) its parity after n steps is known without walking, (b) it never leaves
@@ -694,6 +704,59 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
             det.eop_spurious = uni(det.eop_spurious);
             det.cur_pulse = uni(det.cur_pulse);
             det.ook_f1 = uni(det.ook_f1);
+            // ---- whole chunks at a time: while idle or inside a gap, nothing can happen before the first
+            // chunk whose maximum reaches the (conservative) threshold, the end-of-package count, or the
+            // end of the frame ----
+            if ((det.state == ST_IDLE && det.lead_in > 1024) || det.state == ST_GAP) {
+                int const ci = i >> 5;
+                int const lim_i = min(n_t, i + (flen - dc));
+                int jump_to = i;
+                if (det.state == ST_IDLE) {
+                    int const rmin = __builtin_amdgcn_readlane(sfx_min, ci), rmax = __builtin_amdgcn_readlane(sfx_max, ci);
+                    int const l_lo = min(det.low, min(lz_min, rmin)) - 1;
+                    int const l_hi = max(det.low, max(lz_max, rmax)) + 1;
+                    if (l_hi - l_lo < 1000) {
+                        int thr = (int)(int16_t)((l_lo + min(cfg.min_high, cfg.max_high)) / 2);
+                        if (cfg.fixed_high != 0)
+                            thr = (int)(int16_t)cfg.fixed_high;
+                        int const hys = (int)(int16_t)(thr / 8);
+                        unsigned long long const m = __ballot(lane >= ci && my_cmax > thr + hys);
+                        jump_to = min(m ? (__ffsll(m) - 1) * kChunk : n_t, lim_i);
+                        if (jump_to > i) {
+                            if (lz_n == 0)
+                                lz_from = i;
+                            lz_n += jump_to - i;
+                            lz_min = min(lz_min, rmin);
+                            lz_max = max(lz_max, rmax);
+                        }
+                    }
+                }
+                else {
+                    int thr = (int)(int16_t)((det.low + min(det.high, cfg.max_high)) / 2);
+                    if (cfg.fixed_high != 0)
+                        thr = (int)(int16_t)cfg.fixed_high;
+                    int const hys = (int)(int16_t)(thr / 8);
+                    unsigned long long const m = __ballot(lane >= ci && my_cmax > thr + hys);
+                    long long const lim = min(max(10ll * det.max_pulse, 10ll * cfg.per_ms), 100ll * cfg.per_ms);
+                    long long const togo = det.eop_spurious ? 0 : max(0ll, lim - (long long)det.run);
+                    int const je = togo < (long long)(lim_i - i) ? i + (int)togo : lim_i;
+                    jump_to = min(min(m ? (__ffsll(m) - 1) * kChunk : n_t, je), lim_i);
+                    if (jump_to > i)
+                        det.run += jump_to - i;
+                }
+                if (jump_to > i) {
+                    int const done = jump_to - i;
+                    i += done;
+                    dc += done;
+                    if (dc == flen) {
+                        input_pos += (uint64_t)flen;
+                        frame += 1;
+                        dc = 0;
+                    }
+                    tk[st_it == ST_IDLE ? 1 : 2] += now() - t_it;
+                    continue;
+                }
+            }
             int const base = i & ~63;
             int const e = min(min(n_t, base + 64), i + (flen - dc));
             if (loaded != base) {
