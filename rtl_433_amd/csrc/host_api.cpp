@@ -290,7 +290,7 @@ struct r433_batch {
     DevBuf<int> d_frame_min_high;
     std::vector<int> h_frame_min_high;
     DevBuf<uint32_t> d_dir_stream, d_dir_off, d_rec_bytes, d_rec_off, d_sizes, d_pkg_bytes, d_pkg_off;
-    DevBuf<uint8_t> d_pkg_blob, d_events;
+    DevBuf<uint8_t> d_pkg_blob, d_events, d_stage;
     PinBuf<uint32_t> h_scal, h_frame_sums;
     PinBuf<uint8_t> h_pkg_blob, h_events;
     PinBuf<uint32_t> h_pkg_off, h_rec_off; // per package: byte offset of its first event / of its record
@@ -453,6 +453,7 @@ void r433_batch_destroy(r433_batch *b)
     b->d_pkg_off.release();
     b->d_pkg_blob.release();
     b->d_events.release();
+    b->d_stage.release();
     b->h_scal.release();
     b->h_frame_sums.release();
     b->h_pkg_blob.release();
@@ -682,6 +683,20 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
     lp.pkg_off = b->d_pkg_off.p;
     lp.max_pkgs = max_pkgs;
     if (n_devs && total_pkgs) {
+        // One slicing pass into staging slots when they fit.  A default device set yields ~135 B per
+        // (package, device) on average but the heavy PCM rows reach a few KB, and those are exactly the
+        // slow lanes, so the slot is made as large as the arena budget allows (up to 4 KB); below 512 B
+        // the classic count + write pair runs instead.
+        constexpr size_t kStageMax = (size_t)6 << 30;
+        uint32_t stage_cap = 4096;
+        while (stage_cap >= 512 && (size_t)total_pkgs * b->rows.size() * stage_cap > kStageMax)
+            stage_cap >>= 1;
+        if (stage_cap >= 512 && !getenv("R433_TWO_PASS_SLICER")) {
+            if ((rc = b->d_stage.ensure((size_t)total_pkgs * b->rows.size() * stage_cap)))
+                return rc;
+            lp.stage = b->d_stage.p;
+            lp.stage_cap = stage_cap;
+        }
         HIP_TRY(hipMemsetAsync(b->d_pkg_bytes.p, 0, (size_t)max_pkgs * sizeof(uint32_t), st));
         launch_slice_count(lp, total_pkgs, st);
         HIP_TRY(hipGetLastError());

@@ -94,6 +94,8 @@ struct SliceParams {
     uint32_t const *pkg_off;    // [pkg] exclusive scan of pkg_bytes
     uint8_t *events;
     uint32_t events_cap;
+    uint8_t *stage;             // [pkg][row] slots of stage_cap bytes, or nullptr: count + write passes
+    uint32_t stage_cap;
     uint32_t max_pkgs;
 };
 

@@ -4,9 +4,11 @@
 // pairs are staged once in LDS (<= 9.6 KB, coalesced 8-byte loads) and every lane runs the slicer
 // of its own device over them (LDS broadcast reads).  Devices are grouped by modulation and every
 // group is padded to whole wavefronts, so a wavefront executes exactly one slicer: the slowest lane
-// of a mixed wavefront used to pay for every slicer present in it.  Two passes over the same code (COUNT, WRITE) around an
-// exclusive scan give a dense event stream in canonical (package, device, event) order without
-// atomics on the payload.
+// of a mixed wavefront used to pay for every slicer present in it.  Records are built once into a
+// fixed-size staging slot per (package, device); an exclusive scan of their sizes and a compaction
+// pass give a dense event stream in canonical (package, device, event) order without atomics on the
+// payload.  (A record that outgrows its slot is sliced a second time straight into the stream; if the
+// staging arena itself would be too large the classic count + write pair runs instead.)
 //
 // Replaces run_ook_demods / run_fsk_demods (reference src/r_api.c:438-550) and the ten
 // pulse_slicer_* functions (src/pulse_slicer.c) up to, not including, the decode_fn call, which
@@ -33,10 +35,20 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total)
     return x - v;
 }
 
-template <bool WRITE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
+// MODE: what one visit of a (package, 64 devices) work item does
+//   M_COUNT    slice, keep only the record sizes                    } the two-pass fallback when the
+//   M_WRITE    slice again, records to their final place            } staging arena would not fit
+//   M_STAGE    slice ONCE, records into a fixed-size staging slot per (package, row) + their true sizes
+//   M_COMPACT  copy staged records to their final place; a (package, device) that outgrew its slot is
+//              sliced again straight into the event stream
+enum { M_COUNT = 0, M_WRITE = 1, M_STAGE = 2, M_COMPACT = 3 };
+
+template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
 {
+    constexpr bool PLACE = MODE == M_WRITE || MODE == M_COMPACT; // records go to their final offsets
+    constexpr bool STORE = MODE != M_COUNT;                       // the sink stores bytes
     __shared__ int2 pairs[R433_PD_MAX_PULSES];
-    __shared__ uint32_t prefix[WRITE ? kMaxDevs : 1];
+    __shared__ uint32_t prefix[PLACE ? kMaxDevs : 1];
 
     uint32_t const n_pkgs = min(*p.n_pkgs, p.max_pkgs);
     uint32_t const chunks = p.n_rows / 64;
@@ -49,10 +61,18 @@ template <bool WRITE> __global__ __launch_bounds__(64) void k_slice(SliceParams 
         uint32_t const type = ((uint32_t const *)rec)[2];
         uint32_t const num = min(((uint32_t const *)rec)[3], (uint32_t)R433_PD_MAX_PULSES);
         int2 const *src = (int2 const *)(rec + sizeof(r433_pkg_rec));
+        uint32_t const di = chunk * 64 + lane;
+        DevRow const t = p.devs[di];
+        uint32_t my_size = 0;
+        if (PLACE && t.orig >= 0)
+            my_size = p.sizes[(uint64_t)pkg * p.n_devs + t.orig];
+        // a compaction visit only needs the pulses if some record of the item has to be sliced again
+        bool const need_pulses = MODE != M_COMPACT || __ballot(my_size > p.stage_cap) != 0;
         __syncthreads(); // previous item done with LDS
-        for (uint32_t i = lane; i < num; i += 64)
-            pairs[i] = src[i];
-        if (WRITE) { // exclusive prefix of this package's per-device sizes, in registration order
+        if (need_pulses)
+            for (uint32_t i = lane; i < num; i += 64)
+                pairs[i] = src[i];
+        if (PLACE) { // exclusive prefix of this package's per-device sizes, in registration order
             uint32_t carry = 0;
             for (uint32_t b = 0; b < p.n_devs; b += 64) {
                 uint32_t i = b + lane;
@@ -66,31 +86,56 @@ template <bool WRITE> __global__ __launch_bounds__(64) void k_slice(SliceParams 
         }
         __syncthreads();
 
-        uint32_t const di = chunk * 64 + lane;
         uint32_t my_bytes = 0;
-        DevRow const t = p.devs[di];
+        uint32_t copy_bytes = 0, copy_base = 0;
         if (t.orig >= 0) { // not a padding row
             bool const run = t.valid && (t.is_fsk != 0) == (type == R433_PKG_FSK);
-            BitSink<WRITE> sink;
+            uint8_t *const slot = MODE == M_STAGE || MODE == M_COMPACT
+                    ? p.stage + ((uint64_t)pkg * p.n_rows + di) * p.stage_cap : nullptr;
+            BitSink<STORE> sink;
             uint8_t *out = nullptr;
             uint32_t limit = 0;
             bool fits = true;
-            if (WRITE) {
+            bool slice = run;
+            if (PLACE) {
                 uint32_t base = p.pkg_off[pkg] + prefix[t.orig];
-                limit = p.sizes[(uint64_t)pkg * p.n_devs + t.orig];
+                limit = my_size;
                 fits = limit > 0 && (uint64_t)base + limit <= p.events_cap;
                 out = p.events + base;
+                if (MODE == M_COMPACT && fits && limit <= p.stage_cap) { // the common case: a plain copy (below)
+                    copy_bytes = limit;
+                    copy_base = base;
+                    slice = false;
+                }
             }
-            if (run && fits) {
+            else if (MODE == M_STAGE) {
+                out = slot;
+                limit = p.stage_cap;
+            }
+            if (slice && fits) {
                 PulseView pv{pairs, num};
                 sink.begin(out, limit, pkg, (uint32_t)t.orig);
-                slice_dispatch<WRITE>(pv, t, sink);
+                slice_dispatch<STORE>(pv, t, sink);
                 my_bytes = sink.off;
             }
-            if (!WRITE)
+            if (!PLACE)
                 p.sizes[(uint64_t)pkg * p.n_devs + t.orig] = my_bytes;
         }
-        if (!WRITE) {
+        if (MODE == M_COMPACT) {
+            // staged records -> event stream, one record at a time with the whole wavefront (a lane copying
+            // its own record word by word would pay a global-memory round trip per word)
+            unsigned long long todo = __ballot(copy_bytes > 0);
+            while (todo) {
+                int const r = __ffsll(todo) - 1;
+                todo &= todo - 1;
+                uint32_t const nb = (uint32_t)__builtin_amdgcn_readlane((int)copy_bytes, r);
+                uint32_t const at = (uint32_t)__builtin_amdgcn_readlane((int)copy_base, r);
+                uint8_t const *src_r = p.stage + ((uint64_t)pkg * p.n_rows + chunk * 64 + (uint32_t)r) * p.stage_cap;
+                for (uint32_t w = lane * 4; w < nb; w += 256)
+                    *(uint32_t *)(p.events + at + w) = *(uint32_t const *)(src_r + w);
+            }
+        }
+        if (!PLACE) {
             uint32_t tot;
             wave_excl_scan(my_bytes, tot);
             if (lane == 0 && tot)
@@ -144,7 +189,10 @@ uint32_t slice_grid(uint32_t grid_pkgs, uint32_t n_rows)
 
 void launch_slice_count(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_slice<false>, dim3(slice_grid(grid_pkgs, p.n_rows)), dim3(64), 0, st, p);
+    if (p.stage)
+        hipLaunchKernelGGL(k_slice<M_STAGE>, dim3(slice_grid(grid_pkgs, p.n_rows)), dim3(64), 0, st, p);
+    else
+        hipLaunchKernelGGL(k_slice<M_COUNT>, dim3(slice_grid(grid_pkgs, p.n_rows)), dim3(64), 0, st, p);
 }
 
 void launch_scan_u32(uint32_t const *in, uint32_t *out, uint32_t const *n_ptr, uint32_t n_cap, uint32_t *total,
@@ -155,7 +203,10 @@ void launch_scan_u32(uint32_t const *in, uint32_t *out, uint32_t const *n_ptr, u
 
 void launch_slice_write(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_slice<true>, dim3(slice_grid(grid_pkgs, p.n_rows)), dim3(64), 0, st, p);
+    if (p.stage)
+        hipLaunchKernelGGL(k_slice<M_COMPACT>, dim3(slice_grid(grid_pkgs, p.n_rows)), dim3(64), 0, st, p);
+    else
+        hipLaunchKernelGGL(k_slice<M_WRITE>, dim3(slice_grid(grid_pkgs, p.n_rows)), dim3(64), 0, st, p);
 }
 
 } // namespace r433
