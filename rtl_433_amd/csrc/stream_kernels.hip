@@ -43,6 +43,8 @@ constexpr int kRow = 512;           // samples per phase-A row (8 per lane)
 constexpr int kRows = kTile / kRow;
 constexpr int kPitch16 = kChunk * 2 + 16;  // LDS pitch of a chunk of 16-bit samples: conflict-free b128 per lane
 constexpr int kPitch32 = kChunk * 4 + 16;
+constexpr int kPitchOut = kChunk * 2;       // filtered samples: time-linear, read by sample index (the padded pitch buys
+                                             // nothing there and 8 wavefronts' LDS must fit one CU: 8 x 20 KB = 160 KB)
 
 __device__ __forceinline__ int rl0(int v)
 {
@@ -65,7 +67,7 @@ __device__ __forceinline__ int wave_sum(int v)
 
 __device__ __forceinline__ int ld16(uint8_t const *buf, int i)
 {
-    return (int)*(int16_t const *)(buf + (i >> 5) * kPitch16 + (i & 31) * 2);
+    return (int)*(int16_t const *)(buf + i * 2);
 }
 
 // ---- phase B: one low-pass, both extreme tracks ----
@@ -168,8 +170,8 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
     using G = Geom<SS>;
     __shared__ __attribute__((aligned(16))) uint8_t s_env[64 * kPitch16];
     __shared__ __attribute__((aligned(16))) uint8_t s_f[64 * G::f_pitch];
-    __shared__ __attribute__((aligned(16))) uint8_t s_am[64 * kPitch16];
-    __shared__ __attribute__((aligned(16))) uint8_t s_fm[64 * kPitch16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_am[64 * kPitchOut];
+    __shared__ __attribute__((aligned(16))) uint8_t s_fm[64 * kPitchOut];
     __shared__ int s_cmax[64], s_cmin[64];
 
     int const lane = (int)threadIdx.x;
@@ -438,8 +440,8 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                     }
                 }
                 if (MAIN) {
-                    *(uint4 *)(s_am + lane * kPitch16 + g * 16) = make_uint4(oa[0], oa[1], oa[2], oa[3]);
-                    *(uint4 *)(s_fm + lane * kPitch16 + g * 16) = make_uint4(of[0], of[1], of[2], of[3]);
+                    *(uint4 *)(s_am + lane * kPitchOut + g * 16) = make_uint4(oa[0], oa[1], oa[2], oa[3]);
+                    *(uint4 *)(s_fm + lane * kPitchOut + g * 16) = make_uint4(of[0], of[1], of[2], of[3]);
                 }
             }
         };
@@ -513,7 +515,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                         // every step of my chunk leaves y0 where it is: outputs are constant
                         int const out = (which == 0 || SS == 2) ? y0 : (int)(int16_t)(y0 >> 16);
                         uint32_t const w2 = ((uint32_t)out & 0xffffu) * 0x10001u;
-                        uint8_t *dst = (which == 0 ? s_am : s_fm) + lane * kPitch16;
+                        uint8_t *dst = (which == 0 ? s_am : s_fm) + lane * kPitchOut;
                         for (int g = 0; g < kChunk / 8; ++g)
                             *(uint4 *)(dst + g * 16) = make_uint4(w2, w2, w2, w2);
                         st.y_end = y0;
@@ -569,7 +571,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                                 f1 = f;
                                 out = (int)(int16_t)(y >> 16);
                             }
-                            *(int16_t *)((which == 0 ? s_am : s_fm) + lane * kPitch16 + i * 2) = (int16_t)out;
+                            *(int16_t *)((which == 0 ? s_am : s_fm) + lane * kPitchOut + i * 2) = (int16_t)out;
                         }
                     }
                     if (rerun) {
