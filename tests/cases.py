@@ -66,3 +66,41 @@ def autolevel_capture(seed=31, n_frames=5, amp=15.0, sigma=1.0):
         segs += synth.ook_segments(bits, "pwm", 120, 240, repeats=1) + [(int(rng.integers(50000, 90000)), False)]
     mask = synth._segments_to_mask(segs, n)
     return synth.modulate_cu8(mask, rng, 250000, 15e3, amp, sigma)
+
+
+def mixed_2000k_capture(seed=77, n=900000):
+    """Config-5 style: one 2 MS/s cu8 stream with OOK bursts and FSK bursts over a noise floor that
+    steps up half way (exercises -Y autolevel, the FM low-pass option and both detectors in one capture)."""
+    rng = np.random.default_rng(seed)
+    rate = 2000000
+    t = np.arange(n) / rate
+    amp = np.zeros(n)
+    phase = np.zeros(n)
+    pos = 40000
+    k = 0
+    while pos < n - 120000:
+        if k % 2 == 0:  # OOK PWM burst, 200/400 us pulses
+            bits = rng.integers(0, 2, 24).astype(np.uint8)
+            segs = synth.ook_segments(bits, "pwm", 400, 800, repeats=1)
+            m = synth._segments_to_mask(segs, sum(s[0] for s in segs))
+            a = float(rng.uniform(20, 90))
+            amp[pos:pos + len(m)] = a * m[: n - pos]
+            phase[pos:pos + len(m)] = 2 * np.pi * 30e3 * t[: len(m)]
+            pos += len(m)
+        else:  # FSK PCM burst, 100 us bits, +-50 kHz
+            nb = 64
+            bits = np.concatenate([np.tile([1, 0], 12), rng.integers(0, 2, nb - 24)])
+            lv = np.repeat(2.0 * bits - 1.0, 200)
+            ph = 2 * np.pi * np.cumsum(lv * 50e3) / rate
+            amp[pos:pos + len(ph)] = 80.0
+            phase[pos:pos + len(ph)] = ph
+            pos += len(ph)
+        pos += int(rng.integers(60000, 110000))
+        k += 1
+    sigma = np.where(np.arange(n) < n // 2, 1.0, 3.0)
+    i = 128 + amp * np.cos(phase) + rng.normal(0, 1, n) * sigma
+    q = 128 + amp * np.sin(phase) + rng.normal(0, 1, n) * sigma
+    out = np.empty(2 * n, dtype=np.uint8)
+    out[0::2] = np.clip(np.rint(i), 0, 255)
+    out[1::2] = np.clip(np.rint(q), 0, 255)
+    return out, rate

@@ -192,3 +192,20 @@ def test_autolevel(default_devices):
     o2 = po.oracle_flow(iq[: 2 * 200000], devs, cfg_on, stream_index=1, pkg_base=o_on["n_packages"])
     assert g["packages"][0] == o_on["packages"] + o2["packages"]
     assert g["events"][0] == o_on["events"] + o2["events"]
+
+
+def test_mixed_2000k_autolevel_filter(default_devices):
+    """BASELINE config 5 in miniature: 2 MS/s, OOK + FSK bursts, noise floor step, -Y autolevel, -Y filter."""
+    from tests.cases import mixed_2000k_capture
+    from tests.emu import host
+    devs = default_devices[0][::4]
+    iq, rate = mixed_2000k_capture()
+    kw = dict(auto_level=1.0, fm_low_pass=0.15)
+    cfg = po.default_flow_cfg(2, rate, fpdm=0, **kw)
+    o = po.oracle_flow(iq, devs, cfg, taps=True)
+    types = [p["type"] for p in po.parse_packages(o["packages"])]
+    assert 1 in types and 2 in types, "the capture must produce both OOK and FSK packages"
+    g = host.emu_run([iq], 2, rate, devs, taps=True, **kw)
+    n = iq.nbytes // 2
+    assert np.array_equal(g["taps"][1][0, :n], o["am"]) and np.array_equal(g["taps"][2][0, :n], o["fm"])
+    assert g["packages"][0] == o["packages"] and g["events"][0] == o["events"]

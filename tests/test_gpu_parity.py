@@ -163,3 +163,14 @@ def test_autolevel(default_devices):
     assert o1["n_packages"] >= 4
     assert g["packages"][0] == o1["packages"] + o2["packages"]
     assert g["events"][0] == o1["events"] + o2["events"]
+
+
+def test_mixed_2000k_autolevel_filter(default_devices):
+    """BASELINE config 5 in miniature on the GPU (see tests/test_emu_parity.py)."""
+    from tests.cases import mixed_2000k_capture
+    devs = default_devices[0]
+    iq, rate = mixed_2000k_capture()
+    kw = dict(auto_level=1.0, fm_low_pass=0.15)
+    o = po.oracle_flow(iq, devs, po.default_flow_cfg(2, rate, fpdm=0, **kw))
+    g = _gpu_run([iq], 2, rate, 433920000, devs, **kw)
+    assert g["packages"][0] == o["packages"] and g["events"][0] == o["events"]
