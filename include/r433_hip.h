@@ -86,6 +86,16 @@ int r433_batch_device_events(r433_batch *b, void const **d_events, size_t *len);
  * capture, written to device buffers of n_streams*tap_stride samples.  Pass NULLs to disable. */
 int r433_batch_set_taps(r433_batch *b, void *d_env, void *d_am, void *d_fm, uint64_t tap_stride);
 
+/* Long captures: let several wavefronts work on one capture.  A capture longer than segment_samples is cut
+ * about every segment_samples where the signal looks idle (0 = never, the default).  Cuts are speculative
+ * and verified: every later segment is run for both parities of the noise-floor estimate and kept only if the
+ * segment before it really ended idle with exactly the floor it assumed; a cut that does not verify is
+ * dropped and the piece before it is run again across it, so results never depend on this setting.  There is no reference
+ * counterpart: the reference walks a file sample by sample (src/rtl_433.c:1826-1845). */
+int r433_batch_set_split(r433_batch *b, uint32_t segment_samples);
+/* of the last run: wavefront slots planned (segments incl. parity variants), pieces run again after a dropped cut */
+int r433_batch_split_stats(r433_batch *b, uint32_t *segments, uint32_t *pieces_rerun);
+
 /* Kernel timing of the last run measured with HIP events on the caller's stream (ms). */
 typedef struct r433_batch_timing {
     float detect_ms;  /* k_stream: IQ -> packages */

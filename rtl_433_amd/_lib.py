@@ -50,7 +50,8 @@ _lib = None
 EXPORTS = [
     "r433_version", "r433_last_error", "r433_device_count", "r433_flow_cfg_default", "r433_level_db",
     "r433_batch_create", "r433_batch_destroy", "r433_batch_run", "r433_batch_packages", "r433_batch_events",
-    "r433_batch_frame_sums", "r433_batch_device_events", "r433_batch_set_taps", "r433_batch_set_profiling",
+    "r433_batch_frame_sums", "r433_batch_device_events", "r433_batch_set_taps", "r433_batch_set_split",
+    "r433_batch_split_stats", "r433_batch_set_profiling",
     "r433_batch_get_timing", "r433_batch_debug_state", "r433_batch_dispatch", "r433_batch_dispatch_mt", "r433_dispatch_current",
     "r433_plugin_digest_decode", "r433_envelope_detect", "r433_magnitude_est_cu8",
     "r433_magnitude_est_cs16",
@@ -94,6 +95,10 @@ def bind(L):
     L.r433_batch_device_events.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.r433_batch_set_taps.restype = C.c_int
     L.r433_batch_set_taps.argtypes = [vp, vp, vp, vp, C.c_uint64]
+    L.r433_batch_set_split.restype = C.c_int
+    L.r433_batch_set_split.argtypes = [vp, C.c_uint32]
+    L.r433_batch_split_stats.restype = C.c_int
+    L.r433_batch_split_stats.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.r433_batch_set_profiling.restype = C.c_int
     L.r433_batch_set_profiling.argtypes = [vp, C.c_int]
     L.r433_batch_get_timing.restype = C.c_int

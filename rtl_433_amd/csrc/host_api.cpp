@@ -289,6 +289,13 @@ struct r433_batch {
     DevBuf<uint32_t> d_frame_sums, d_stream_bytes, d_pkg_base, d_scal;
     DevBuf<int> d_frame_min_high;
     std::vector<int> h_frame_min_high;
+    // split captures (r433_batch_set_split)
+    uint32_t split_samples = 0;
+    DevBuf<uint32_t> d_tile_max, d_order;
+    DevBuf<SegDesc> d_segs;
+    PinBuf<uint32_t> h_tile_max;
+    PinBuf<StreamState> h_state;
+    uint32_t last_segments = 0, last_redone = 0;
     DevBuf<uint32_t> d_dir_stream, d_dir_off, d_rec_bytes, d_rec_off, d_sizes, d_pkg_bytes, d_pkg_off;
     DevBuf<uint8_t> d_pkg_blob, d_events, d_stage;
     PinBuf<uint32_t> h_scal, h_frame_sums;
@@ -441,6 +448,11 @@ void r433_batch_destroy(r433_batch *b)
     b->d_state.release();
     b->d_frame_sums.release();
     b->d_frame_min_high.release();
+    b->d_tile_max.release();
+    b->d_order.release();
+    b->d_segs.release();
+    b->h_tile_max.release();
+    b->h_state.release();
     b->d_stream_bytes.release();
     b->d_pkg_base.release();
     b->d_scal.release();
@@ -478,6 +490,27 @@ int r433_batch_set_taps(r433_batch *b, void *d_env, void *d_am, void *d_fm, uint
     b->tap_am = d_am;
     b->tap_fm = d_fm;
     b->tap_stride = tap_stride;
+    return 0;
+}
+
+int r433_batch_set_split(r433_batch *b, uint32_t segment_samples)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    if (segment_samples && segment_samples < 4096)
+        return fail(R433_EINVAL, "segments shorter than 4096 samples make no sense (the establishing tile alone is 2048)");
+    b->split_samples = segment_samples;
+    return 0;
+}
+
+int r433_batch_split_stats(r433_batch *b, uint32_t *segments, uint32_t *pieces_rerun)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    if (segments)
+        *segments = b->last_segments;
+    if (pieces_rerun)
+        *pieces_rerun = b->last_redone;
     return 0;
 }
 
@@ -600,9 +633,93 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
                 hipMemcpyHostToDevice, st));
         d_min_high = b->d_frame_min_high.p;
     }
+    // ---- plan: one wavefront per capture, or several per long capture (speculative cuts) ----
+    std::vector<SegDesc> segs;
+    std::vector<uint32_t> seg_first_of(n_streams + 1, 0); // segs of capture c: [seg_first_of[c], seg_first_of[c+1])
+    std::vector<uint32_t> cap_n(n_streams);
+    for (uint32_t c = 0; c < n_streams; ++c)
+        cap_n[c] = (stream_bytes ? stream_bytes[c] : (uint32_t)stride_bytes) / ss;
+    bool const split = b->split_samples > 0;
+    uint32_t max_seg_samples = max_samples;
+    if (split) {
+        constexpr uint32_t kTileS = 2048;
+        uint32_t const tiles_cap = max_samples / kTileS + 1;
+        if ((rc = b->d_tile_max.ensure((size_t)n_streams * tiles_cap)) || (rc = b->h_tile_max.ensure((size_t)n_streams * tiles_cap)))
+            return rc;
+        int const kind = ss == 4 ? ENV_MAG_CS16 : b->cfg.use_mag_est ? ENV_MAG_CU8 : ENV_AMP_CU8;
+        launch_tile_max(kind, d_iq, stride_bytes, stream_bytes ? b->d_stream_bytes.p : nullptr, (uint32_t)stride_bytes, n_streams,
+                tiles_cap, b->d_tile_max.p, st);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(b->h_tile_max.p, b->d_tile_max.p, (size_t)n_streams * tiles_cap * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        // a tile is quiet when nothing in it can hold a pulse up: below the falling-edge level of the
+        // lowest threshold the detector can have (pulse_detect.c:300-304 with low = -1, high = min_high)
+        int thr = (-1 + std::min(b->det.min_high, b->det.max_high)) / 2;
+        if (b->det.fixed_high)
+            thr = b->det.fixed_high;
+        uint32_t const quiet_below = (uint32_t)std::max(1, thr - thr / 8);
+        bool const blind = getenv("R433_SPLIT_BLIND") != nullptr; // tests: cut anywhere, let the verification sort it out
+        uint32_t const seg_len = (b->split_samples + kTileS - 1) / kTileS * kTileS;
+        // a package stays open until its last gap exceeds 10 pulse widths and 10 ms (pulse_detect.c:446-450):
+        // ask for 25 ms of quiet before a cut (the stitch catches the rest: at most 100 ms are ever needed)
+        uint32_t const quiet_tiles = std::max<uint32_t>(2u, (b->cfg.samp_rate / 40u + kTileS - 1) / kTileS);
+        max_seg_samples = 0;
+        for (uint32_t c = 0; c < n_streams; ++c) {
+            seg_first_of[c] = (uint32_t)segs.size();
+            uint32_t const n = cap_n[c];
+            uint32_t const *tm = b->h_tile_max.p + (size_t)c * tiles_cap;
+            std::vector<uint32_t> cuts;
+            uint32_t pos = seg_len;
+            while (n > seg_len && pos + seg_len / 2 < n) {
+                uint32_t cut = 0;
+                for (uint32_t P = pos; P < std::min(n, pos + seg_len) && P + kTileS <= n; P += kTileS) {
+                    bool quiet = P / kTileS >= quiet_tiles;
+                    for (uint32_t q = 1; quiet && q <= quiet_tiles; ++q)
+                        quiet = tm[P / kTileS - q] < quiet_below;
+                    if (blind || quiet) {
+                        cut = P;
+                        break;
+                    }
+                }
+                if (cut) {
+                    cuts.push_back(cut);
+                    pos = cut + seg_len;
+                }
+                else {
+                    pos += seg_len;
+                }
+            }
+            uint32_t from = 0;
+            for (size_t k = 0; k <= cuts.size(); ++k) {
+                uint32_t const to = k < cuts.size() ? cuts[k] : n;
+                uint32_t const last = k == cuts.size() ? SEG_LAST : 0u;
+                if (k == 0) {
+                    segs.push_back(SegDesc{c, 0u, to, SEG_FIRST | SEG_PRIMARY | last});
+                }
+                else { // both parities of the noise floor
+                    segs.push_back(SegDesc{c, from, to, SEG_PRIMARY | last});
+                    segs.push_back(SegDesc{c, from, to, SEG_ODD | last});
+                }
+                max_seg_samples = std::max(max_seg_samples, to - from + kTileS);
+                from = to;
+            }
+        }
+        seg_first_of[n_streams] = (uint32_t)segs.size();
+    }
+    uint32_t const n_planned = split ? (uint32_t)segs.size() : n_streams;
+    uint32_t const n_slots = split ? 3 * n_planned : n_streams; // + re-run slots for cuts that have to be dropped
+    if (split && b->arena_stride == want_stride) // sized for whole captures above: segments need less
+        b->arena_stride = std::max<uint32_t>(16384u, ((max_seg_samples + 4096u) + 15u) & ~15u);
+    if ((rc = b->d_ring.ensure((size_t)n_slots * R433_PD_MAX_PULSES)) || (rc = b->d_state.ensure(n_slots))
+            || (rc = b->d_pkg_base.ensure(n_slots)) || (rc = b->h_state.ensure(n_slots)) || (rc = b->d_order.ensure(n_slots))
+            || (rc = b->d_segs.ensure(n_slots)))
+        return rc;
+
     uint32_t total_pkgs = 0;
+    uint32_t n_order = n_streams;
+    std::vector<uint32_t> order;
     for (int attempt = 0;; ++attempt) {
-        if ((rc = b->d_arena.ensure((size_t)n_streams * b->arena_stride)))
+        if ((rc = b->d_arena.ensure((size_t)n_slots * b->arena_stride)))
             return rc;
         StreamParams sp;
         memset(&sp, 0, sizeof(sp));
@@ -610,7 +727,7 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
         sp.stride_bytes = stride_bytes;
         sp.stream_bytes = stream_bytes ? b->d_stream_bytes.p : nullptr;
         sp.uniform_bytes = (uint32_t)stride_bytes;
-        sp.n_streams = n_streams;
+        sp.n_streams = n_planned;
         sp.frame_samples = b->cfg.frame_samples;
         sp.flags = 0;
         if (char const *dbg = getenv("R433_DEBUG_FLAGS")) // phase timing experiments only (results are then incomplete)
@@ -633,12 +750,159 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
         sp.tap_am = (int16_t *)b->tap_am;
         sp.tap_fm = (int16_t *)b->tap_fm;
         sp.tap_stride = b->tap_stride;
-        HIP_TRY(hipMemsetAsync(b->d_frame_sums.p, 0, (size_t)n_streams * frames_cap * sizeof(uint32_t), st));
+        if (split) { // segments overlap in frames and may be re-run: the sums come from their own HBM-bound pass
+            sp.frame_sums = nullptr;
+            int const kind = ss == 4 ? ENV_MAG_CS16 : b->cfg.use_mag_est ? ENV_MAG_CU8 : ENV_AMP_CU8;
+            launch_frame_sums(kind, d_iq, stride_bytes, stream_bytes ? b->d_stream_bytes.p : nullptr, (uint32_t)stride_bytes, n_streams,
+                    b->cfg.frame_samples, frames_cap, b->d_frame_sums.p, st);
+        }
+        else {
+            HIP_TRY(hipMemsetAsync(b->d_frame_sums.p, 0, (size_t)n_streams * frames_cap * sizeof(uint32_t), st));
+        }
+        uint32_t const *d_order = nullptr;
+        b->last_segments = n_planned;
+        b->last_redone = 0;
+        if (split) {
+            HIP_TRY(hipMemcpyAsync(b->d_segs.p, segs.data(), segs.size() * sizeof(SegDesc), hipMemcpyHostToDevice, st));
+            sp.segs = b->d_segs.p;
+        }
         launch_stream(sp, ss, st);
         HIP_TRY(hipGetLastError());
+        if (split) {
+            // ---- stitch.  Per capture an ordered list of pieces; every piece but the first exists in two
+            // parity variants (two slots).  Walk the pieces in order; at each cut keep the variant that
+            // assumed exactly the floor the piece before it really ended with (and require that piece to
+            // have ended idle).  A cut that does not verify is dropped: the piece before it is run again
+            // through to the end of the next piece, and the walk resumes from there.  Every round
+            // removes at least one cut per capture that still has a problem, so this terminates.
+            struct Piece {
+                SegDesc seg;      // flags without SEG_ODD / SEG_PRIMARY
+                uint32_t slot[2]; // even / odd parity variant (the first piece of a capture: slot[0] only)
+            };
+            std::vector<std::vector<Piece>> pieces(n_streams);
+            for (uint32_t c = 0; c < n_streams; ++c)
+                for (uint32_t k = seg_first_of[c]; k < seg_first_of[c + 1]; k += (k == seg_first_of[c] ? 1 : 2)) {
+                    Piece pc;
+                    pc.seg = segs[k];
+                    pc.seg.flags &= ~(uint32_t)(SEG_ODD | SEG_PRIMARY);
+                    pc.slot[0] = k;
+                    pc.slot[1] = k == seg_first_of[c] ? k : k + 1;
+                    pieces[c].push_back(pc);
+                }
+            uint32_t n_have = n_planned; // slots whose state is on the host
+            std::vector<SegDesc> slot_seg(segs), launch_list;
+            auto new_slot = [&](SegDesc const &d) {
+                launch_list.push_back(d);
+                slot_seg.push_back(d);
+                return n_have + (uint32_t)launch_list.size() - 1;
+            };
+            auto run_launch_list = [&]() -> int {
+                if (launch_list.empty())
+                    return 0;
+                if (n_have + launch_list.size() > n_slots)
+                    return fail(R433_EHIP, "split bookkeeping ran out of slots");
+                b->last_redone += (uint32_t)launch_list.size();
+                HIP_TRY(hipMemcpyAsync(b->d_segs.p + n_have, launch_list.data(), launch_list.size() * sizeof(SegDesc), hipMemcpyHostToDevice, st));
+                StreamParams sr = sp;
+                sr.n_streams = (uint32_t)launch_list.size();
+                sr.segs = b->d_segs.p + n_have;
+                sr.arena = b->d_arena.p + (size_t)n_have * b->arena_stride;
+                sr.fsk_ring = b->d_ring.p + (size_t)n_have * R433_PD_MAX_PULSES;
+                sr.state = b->d_state.p + n_have;
+                launch_stream(sr, ss, st);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(b->h_state.p + n_have, b->d_state.p + n_have, launch_list.size() * sizeof(StreamState), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                n_have += (uint32_t)launch_list.size();
+                launch_list.clear();
+                return 0;
+            };
+            HIP_TRY(hipMemcpyAsync(b->h_state.p, b->d_state.p, (size_t)n_planned * sizeof(StreamState), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            // (1) cuts neither variant could start from (no provable filter carry or floor: digital
+            // silence does that) are known now, all at once: merge across them in one extra launch
+            for (uint32_t c = 0; c < n_streams; ++c) {
+                std::vector<Piece> merged;
+                for (Piece const &pc : pieces[c]) {
+                    bool const unstartable = !merged.empty() && b->h_state.p[pc.slot[0]].seg_fail && b->h_state.p[pc.slot[1]].seg_fail;
+                    if (!unstartable) {
+                        merged.push_back(pc);
+                        continue;
+                    }
+                    Piece &m = merged.back();
+                    m.seg.end = pc.seg.end;
+                    m.seg.flags |= pc.seg.flags & SEG_LAST;
+                    m.slot[0] = m.slot[1] = UINT32_MAX; // to be run again
+                }
+                for (Piece &m : merged)
+                    if (m.slot[0] == UINT32_MAX) {
+                        SegDesc d = m.seg;
+                        d.flags |= SEG_PRIMARY;
+                        m.slot[0] = new_slot(d);
+                        m.slot[1] = m.slot[0];
+                        if (!(d.flags & SEG_FIRST)) {
+                            d.flags = (d.flags & ~(uint32_t)SEG_PRIMARY) | SEG_ODD;
+                            m.slot[1] = new_slot(d);
+                        }
+                    }
+                pieces[c].swap(merged);
+            }
+            if ((rc = run_launch_list()))
+                return rc;
+            // (2) the walk proper
+            std::vector<std::vector<uint32_t>> chosen(n_streams);
+            std::vector<size_t> at(n_streams, 1);
+            std::vector<uint32_t> dropped(n_streams, 0);
+            for (uint32_t c = 0; c < n_streams; ++c)
+                chosen[c].push_back(pieces[c][0].slot[0]);
+            for (;;) {
+                for (uint32_t c = 0; c < n_streams; ++c) {
+                    std::vector<Piece> &pcs = pieces[c];
+                    while (at[c] < pcs.size()) {
+                        uint32_t const cur = chosen[c].back();
+                        StreamState const &P = b->h_state.p[cur];
+                        Piece const &nx = pcs[at[c]];
+                        uint32_t pick = UINT32_MAX;
+                        if (P.seg_end_state == ST_IDLE && P.seg_end_lead == 1025)
+                            for (int v = 0; v < 2; ++v)
+                                if (!b->h_state.p[nx.slot[v]].seg_fail && b->h_state.p[nx.slot[v]].seg_init_low == P.seg_end_low)
+                                    pick = nx.slot[v];
+                        if (pick != UINT32_MAX) {
+                            chosen[c].push_back(pick);
+                            at[c] += 1;
+                            dropped[c] = 0;
+                            continue;
+                        }
+                        // drop this cut: the standing piece continues through the next one.  (Three cuts in a
+                        // row that fail are not worth a fourth try: the piece then runs to the capture's end.)
+                        bool const give_up = ++dropped[c] >= 3;
+                        if (getenv("R433_SPLIT_DEBUG"))
+                            fprintf(stderr, "split: capture %u cut at %u dropped (end state %d, floor %d vs %d/%d, fail %d/%d)\n", c, nx.seg.start,
+                                    P.seg_end_state, P.seg_end_low, b->h_state.p[nx.slot[0]].seg_init_low, b->h_state.p[nx.slot[1]].seg_init_low,
+                                    b->h_state.p[nx.slot[0]].seg_fail, b->h_state.p[nx.slot[1]].seg_fail);
+                        SegDesc d = slot_seg[cur];
+                        d.end = give_up ? cap_n[c] : nx.seg.end;
+                        d.flags = (d.flags & ~(uint32_t)SEG_LAST) | (give_up ? (uint32_t)SEG_LAST : (nx.seg.flags & SEG_LAST));
+                        chosen[c].back() = new_slot(d);
+                        at[c] = give_up ? pcs.size() : at[c] + 1;
+                        break; // its end state is not known yet: resume in the next round
+                    }
+                }
+                if (launch_list.empty())
+                    break;
+                if ((rc = run_launch_list()))
+                    return rc;
+            }
+            order.clear();
+            for (uint32_t c = 0; c < n_streams; ++c)
+                order.insert(order.end(), chosen[c].begin(), chosen[c].end());
+            n_order = (uint32_t)order.size();
+            HIP_TRY(hipMemcpyAsync(b->d_order.p, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            d_order = b->d_order.p;
+        }
         if (b->profiling && attempt == 0)
             HIP_TRY(hipEventRecord(b->ev[1], st));
-        launch_pkg_scan(b->d_state.p, n_streams, b->d_pkg_base.p, b->d_scal.p, st);
+        launch_pkg_scan(b->d_state.p, d_order, n_order, b->d_pkg_base.p, b->d_scal.p, st);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(b->h_scal.p, b->d_scal.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -661,8 +925,8 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
             || (rc = b->d_sizes.ensure((size_t)max_pkgs * std::max<uint32_t>(n_devs, 1))))
         return rc;
 
-    launch_directory(b->d_arena.p, b->arena_stride, b->d_state.p, n_streams, b->d_pkg_base.p, b->d_dir_stream.p,
-            b->d_dir_off.p, b->d_rec_bytes.p, max_pkgs, st);
+    launch_directory(b->d_arena.p, b->arena_stride, b->d_state.p, split ? b->d_order.p : nullptr, n_order, b->d_pkg_base.p,
+            b->d_dir_stream.p, b->d_dir_off.p, b->d_rec_bytes.p, max_pkgs, st);
     launch_scan_u32(b->d_rec_bytes.p, b->d_rec_off.p, b->d_scal.p, max_pkgs, b->d_scal.p + 2, st);
     HIP_TRY(hipGetLastError());
     if (b->profiling)

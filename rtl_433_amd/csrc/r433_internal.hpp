@@ -28,6 +28,31 @@ struct StreamState {
     uint32_t cursor;
     uint32_t n_pkgs;
     uint32_t overflow;
+    // what a segment of a split capture reports for the stitch (SegDesc below)
+    int seg_init_low;  // noise floor it assumed at its first sample (its parity variant)
+    int seg_fail;      // its start could not be established (filter carry or floor not provable)
+    int seg_end_state; // detector state, lead-in counter and noise floor after its last sample
+    int seg_end_lead;
+    int seg_end_low;
+};
+
+// A capture processed by several wavefronts.  Cuts are speculative: a segment that does not start the
+// capture assumes the detector idle at its first sample (lead-in saturated, nothing open), takes the
+// filter carries from an all-extremes pass over the tile before it and the noise floor from the last
+// 128 samples of that tile walked from both extremes of ONE assumed parity.  Both parities are run;
+// the host keeps the variant whose assumed floor equals the floor the previous segment really ended
+// with (and requires that segment to have ended idle) -- otherwise the capture is redone in one piece.
+struct SegDesc {
+    uint32_t capture;  // index of the capture (arena records carry it)
+    uint32_t start;    // first sample, a multiple of the tile; > 0 unless SEG_FIRST
+    uint32_t end;      // one past the last sample: a multiple of the tile or the capture length
+    uint32_t flags;
+};
+enum : uint32_t {
+    SEG_FIRST = 1u,   // starts the capture: reset state, no assumptions
+    SEG_LAST = 2u,    // ends the capture: end-of-input flush
+    SEG_ODD = 4u,     // assumed parity of the noise floor at `start`
+    SEG_PRIMARY = 8u, // the variant that also delivers frame sums and taps
 };
 
 enum : uint32_t {
@@ -55,6 +80,7 @@ struct StreamParams {
     uint8_t *arena;               // n_streams * arena_stride bytes
     uint32_t arena_stride;
     int2 *fsk_ring;               // n_streams * 1200 pairs
+    SegDesc const *segs;          // n_streams segments (nullptr: one whole capture per wavefront)
     StreamState *state;           // n_streams
     uint32_t *frame_sums;         // n_streams * frames_cap (may be null)
     uint32_t frames_cap;
@@ -99,12 +125,15 @@ struct SliceParams {
     uint32_t max_pkgs;
 };
 
+// `order` (may be null = identity) lists the wavefront slots (whole captures or the chosen segments of split
+// captures) in canonical order; n = its length.
 // scal[0] = total packages, scal[1] = any arena overflow
-void launch_pkg_scan(StreamState const *state, uint32_t n_streams, uint32_t *pkg_base, uint32_t *scal, hipStream_t st);
-// fills dir_stream/dir_off/rec_bytes for every package (canonical order)
-void launch_directory(uint8_t const *arena, uint32_t arena_stride, StreamState const *state, uint32_t n_streams,
-        uint32_t const *pkg_base, uint32_t *dir_stream, uint32_t *dir_off, uint32_t *rec_bytes, uint32_t max_pkgs,
+void launch_pkg_scan(StreamState const *state, uint32_t const *order, uint32_t n, uint32_t *pkg_base, uint32_t *scal,
         hipStream_t st);
+// fills dir_stream (arena slot) / dir_off / rec_bytes for every package (canonical order)
+void launch_directory(uint8_t const *arena, uint32_t arena_stride, StreamState const *state, uint32_t const *order,
+        uint32_t n, uint32_t const *pkg_base, uint32_t *dir_stream, uint32_t *dir_off, uint32_t *rec_bytes,
+        uint32_t max_pkgs, hipStream_t st);
 // out[i] = sum(in[0..i)), *total = sum(in[0..n)), n = min(*n_ptr, n_cap); single block
 void launch_scan_u32(uint32_t const *in, uint32_t *out, uint32_t const *n_ptr, uint32_t n_cap, uint32_t *total,
         hipStream_t st);
@@ -117,6 +146,8 @@ void launch_slice_write(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st
 
 // ---- function-level baseband kernels (device pointers) ----
 enum { ENV_AMP_CU8 = 0, ENV_MAG_CU8 = 1, ENV_MAG_CS16 = 2 };
+void launch_tile_max(int kind, void const *d_iq, uint64_t stride_bytes, uint32_t const *stream_bytes, uint32_t uniform_bytes,
+        uint32_t n_streams, uint32_t tiles_cap, uint32_t *tile_max, hipStream_t st);
 void launch_frame_sums(int kind, void const *d_iq, uint64_t stride_bytes, uint32_t const *stream_bytes, uint32_t uniform_bytes,
         uint32_t n_streams, uint32_t frame_samples, uint32_t frames_cap, uint32_t *sums, hipStream_t st);
 void launch_envelope(int kind, void const *d_iq, uint16_t *d_env, uint32_t n, uint32_t *d_sum, hipStream_t st);

@@ -43,6 +43,7 @@ constexpr int kRow = 512;           // samples per phase-A row (8 per lane)
 constexpr int kRows = kTile / kRow;
 constexpr int kPitch16 = kChunk * 2 + 16;  // LDS pitch of a chunk of 16-bit samples: conflict-free b128 per lane
 constexpr int kPitch32 = kChunk * 4 + 16;
+constexpr int kFloorWindow = 512;           // samples a later segment of a split capture walks to find its noise floor
 constexpr int kPitchOut = kChunk * 2;       // filtered samples: time-linear, read by sample index (the padded pitch buys
                                              // nothing there and 8 wavefronts' LDS must fit one CU: 8 x 20 KB = 160 KB)
 
@@ -175,12 +176,21 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
     __shared__ int s_cmax[64], s_cmin[64];
 
     int const lane = (int)threadIdx.x;
-    uint32_t const s = blockIdx.x;
-    uint32_t const my_bytes = p.stream_bytes ? p.stream_bytes[s] : p.uniform_bytes;
+    uint32_t const s = blockIdx.x; // wavefront = one capture, or one segment of a split capture
+    uint32_t const cap = p.segs ? p.segs[s].capture : s;
+    uint32_t const my_bytes = p.stream_bytes ? p.stream_bytes[cap] : p.uniform_bytes;
     uint32_t const my_n = my_bytes / SS;
     uint32_t const n_tiles = (my_n + kTile - 1) / kTile;
-    uint8_t const *const iq = p.iq + (uint64_t)s * p.stride_bytes;
+    uint8_t const *const iq = p.iq + (uint64_t)cap * p.stride_bytes;
     uint32_t const F = p.frame_samples;
+    uint32_t const seg_flags = p.segs ? p.segs[s].flags : (SEG_FIRST | SEG_LAST | SEG_PRIMARY);
+    uint32_t const seg_start = p.segs ? p.segs[s].start : 0u;
+    uint32_t const seg_end = p.segs ? min(p.segs[s].end, my_n) : my_n;
+    bool const seg_first = (seg_flags & SEG_FIRST) != 0, seg_primary = (seg_flags & SEG_PRIMARY) != 0;
+    // a later segment starts one tile early: that tile only establishes the filter carries and the floor
+    uint32_t const tile_first = seg_first ? 0u : seg_start / kTile - 1u;
+    uint32_t const tile_end = (seg_end + kTile - 1) / kTile;
+    int seg_fail = 0, seg_init_low = 0;
 
     // ---- detector: wave-uniform.  Every lane carries the same scalar state and takes the same
     // branches, in the fast paths and in the general step alike; lane 0 alone touches the arena and
@@ -191,14 +201,19 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
     det.arena = p.arena + (uint64_t)s * p.arena_stride;
     det.fsk_ring = p.fsk_ring + (uint64_t)s * R433_PD_MAX_PULSES; // HBM scratch, touched by lane 0 on FSK pulses only
     det.arena_cap = p.arena_stride;
-    det.stream = s;
+    det.stream = cap;
     det.writer = lane == 0;
     det.cursor = 0;
     det.n_pkgs = 0;
     det.overflow = 0;
-    uint64_t input_pos = 0;
-    uint32_t frame = 0;
-    int dc = 0, flen = 0;
+    uint32_t frame = seg_start / F;
+    uint64_t input_pos = (uint64_t)frame * F;
+    int dc = (int)(seg_start - frame * F);
+    int flen = (int)min(my_n - frame * F, F); // only meaningful when the segment starts inside a frame
+    if (!seg_first)
+        det.lead_in = 1025; // saturated for good after the first 1025 idle samples of a capture
+    if (p.frame_min_high) // -Y autolevel: the level of the frame the segment starts in
+        cfg.min_high = p.frame_min_high[(uint64_t)cap * p.frames_cap + min(frame, p.frames_cap - 1)];
 
     // ---- filter carries across tiles (wave-uniform) ----
     int carry_ya = 0, carry_xa = 0; // AM low-pass: y[-1], x[-1]
@@ -222,11 +237,12 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
             pf[k] = v;
         }
     };
-    issue_loads(0);
+    issue_loads(tile_first);
 
-    for (uint32_t tile = 0; tile < n_tiles; ++tile) {
-        uint32_t const t0 = tile * kTile;                     // absolute sample index of the tile
-        int const n_t = (int)min((uint32_t)kTile, my_n - t0); // valid samples in it
+    for (uint32_t tile = tile_first; tile < tile_end; ++tile) {
+        uint32_t const t0 = tile * kTile;                        // absolute sample index of the tile
+        int const n_t = (int)min((uint32_t)kTile, seg_end - t0); // valid samples in it
+        bool const warm = !seg_first && tile == tile_first;      // the establishing tile of a later segment
 
         // ================= phase A: envelope + discriminator, 8 samples per lane and row =================
         long long const t_tile = now();
@@ -319,8 +335,8 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     int idx = r * kRow + lane * 8 + j;
-                    if (idx < n_t)
-                        p.tap_env[(uint64_t)s * p.tap_stride + t0 + (uint32_t)idx] = (uint16_t)ev[j];
+                    if (idx < n_t && seg_primary && !warm)
+                        p.tap_env[(uint64_t)cap * p.tap_stride + t0 + (uint32_t)idx] = (uint16_t)ev[j];
                 }
             }
         }
@@ -333,7 +349,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
         int const cs = lane * kChunk;                       // chunk start inside the tile
         int const cnt = max(0, min(kChunk, n_t - cs));      // valid samples of my chunk
         int const first = max(0, lane - kWarmChunks);       // first chunk I read
-        bool const from_carry = lane <= kWarmChunks;        // my warm-up reaches the tile start: exact carry
+        bool const from_carry = lane <= kWarmChunks && !warm; // my warm-up reaches the tile start: exact carry
         // chunks at which a frame (= a push_sdr_flow call) starts
         unsigned long long const fs_mask = __ballot((t0 + (uint32_t)cs) % F == 0);
         Track16<FAST> ta, tf16;
@@ -350,9 +366,12 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
             ta.lo = -32768, ta.hi = 32767;
             tf16.lo = -32768, tf16.hi = 32767;
             tf32.lo = INT32_MIN, tf32.hi = INT32_MAX;
-            xa1 = (int)*(uint16_t const *)(s_env + (first - 1) * kPitch16 + (kChunk - 1) * 2);
-            ff1 = SS == 2 ? (int)*(int16_t const *)(s_f + (first - 1) * G::f_pitch + (kChunk - 1) * 2)
-                          : *(int const *)(s_f + (first - 1) * G::f_pitch + (kChunk - 1) * 4);
+            xa1 = ff1 = 0; // lanes 0..2 of an establishing tile have no history at all: never proven, never used
+            if (first > 0) {
+                xa1 = (int)*(uint16_t const *)(s_env + (first - 1) * kPitch16 + (kChunk - 1) * 2);
+                ff1 = SS == 2 ? (int)*(int16_t const *)(s_f + (first - 1) * G::f_pitch + (kChunk - 1) * 2)
+                              : *(int const *)(s_f + (first - 1) * G::f_pitch + (kChunk - 1) * 4);
+            }
         }
         ta.ok = tf16.ok = tf32.ok = 1;
 
@@ -470,6 +489,10 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
             sa.start_known = sf.start_known = true;
             sa.end_known = sf.end_known = false;
         }
+        if (warm && lane < kWarmChunks) { // no history: take what the tracks say, proven or not, and never wait for it
+            sa.start_known = sf.start_known = true;
+            sa.ident = sf.ident = 0;
+        }
         // the fixed-point argument needs a feedback coefficient in [0, 1]: monotone map, slope <= 1
         sa.ident &= ta.ok;
         sf.ident &= SS == 2 ? (tf16.ok & (int)(p.a16 >= 0 && p.a16 <= 16384)) : (tf32.ok & (int)(p.a32 >= 0 && p.a32 <= (1ll << 30)));
@@ -484,8 +507,11 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                 unsigned long long const open = __ballot(!st.start_known);
                 if (!open)
                     break;
-                if (round > 64) { // cannot happen (the first open lane settles every round); never spin on the GPU
-                    det.overflow = 2;
+                if (round > 64) { // cannot happen in a regular tile (the first open lane settles every round)
+                    if (warm)
+                        seg_fail = 1; // a stall reaching back past the establishing tile: the carry is not provable here
+                    else
+                        det.overflow = 2;
                     break;
                 }
                 // What does the carry look like when it leaves each lane?  CONST(y_end) where the end is
@@ -590,21 +616,59 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
         s_cmax[lane] = cmax;
         s_cmin[lane] = cmin;
 
+        if (warm) {
+            // ---- establishing tile of a later segment: no detection here.  The carries just taken must be
+            // proven, and so must the last sixteen chunks (the floor is walked over their samples).
+            bool const tail_ok = lane < 64 - kFloorWindow / kChunk || (sa.start_known && sa.end_known && sf.start_known && sf.end_known);
+            if (__ballot(!tail_ok))
+                seg_fail = 1;
+            __syncthreads();
+            // Noise floor at the segment's first sample: the detector is assumed idle over the last 512
+            // samples with a floor of the assumed parity somewhere inside the tile's sample range; both
+            // extremes of that parity are walked and must meet (see the lazy floor below).
+            int rmax = lane >= 4 ? cmax : -0x7fffffff, rmin = lane >= 4 ? cmin : 0x7fffffff;
+            for (int o = 32; o > 0; o >>= 1) {
+                rmax = max(rmax, __shfl_xor(rmax, o, 64));
+                rmin = min(rmin, __shfl_xor(rmin, o, 64));
+            }
+            int const par = (seg_flags & SEG_ODD) ? 1 : 0;
+            int a = rmin - 1, b = rmax + 1;
+            if (b - a >= 1000)
+                seg_fail = 1; // steps of more than one are possible: not the regime the cut assumes
+            a += (a ^ par) & 1;
+            b -= (b ^ par) & 1;
+            for (int w = kTile - kFloorWindow; w < kTile; w += 64) { // chunks 48..63: proven above
+                int const v = ld16(s_am, w + lane);
+#pragma unroll 8
+                for (int u = 0; u < 64; ++u) {
+                    int const x = __builtin_amdgcn_readlane(v, u);
+                    a += x > a ? 1 : -1;
+                    b += x > b ? 1 : -1;
+                }
+            }
+            if (a != b)
+                seg_fail = 1;
+            det.low = a;
+            det.high = max(cfg.ratio * a, cfg.min_high);
+            seg_init_low = a;
+            continue;
+        }
+
         // per-frame envelope sums (u32, wraps like the reference's accumulator, baseband.c:39-44)
-        if (p.frame_sums) {
+        if (p.frame_sums && seg_primary) {
             uint32_t const f_first = t0 / F, f_last = (t0 + (uint32_t)n_t - 1) / F;
             uint32_t const my_frame = (t0 + (uint32_t)cs) / F;
             for (uint32_t f = f_first; f <= f_last; ++f) {
                 int const part = wave_sum(cnt > 0 && my_frame == f ? csum : 0);
-                if (lane == 0 && f < p.frames_cap)
-                    p.frame_sums[(uint64_t)s * p.frames_cap + f] += (uint32_t)part;
+                if (lane == 0 && f < p.frames_cap) // several segments of a capture may share a frame
+                    atomicAdd(&p.frame_sums[(uint64_t)cap * p.frames_cap + f], (uint32_t)part);
             }
         }
         __syncthreads();
 
-        if (p.tap_am) {
+        if (p.tap_am && seg_primary) {
             for (int idx = lane; idx < n_t; idx += 64) {
-                uint64_t o = (uint64_t)s * p.tap_stride + t0 + (uint32_t)idx;
+                uint64_t o = (uint64_t)cap * p.tap_stride + t0 + (uint32_t)idx;
                 p.tap_am[o] = (int16_t)ld16(s_am, idx);
                 p.tap_fm[o] = (int16_t)ld16(s_fm, idx);
             }
@@ -687,7 +751,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
             if (dc == 0) { // a new frame == a new push_sdr_flow call
                 flen = (int)min(my_n - (t0 + (uint32_t)i), F);
                 if (p.frame_min_high) // pulse_detect_set_levels before this frame's detection, r_flow.c:180-186
-                    cfg.min_high = uni(p.frame_min_high[(uint64_t)s * p.frames_cap + min(frame, p.frames_cap - 1)]);
+                    cfg.min_high = uni(p.frame_min_high[(uint64_t)cap * p.frames_cap + min(frame, p.frames_cap - 1)]);
                 det_call_entry(det, cfg, flen, 0);
             }
             // Every lane holds the same values here, but they have been through per-lane-looking code
@@ -976,10 +1040,16 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
         tk[6] += now() - t_res; // the samples leave LDS with the tile
     }
 
-    if (!(p.flags & RUN_NOFLUSH))
+    int const end_state = det.state; // before the flush: what the next segment has to agree with
+    if (!(p.flags & RUN_NOFLUSH) && (seg_flags & SEG_LAST))
         det_flush(det, cfg, frame);
     if (lane == 0) {
         StreamState &S = p.state[s];
+        S.seg_init_low = seg_init_low;
+        S.seg_fail = seg_fail;
+        S.seg_end_state = end_state;
+        S.seg_end_lead = det.lead_in;
+        S.seg_end_low = det.low;
         S.cursor = det.cursor;
         S.n_pkgs = det.n_pkgs;
         S.overflow = det.overflow;
@@ -994,8 +1064,8 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
 
 // ---- package directory: canonical (capture, detection order) numbering ----
 
-__global__ __launch_bounds__(1024) void k_pkg_scan(StreamState const *state, uint32_t n_streams, uint32_t *pkg_base,
-        uint32_t *scal)
+__global__ __launch_bounds__(1024) void k_pkg_scan(StreamState const *state, uint32_t const *order, uint32_t n_streams,
+        uint32_t *pkg_base, uint32_t *scal)
 {
     __shared__ uint32_t part[1024];
     __shared__ uint32_t carry;
@@ -1008,8 +1078,9 @@ __global__ __launch_bounds__(1024) void k_pkg_scan(StreamState const *state, uin
     __syncthreads();
     for (uint32_t base = 0; base < n_streams; base += 1024) {
         uint32_t i = base + (uint32_t)tid;
-        uint32_t v = i < n_streams ? state[i].n_pkgs : 0u;
-        if (i < n_streams && state[i].overflow)
+        uint32_t const slot = i < n_streams ? (order ? order[i] : i) : 0u;
+        uint32_t v = i < n_streams ? state[slot].n_pkgs : 0u;
+        if (i < n_streams && state[slot].overflow)
             any_overflow = 1;
         part[tid] = v;
         __syncthreads();
@@ -1033,17 +1104,18 @@ __global__ __launch_bounds__(1024) void k_pkg_scan(StreamState const *state, uin
 }
 
 __global__ __launch_bounds__(256) void k_pkg_directory(uint8_t const *arena, uint32_t arena_stride,
-        StreamState const *state, uint32_t n_streams, uint32_t const *pkg_base, uint32_t *dir_stream,
-        uint32_t *dir_off, uint32_t *rec_bytes, uint32_t max_pkgs)
+        StreamState const *state, uint32_t const *order, uint32_t n_streams, uint32_t const *pkg_base,
+        uint32_t *dir_stream, uint32_t *dir_off, uint32_t *rec_bytes, uint32_t max_pkgs)
 {
-    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_streams)
+    uint32_t const k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_streams)
         return;
+    uint32_t const s = order ? order[k] : k; // arena slot
     uint32_t n = state[s].n_pkgs;
     uint32_t at = 0;
     uint8_t const *a = arena + (uint64_t)s * arena_stride;
     for (uint32_t i = 0; i < n; ++i) {
-        uint32_t g = pkg_base[s] + i;
+        uint32_t g = pkg_base[k] + i;
         uint32_t sz = *(uint32_t const *)(a + at);
         if (g < max_pkgs) {
             dir_stream[g] = s;
@@ -1107,17 +1179,18 @@ void launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st)
 #undef R433_LAUNCH_WAVE
 }
 
-void launch_pkg_scan(StreamState const *state, uint32_t n_streams, uint32_t *pkg_base, uint32_t *scal, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_pkg_scan, dim3(1), dim3(1024), 0, st, state, n_streams, pkg_base, scal);
-}
-
-void launch_directory(uint8_t const *arena, uint32_t arena_stride, StreamState const *state, uint32_t n_streams,
-        uint32_t const *pkg_base, uint32_t *dir_stream, uint32_t *dir_off, uint32_t *rec_bytes, uint32_t max_pkgs,
+void launch_pkg_scan(StreamState const *state, uint32_t const *order, uint32_t n, uint32_t *pkg_base, uint32_t *scal,
         hipStream_t st)
 {
-    hipLaunchKernelGGL(k_pkg_directory, dim3((n_streams + 255) / 256), dim3(256), 0, st, arena, arena_stride, state,
-            n_streams, pkg_base, dir_stream, dir_off, rec_bytes, max_pkgs);
+    hipLaunchKernelGGL(k_pkg_scan, dim3(1), dim3(1024), 0, st, state, order, n, pkg_base, scal);
+}
+
+void launch_directory(uint8_t const *arena, uint32_t arena_stride, StreamState const *state, uint32_t const *order,
+        uint32_t n, uint32_t const *pkg_base, uint32_t *dir_stream, uint32_t *dir_off, uint32_t *rec_bytes,
+        uint32_t max_pkgs, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pkg_directory, dim3((n + 255) / 256), dim3(256), 0, st, arena, arena_stride, state, order, n,
+            pkg_base, dir_stream, dir_off, rec_bytes, max_pkgs);
 }
 
 void launch_gather_packages(uint8_t const *arena, uint32_t arena_stride, uint32_t const *dir_stream,

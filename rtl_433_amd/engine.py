@@ -95,6 +95,15 @@ class BatchEngine:
         rc = self.L.r433_batch_run(self.h, C.c_void_p(iq.data_ptr()), stride, sb, n_streams, C.c_void_p(st))
         return _lib.check(rc, "r433_batch_run", self.L)
 
+    def set_split(self, segment_samples):
+        """Cut captures longer than segment_samples into independently processed, verified segments."""
+        _lib.check(self.L.r433_batch_set_split(self.h, int(segment_samples)), "r433_batch_set_split", self.L)
+
+    def split_stats(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        _lib.check(self.L.r433_batch_split_stats(self.h, C.byref(a), C.byref(b)), "r433_batch_split_stats", self.L)
+        return dict(segments=a.value, pieces_rerun=b.value)
+
     def enable_taps(self, n_streams, n_samples):
         import torch
         env = torch.zeros((n_streams, n_samples), dtype=torch.int16, device="cuda")  # u16 payload

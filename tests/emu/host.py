@@ -21,7 +21,7 @@ def emu_lib():
     return _emu
 
 
-def emu_run(iq_list, ss, rate, devs, fpdm=0, taps=False, enable_fm=1, center_frequency=433920000, **kw):
+def emu_run(iq_list, ss, rate, devs, fpdm=0, taps=False, enable_fm=1, center_frequency=433920000, split=0, **kw):
     """Same contract as tests/test_gpu_parity._gpu_run, on the emulator."""
     n = len(iq_list)
     lens = np.array([a.nbytes for a in iq_list], dtype=np.uint32)
@@ -35,13 +35,15 @@ def emu_run(iq_list, ss, rate, devs, fpdm=0, taps=False, enable_fm=1, center_fre
         arena[i, :a.nbytes] = a.view(np.uint8)
     cfg = flow_cfg(ss, rate, fpdm=fpdm, enable_fm=enable_fm, center_frequency=center_frequency, **kw)
     eng = BatchEngine(cfg, devs, profiling=False, library=emu_lib())
+    if split:
+        eng.set_split(split)
     tap_bufs = None
     if taps:
         ns = max(1, stride // ss)
         tap_bufs = [np.zeros((n, ns), dtype=np.uint16), np.zeros((n, ns), dtype=np.int16), np.zeros((n, ns), dtype=np.int16)]
         _lib.check(eng.L.r433_batch_set_taps(eng.h, *[C.c_void_p(t.ctypes.data) for t in tap_bufs], ns), "set_taps")
     npk = eng.run_ptr(arena.ctypes.data, stride, n, lens)
-    out = dict(n_packages=npk, packages=eng.packages(), events=eng.events(), sums=eng.frame_sums(n))
+    out = dict(n_packages=npk, packages=eng.packages(), events=eng.events(), sums=eng.frame_sums(n), split=eng.split_stats())
     if taps:
         out["taps"] = tuple(tap_bufs)
     eng.close()

@@ -174,3 +174,36 @@ def test_mixed_2000k_autolevel_filter(default_devices):
     o = po.oracle_flow(iq, devs, po.default_flow_cfg(2, rate, fpdm=0, **kw))
     g = _gpu_run([iq], 2, rate, 433920000, devs, **kw)
     assert g["packages"][0] == o["packages"] and g["events"][0] == o["events"]
+
+
+@pytest.mark.parametrize("blind", [False, True])
+def test_split_captures(blind, default_devices, monkeypatch):
+    """Several wavefronts per capture (r433_batch_set_split): byte-identical to the oracle whatever the cuts."""
+    import torch
+    from rtl_433_amd.engine import BatchEngine, flow_cfg
+    from tests.test_split import long_capture
+    from rtl_433_amd import synth
+    devs = default_devices[0]
+    caps = [long_capture(11, n_bursts=20), long_capture(12, sigma=1.0), long_capture(13, sigma=0.0), synth.noise_cu8(15, 400000, 3.0)]
+    if blind:
+        monkeypatch.setenv("R433_SPLIT_BLIND", "1")
+    lens = np.array([a.nbytes for a in caps], dtype=np.uint32)
+    stride = int((lens.max() + 15) // 16 * 16)
+    host = np.zeros((len(caps), stride), dtype=np.uint8)
+    for i, a in enumerate(caps):
+        host[i, :a.nbytes] = a
+    eng = BatchEngine(flow_cfg(2, 250000), devs)
+    eng.set_split(16384)
+    eng.run(torch.from_numpy(host).cuda(), lens)
+    st = eng.split_stats()
+    pk, ev = eng.packages()[0], eng.events()[0]
+    eng.close()
+    cfg = po.default_flow_cfg(2, 250000)
+    pk_o, ev_o, base = b"", b"", 0
+    for s, a in enumerate(caps):
+        o = po.oracle_flow(a, devs, cfg, stream_index=s, pkg_base=base)
+        pk_o += o["packages"]
+        ev_o += o["events"]
+        base += o["n_packages"]
+    assert st["segments"] > 50
+    assert pk == pk_o and ev == ev_o
