@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--samples", type=int, default=65536, help="samples per capture")
     ap.add_argument("--threads", type=int, default=0, help="host dispatch threads per rank (0 = auto)")
     ap.add_argument("--engines", type=int, default=3, help="batch engines in the software pipeline (>= 2)")
+    ap.add_argument("--split", type=int, default=0, help="r433_batch_set_split segment length in samples (0 = one wavefront per capture)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -133,6 +134,9 @@ def main():
     from rtl_433_amd import shard
     n_eng = max(2, args.engines)
     engines = [eng] + [BatchEngine(flow_cfg(2, 250000), devs, profiling=True) for _ in range(n_eng - 1)]
+    if args.split:
+        for e in engines:
+            e.set_split(args.split)
     streams = [torch.cuda.Stream() for _ in range(n_eng)]
     gpu_threads = ThreadPoolExecutor(n_eng - 1)
     dev = torch.device("cuda", local_rank)

@@ -87,11 +87,13 @@ int r433_batch_device_events(r433_batch *b, void const **d_events, size_t *len);
 int r433_batch_set_taps(r433_batch *b, void *d_env, void *d_am, void *d_fm, uint64_t tap_stride);
 
 /* Long captures: let several wavefronts work on one capture.  A capture longer than segment_samples is cut
- * about every segment_samples where the signal looks idle (0 = never, the default).  Cuts are speculative
+ * about every segment_samples where the signal looks idle.  0 = never; R433_SPLIT_AUTO (the default) = only for
+ * batches of at most 64 captures with one of at least 2^20 samples, aiming at ~4096 segments of >= 65536 samples.  Cuts are speculative
  * and verified: every later segment is run for both parities of the noise-floor estimate and kept only if the
  * segment before it really ended idle with exactly the floor it assumed; a cut that does not verify is
  * dropped and the piece before it is run again across it, so results never depend on this setting.  There is no reference
  * counterpart: the reference walks a file sample by sample (src/rtl_433.c:1826-1845). */
+#define R433_SPLIT_AUTO 1u
 int r433_batch_set_split(r433_batch *b, uint32_t segment_samples);
 /* of the last run: wavefront slots planned (segments incl. parity variants), pieces run again after a dropped cut */
 int r433_batch_split_stats(r433_batch *b, uint32_t *segments, uint32_t *pieces_rerun);

@@ -290,7 +290,7 @@ struct r433_batch {
     DevBuf<int> d_frame_min_high;
     std::vector<int> h_frame_min_high;
     // split captures (r433_batch_set_split)
-    uint32_t split_samples = 0;
+    uint32_t split_samples = R433_SPLIT_AUTO;
     DevBuf<uint32_t> d_tile_max, d_order;
     DevBuf<SegDesc> d_segs;
     PinBuf<uint32_t> h_tile_max;
@@ -497,7 +497,7 @@ int r433_batch_set_split(r433_batch *b, uint32_t segment_samples)
 {
     if (!b)
         return fail(R433_EINVAL, "null batch");
-    if (segment_samples && segment_samples < 4096)
+    if (segment_samples > R433_SPLIT_AUTO && segment_samples < 4096)
         return fail(R433_EINVAL, "segments shorter than 4096 samples make no sense (the establishing tile alone is 2048)");
     b->split_samples = segment_samples;
     return 0;
@@ -639,7 +639,16 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
     std::vector<uint32_t> cap_n(n_streams);
     for (uint32_t c = 0; c < n_streams; ++c)
         cap_n[c] = (stream_bytes ? stream_bytes[c] : (uint32_t)stride_bytes) / ss;
-    bool const split = b->split_samples > 0;
+    // automatic: only where one wavefront per capture would leave the chip empty -- few, long captures.
+    // Aim at ~4096 segments, at least 64 Ki samples each.
+    uint32_t split_samples = b->split_samples;
+    if (split_samples == R433_SPLIT_AUTO) {
+        uint64_t total = 0;
+        for (uint32_t c = 0; c < n_streams; ++c)
+            total += cap_n[c];
+        split_samples = (n_streams <= 64 && max_samples >= (1u << 20)) ? (uint32_t)std::max<uint64_t>(65536, total / 4096) : 0u;
+    }
+    bool const split = split_samples > 0;
     uint32_t max_seg_samples = max_samples;
     if (split) {
         constexpr uint32_t kTileS = 2048;
@@ -659,7 +668,7 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
             thr = b->det.fixed_high;
         uint32_t const quiet_below = (uint32_t)std::max(1, thr - thr / 8);
         bool const blind = getenv("R433_SPLIT_BLIND") != nullptr; // tests: cut anywhere, let the verification sort it out
-        uint32_t const seg_len = (b->split_samples + kTileS - 1) / kTileS * kTileS;
+        uint32_t const seg_len = (split_samples + kTileS - 1) / kTileS * kTileS;
         // a package stays open until its last gap exceeds 10 pulse widths and 10 ms (pulse_detect.c:446-450):
         // ask for 25 ms of quiet before a cut (the stitch catches the rest: at most 100 ms are ever needed)
         uint32_t const quiet_tiles = std::max<uint32_t>(2u, (b->cfg.samp_rate / 40u + kTileS - 1) / kTileS);

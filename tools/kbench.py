@@ -12,6 +12,7 @@ ap.add_argument("--streams", type=int, default=1024)
 ap.add_argument("--samples", type=int, default=65536)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--nodevs", action="store_true")
+ap.add_argument("--split", type=int, default=0)
 ap.add_argument("--cs16", action="store_true", help="config 3 style: 1024 kS/s cs16 FSK Manchester bursts, minmax detector")
 a = ap.parse_args()
 if a.cs16:
@@ -24,13 +25,15 @@ else:
 d = torch.from_numpy(host).cuda()
 devs = None if a.nodevs else load_device_table()[0]
 eng = BatchEngine(cfg, devs, profiling=True)
+if a.split:
+    eng.set_split(a.split)
 ts = []
 for r in range(a.reps):
     n = eng.run(d)
     ts.append(eng.timing())
 best = min(ts, key=lambda t: t["detect_ms"])
 print(f"flags={os.environ.get('R433_DEBUG_FLAGS','0')} streams={a.streams} samples={a.samples} pkgs={n} " +
-      " ".join(f"{k}={v:.3f}" for k, v in best.items()))
+      " ".join(f"{k}={v:.3f}" for k, v in best.items()) + (f" split={eng.split_stats()}" if a.split else ""))
 
 if int(os.environ.get("R433_DEBUG_FLAGS", "0"), 0) & 1024:
     import ctypes as C

@@ -24,10 +24,9 @@ iq = np.tile(base, reps)[: 2 * n].copy()
 # keep the noise floor of the bursts' captures consistent enough: overlay nothing, the tile pattern repeats
 d = torch.from_numpy(iq.reshape(1, -1)).cuda()
 res = {}
-for split in (0, a.split):
+for split in (0, 1, a.split):
     eng = BatchEngine(flow_cfg(2, 250000), None, profiling=True)
-    if split:
-        eng.set_split(split)
+    eng.set_split(split)
     best = None
     for r in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter()
