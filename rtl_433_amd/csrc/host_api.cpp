@@ -780,8 +780,10 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
         if (split) {
             // ---- stitch.  Per capture an ordered list of pieces; every piece but the first exists in two
             // parity variants (two slots).  Walk the pieces in order; at each cut keep the variant that
-            // assumed exactly the floor the piece before it really ended with (and require that piece to
-            // have ended idle).  A cut that does not verify is dropped: the piece before it is run again
+            // assumed exactly the floor (and the level estimate that an idle step leaves behind: a spurious
+            // short pulse returns to idle without one) the piece before it really ended with, and require
+            // that piece to have ended idle with the lead-in saturated -- that is the detector's whole
+            // state between packages (everything else is reset when a pulse starts).  A cut that does not verify is dropped: the piece before it is run again
             // through to the end of the next piece, and the walk resumes from there.  Every round
             // removes at least one cut per capture that still has a problem, so this terminates.
             struct Piece {
@@ -874,7 +876,8 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
                         uint32_t pick = UINT32_MAX;
                         if (P.seg_end_state == ST_IDLE && P.seg_end_lead == 1025)
                             for (int v = 0; v < 2; ++v)
-                                if (!b->h_state.p[nx.slot[v]].seg_fail && b->h_state.p[nx.slot[v]].seg_init_low == P.seg_end_low)
+                                if (!b->h_state.p[nx.slot[v]].seg_fail && b->h_state.p[nx.slot[v]].seg_init_low == P.seg_end_low
+                                        && b->h_state.p[nx.slot[v]].seg_init_high == P.seg_end_high)
                                     pick = nx.slot[v];
                         if (pick != UINT32_MAX) {
                             chosen[c].push_back(pick);

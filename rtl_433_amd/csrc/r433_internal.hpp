@@ -30,10 +30,12 @@ struct StreamState {
     uint32_t overflow;
     // what a segment of a split capture reports for the stitch (SegDesc below)
     int seg_init_low;  // noise floor it assumed at its first sample (its parity variant)
+    int seg_init_high; // and the level estimate that goes with an idle detector at that floor
     int seg_fail;      // its start could not be established (filter carry or floor not provable)
     int seg_end_state; // detector state, lead-in counter and noise floor after its last sample
     int seg_end_lead;
     int seg_end_low;
+    int seg_end_high;
 };
 
 // A capture processed by several wavefronts.  Cuts are speculative: a segment that does not start the

@@ -190,7 +190,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
     // a later segment starts one tile early: that tile only establishes the filter carries and the floor
     uint32_t const tile_first = seg_first ? 0u : seg_start / kTile - 1u;
     uint32_t const tile_end = (seg_end + kTile - 1) / kTile;
-    int seg_fail = 0, seg_init_low = 0;
+    int seg_fail = 0, seg_init_low = 0, seg_init_high = 0;
 
     // ---- detector: wave-uniform.  Every lane carries the same scalar state and takes the same
     // branches, in the fast paths and in the general step alike; lane 0 alone touches the arena and
@@ -651,6 +651,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
             det.low = a;
             det.high = max(cfg.ratio * a, cfg.min_high);
             seg_init_low = a;
+            seg_init_high = det.high;
             continue;
         }
 
@@ -1040,16 +1041,18 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
         tk[6] += now() - t_res; // the samples leave LDS with the tile
     }
 
-    int const end_state = det.state; // before the flush: what the next segment has to agree with
+    int const end_state = det.state, end_high = det.high; // before the flush: what the next segment has to agree with
     if (!(p.flags & RUN_NOFLUSH) && (seg_flags & SEG_LAST))
         det_flush(det, cfg, frame);
     if (lane == 0) {
         StreamState &S = p.state[s];
         S.seg_init_low = seg_init_low;
+        S.seg_init_high = seg_init_high;
         S.seg_fail = seg_fail;
         S.seg_end_state = end_state;
         S.seg_end_lead = det.lead_in;
         S.seg_end_low = det.low;
+        S.seg_end_high = end_high;
         S.cursor = det.cursor;
         S.n_pkgs = det.n_pkgs;
         S.overflow = det.overflow;
