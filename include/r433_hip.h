@@ -88,7 +88,7 @@ int r433_batch_set_taps(r433_batch *b, void *d_env, void *d_am, void *d_fm, uint
 
 /* Long captures: let several wavefronts work on one capture.  A capture longer than segment_samples is cut
  * about every segment_samples where the signal looks idle.  0 = never; R433_SPLIT_AUTO (the default) = only for
- * batches of at most 64 captures with one of at least 2^20 samples, aiming at ~4096 segments of >= 65536 samples.  Cuts are speculative
+ * batches of at most 64 captures with one of at least 2^20 samples, aiming at ~4096 segments of >= 32768 samples.  Cuts are speculative
  * and verified: every later segment is run for both parities of the noise-floor estimate and kept only if the
  * segment before it really ended idle with exactly the floor it assumed; a cut that does not verify is
  * dropped and the piece before it is run again across it, so results never depend on this setting.  There is no reference

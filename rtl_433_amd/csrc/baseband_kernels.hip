@@ -101,36 +101,36 @@ template <int KIND> __global__ __launch_bounds__(256) void k_frame_sums(uint8_t 
         sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
-// Largest raw envelope value of every 2048-sample tile: where a long capture may be cut into
-// independently processed segments (the low-passed envelope cannot exceed the recent raw maximum by
-// more than a vanishing term).  A heuristic only -- every cut is verified after the fact.
+// Mean raw envelope of every 2048-sample tile (as a sum): where a long capture may be cut into
+// independently processed segments -- tiles that carry no more energy than the noise floor.  A
+// heuristic only: every cut is verified after the fact.
 template <int KIND> __global__ __launch_bounds__(64) void k_tile_max(uint8_t const *iq, uint64_t stride_bytes,
-        uint32_t const *stream_bytes, uint32_t uniform_bytes, uint32_t tiles_cap, uint32_t *tile_max)
+        uint32_t const *stream_bytes, uint32_t uniform_bytes, uint32_t tiles_cap, uint32_t *tile_sum)
 {
     constexpr int SS = KIND == ENV_MAG_CS16 ? 4 : 2;
     constexpr int SPV = 16 / SS;
     uint32_t const s = blockIdx.x / tiles_cap, t = blockIdx.x % tiles_cap;
     uint32_t const my_n = (stream_bytes ? stream_bytes[s] : uniform_bytes) / SS;
     uint64_t const start = (uint64_t)t * 2048u;
-    uint32_t mx = 0;
-    if (start < my_n) {
-        uint32_t const cnt = (uint32_t)min((uint64_t)2048u, (uint64_t)my_n - start);
+    uint32_t acc = 0;
+    if (start + 2048u <= my_n) { // whole tiles only: nobody cuts next to the ragged end of a capture
         uint8_t const *base = iq + (uint64_t)s * stride_bytes + start * SS;
-        for (uint32_t v = threadIdx.x; v < cnt / SPV; v += 64) {
+        for (uint32_t v = threadIdx.x; v < 2048u / SPV; v += 64) {
             uint4 w = ((uint4 const *)base)[v];
             if (SS == 2)
-                mx = max(mx, max(max(max(env_one<KIND>(w.x & 0xffffu), env_one<KIND>(w.x >> 16)), max(env_one<KIND>(w.y & 0xffffu), env_one<KIND>(w.y >> 16))),
-                                 max(max(env_one<KIND>(w.z & 0xffffu), env_one<KIND>(w.z >> 16)), max(env_one<KIND>(w.w & 0xffffu), env_one<KIND>(w.w >> 16)))));
+                acc += env_one<KIND>(w.x & 0xffffu) + env_one<KIND>(w.x >> 16) + env_one<KIND>(w.y & 0xffffu) + env_one<KIND>(w.y >> 16)
+                        + env_one<KIND>(w.z & 0xffffu) + env_one<KIND>(w.z >> 16) + env_one<KIND>(w.w & 0xffffu) + env_one<KIND>(w.w >> 16);
             else
-                mx = max(mx, max(max(env_one<KIND>(w.x), env_one<KIND>(w.y)), max(env_one<KIND>(w.z), env_one<KIND>(w.w))));
+                acc += env_one<KIND>(w.x) + env_one<KIND>(w.y) + env_one<KIND>(w.z) + env_one<KIND>(w.w);
         }
-        if (cnt % SPV) // ragged tail: treat as loud, nobody cuts next to the end of a capture anyway
-            mx = 0xffffu;
+    }
+    else {
+        acc = 0xffffffffu / 64u; // loud
     }
     for (int o = 32; o > 0; o >>= 1)
-        mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+        acc += (uint32_t)__shfl_xor((int)acc, o, 64);
     if (threadIdx.x == 0)
-        tile_max[blockIdx.x] = mx;
+        tile_sum[blockIdx.x] = acc;
 }
 
 } // namespace

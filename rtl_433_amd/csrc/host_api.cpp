@@ -640,13 +640,13 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
     for (uint32_t c = 0; c < n_streams; ++c)
         cap_n[c] = (stream_bytes ? stream_bytes[c] : (uint32_t)stride_bytes) / ss;
     // automatic: only where one wavefront per capture would leave the chip empty -- few, long captures.
-    // Aim at ~4096 segments, at least 64 Ki samples each.
+    // Aim at ~4096 segments, at least 32 Ki samples each.
     uint32_t split_samples = b->split_samples;
     if (split_samples == R433_SPLIT_AUTO) {
         uint64_t total = 0;
         for (uint32_t c = 0; c < n_streams; ++c)
             total += cap_n[c];
-        split_samples = (n_streams <= 64 && max_samples >= (1u << 20)) ? (uint32_t)std::max<uint64_t>(65536, total / 4096) : 0u;
+        split_samples = (n_streams <= 64 && max_samples >= (1u << 20)) ? (uint32_t)std::max<uint64_t>(32768, total / 4096) : 0u;
     }
     bool const split = split_samples > 0;
     uint32_t max_seg_samples = max_samples;
@@ -661,22 +661,29 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(b->h_tile_max.p, b->d_tile_max.p, (size_t)n_streams * tiles_cap * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        // a tile is quiet when nothing in it can hold a pulse up: below the falling-edge level of the
-        // lowest threshold the detector can have (pulse_detect.c:300-304 with low = -1, high = min_high)
+        // A tile is quiet when it carries no more energy than the noise floor: mean envelope at most 1.5x
+        // the capture's median tile, or -- for captures that are mostly signal -- below half the
+        // falling-edge level of the lowest threshold the detector can have (pulse_detect.c:300-304).
         int thr = (-1 + std::min(b->det.min_high, b->det.max_high)) / 2;
         if (b->det.fixed_high)
             thr = b->det.fixed_high;
-        uint32_t const quiet_below = (uint32_t)std::max(1, thr - thr / 8);
+        uint64_t const abs_quiet = (uint64_t)std::max(1, (thr - thr / 8) / 2) * 2048u;
         bool const blind = getenv("R433_SPLIT_BLIND") != nullptr; // tests: cut anywhere, let the verification sort it out
         uint32_t const seg_len = (split_samples + kTileS - 1) / kTileS * kTileS;
         // a package stays open until its last gap exceeds 10 pulse widths and 10 ms (pulse_detect.c:446-450):
-        // ask for 25 ms of quiet before a cut (the stitch catches the rest: at most 100 ms are ever needed)
-        uint32_t const quiet_tiles = std::max<uint32_t>(2u, (b->cfg.samp_rate / 40u + kTileS - 1) / kTileS);
+        // ask for 12.5 ms of quiet before a cut (pulses up to 1.25 ms; the stitch catches the rest)
+        uint32_t const quiet_tiles = std::max<uint32_t>(2u, (b->cfg.samp_rate / 80u + kTileS - 1) / kTileS);
         max_seg_samples = 0;
         for (uint32_t c = 0; c < n_streams; ++c) {
             seg_first_of[c] = (uint32_t)segs.size();
             uint32_t const n = cap_n[c];
             uint32_t const *tm = b->h_tile_max.p + (size_t)c * tiles_cap;
+            uint64_t quiet_below = abs_quiet; // on tile sums
+            if (n >= 2 * kTileS) {
+                std::vector<uint32_t> med(tm, tm + n / kTileS);
+                std::nth_element(med.begin(), med.begin() + med.size() / 2, med.end());
+                quiet_below = std::max<uint64_t>(abs_quiet, (uint64_t)med[med.size() / 2] * 3 / 2);
+            }
             std::vector<uint32_t> cuts;
             uint32_t pos = seg_len;
             while (n > seg_len && pos + seg_len / 2 < n) {
