@@ -1,6 +1,7 @@
-// stream_kernels.hip -- the IQ -> pulse-package kernel: one capture per wavefront.
+// stream_kernels.hip -- the IQ -> pulse-package kernel: one capture (or one verified segment of a long
+// capture, SegDesc in r433_internal.hpp) per wavefront.
 //
-// A wavefront walks its capture in tiles of 2048 samples and runs three phases per tile:
+// A wavefront walks its samples in tiles of 2048 and runs three phases per tile:
 //
 //   A  sample-parallel   16-byte-per-lane coalesced IQ loads (issued one tile ahead), envelope and FM
 //                        discriminator for 8 consecutive samples per lane, parked in LDS.
@@ -21,7 +22,7 @@
 //                        between (noise floor -- evaluated lazily --, level and carrier averages,
 //                        counters) and the exact general step (detect_device.hpp) on the candidates.
 //
-// Packages leave as r433_pkg_rec records in a per-capture arena.  Frame semantics of the file reader
+// Packages leave as r433_pkg_rec records in a per-wavefront arena.  Frame semantics of the file reader
 // (one push_sdr_flow call per 262144 input bytes) are reproduced at their exact sample positions.
 //
 // Replaces, for file input: envelope_detect / magnitude_est_* (reference src/baseband.c:36-110),
