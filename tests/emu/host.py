@@ -26,8 +26,6 @@ def emu_run(iq_list, ss, rate, devs, fpdm=0, taps=False, enable_fm=1, center_fre
     n = len(iq_list)
     lens = np.array([a.nbytes for a in iq_list], dtype=np.uint32)
     stride = max(16, int((lens.max() + 15) // 16 * 16)) if n else 16
-    host = np.zeros((max(n, 1), stride + 64), dtype=np.uint8)
-    host = host[:, :stride] if False else host
     buf = np.zeros(max(n, 1) * stride + 64, dtype=np.uint8)
     base = (-buf.ctypes.data) % 16
     arena = buf[base:base + max(n, 1) * stride].reshape(max(n, 1), stride)
