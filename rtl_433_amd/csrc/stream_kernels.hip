@@ -772,6 +772,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
             det.eop_spurious = uni(det.eop_spurious);
             det.cur_pulse = uni(det.cur_pulse);
             det.ook_f1 = uni(det.ook_f1);
+            det.fsk_num = (uint32_t)uni((int)det.fsk_num);
             // ---- whole chunks at a time: while idle or inside a gap, nothing can happen before the first
             // chunk whose maximum reaches the (conservative) threshold, the end-of-package count, or the
             // end of the frame ----
@@ -973,9 +974,13 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                 det.ook_f1 = f1;
                 det.run += k - i;
             }
-            else if (st == ST_GAP_START && det.ook_num > 0) {
+            else if (st == ST_GAP_START && det.ook_num > 0 && det.fsk_num <= 16) {
                 // debouncing the end of a pulse (pulse_detect.c:376-421) once the FSK candidate is out of
-                // the picture: either the signal comes back before the count reaches 10, or the gap begins
+                // the picture: either the signal comes back before the count reaches 10, or the gap begins.
+                // (The candidate can still be in the picture after the first pulse: the sample that ends the
+                // first debounce is fed to the FSK detector AFTER the `> 16 pulses` test, so the 17th FSK
+                // pulse may arrive there and the reference then returns the FSK package at the end of the
+                // NEXT pulse -- the general step does that.)
                 int thr = (int)(int16_t)((det.low + min(det.high, cfg.max_high)) / 2);
                 if (cfg.fixed_high != 0)
                     thr = (int)(int16_t)cfg.fixed_high;

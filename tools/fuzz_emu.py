@@ -1,0 +1,151 @@
+"""CPU fuzzing of the kernel sources (wave emulator) against the oracle: random signals x random flow options.
+    python tools/fuzz_emu.py [n_cases] [first_seed]
+Every case: 1-3 captures in one launch, byte-for-byte comparison of package and event records and of the
+am/fm taps.  Prints the seed of every failing case."""
+import os, sys, time, traceback
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from oracle import pyoracle as po
+from rtl_433_amd import synth
+from rtl_433_amd.engine import load_device_table
+from tests.emu import host
+
+DEVS = load_device_table()[0]
+
+
+def rand_ook(rng, rate, n_max):
+    """OOK bursts with adversarial timing: very short (spurious) pulses, very long packages, gaps around the
+    end-of-package rules, amplitude steps."""
+    segs = [(int(rng.integers(0, 3000)), False)]
+    for _ in range(int(rng.integers(1, 6))):
+        style = rng.integers(0, 6)
+        short = int(rng.integers(3, 200)) if style != 1 else int(rng.integers(3, 12))
+        nb = int(rng.integers(4, 80)) if style != 2 else int(rng.integers(1300, 1500))  # > PD_MAX_PULSES
+        for _b in range(nb):
+            w = short * int(rng.integers(1, 4))
+            g = short * int(rng.integers(1, 4))
+            if style == 3 and rng.random() < 0.1:
+                g = int(rng.integers(2000, 30000))  # around 10 ms / 100 ms at 250k
+            segs += [(w, True), (g, False)]
+        segs.append((int(rng.integers(100, 40000)), False))
+    n = min(n_max, sum(s[0] for s in segs))
+    return synth._segments_to_mask(segs, n)
+
+
+def make_capture(rng, ss, rate):
+    kind = rng.integers(0, 8)
+    n_max = int(rng.integers(3000, 140000))
+    if ss == 2:
+        if kind == 0:
+            return synth.random_cu8(int(rng.integers(1 << 30)), int(rng.integers(1, 20000)))
+        if kind == 1:
+            return synth.noise_cu8(int(rng.integers(1 << 30)), n_max, float(rng.choice([0.0, 0.5, 1, 3, 8, 20, 40])))
+        if kind == 2:
+            return synth.fsk_stream_cu8(int(rng.integers(1 << 30)), n_max, rate=rate, n_bursts=int(rng.integers(1, 4)))
+        if kind == 3:  # FSK with very many transitions (> 1200 FSK pulses: ring overflow)
+            n = n_max
+            t = np.arange(n)
+            lv = np.sign(np.sin(2 * np.pi * t / float(rng.integers(24, 60))))
+            ph = 2 * np.pi * np.cumsum(lv * 40e3) / rate
+            a = 90.0 * (t > 2000) * (t < n - 3000)
+            sg = float(rng.choice([0, 1, 2]))
+            i = 128 + a * np.cos(ph) + rng.normal(0, 1, n) * sg
+            q = 128 + a * np.sin(ph) + rng.normal(0, 1, n) * sg
+            out = np.empty(2 * n, dtype=np.uint8)
+            out[0::2] = np.clip(np.rint(i), 0, 255)
+            out[1::2] = np.clip(np.rint(q), 0, 255)
+            return out
+        mask = rand_ook(rng, rate, n_max)
+        amp = float(rng.choice([6, 12, 25, 60, 110, 127]))
+        sig = float(rng.choice([0, 0, 1, 2, 5, 12]))
+        iq = synth.modulate_cu8(mask, rng, rate, float(rng.uniform(-80e3, 80e3)), amp, sig)
+        if kind == 7 and len(iq) > 4000:  # amplitude step / saturated stretch
+            k = int(rng.integers(0, len(iq) // 2 - 1000)) * 2
+            iq[k:k + 2000] = rng.choice([0, 255])
+        return iq
+    # cs16
+    if kind < 3:
+        return synth.fsk_stream_cs16(int(rng.integers(1 << 30)), n_max, rate=rate, n_bursts=int(rng.integers(1, 4)),
+                                     coding=str(rng.choice(["mc", "pcm"])), sigma=float(rng.choice([0.0, 0.01, 0.05])))
+    if kind == 3:
+        return rng.integers(-32768, 32768, 2 * int(rng.integers(1, 20000)), dtype=np.int64).astype(np.int16)
+    mask = rand_ook(rng, rate, n_max)
+    n = len(mask)
+    ph = 2 * np.pi * float(rng.uniform(-0.2, 0.2)) * np.arange(n)
+    a = float(rng.choice([300, 3000, 20000, 32000])) * mask
+    sg = float(rng.choice([0, 30, 300]))
+    out = np.empty(2 * n, dtype=np.int16)
+    out[0::2] = np.clip(np.rint(a * np.cos(ph) + rng.normal(0, 1, n) * sg), -32768, 32767)
+    out[1::2] = np.clip(np.rint(a * np.sin(ph) + rng.normal(0, 1, n) * sg), -32768, 32767)
+    return out
+
+
+def one_case(seed):
+    rng = np.random.default_rng(seed)
+    ss = int(rng.choice([2, 2, 2, 4]))
+    rate = int(rng.choice([250000, 250000, 1000000, 1024000, 2000000, 48000]))
+    kw = {}
+    if rng.random() < 0.2 and ss == 2:
+        kw["use_mag_est"] = 1
+    if rng.random() < 0.2:
+        kw["level_limit_db"] = float(rng.choice([-5.0, -10.0, -20.0]))
+    if rng.random() < 0.3:
+        kw["min_level_db"] = float(rng.choice([-6.0, -20.0, -30.0]))
+    if rng.random() < 0.2:
+        kw["min_snr_db"] = float(rng.choice([3.0, 6.0, 12.0]))
+    if rng.random() < 0.3:
+        kw["fm_low_pass"] = float(rng.choice([0.02, 0.05, 0.15, 0.3, 0.45, 50.0, 30000.0]))
+    if rng.random() < 0.3:
+        kw["frame_samples"] = int(rng.choice([64, 192, 2048, 4096, 10048, 65536]))
+    if rng.random() < 0.2:
+        kw["auto_level"] = 1.0
+    fpdm = int(rng.integers(0, 2))
+    enable_fm = int(rng.random() < 0.85)
+    devs = DEVS[rng.choice(len(DEVS), int(rng.integers(0, 30)), replace=False)] if rng.random() < 0.8 else None
+    if devs is not None:
+        devs = devs[np.argsort(rng.random(len(devs)))]
+        if not enable_fm:
+            devs = devs[devs["modulation"] < 16]
+        if len(devs) == 0:
+            devs = None
+    caps = [make_capture(rng, ss, rate) for _ in range(int(rng.integers(1, 4)))]
+    split = int(rng.choice([0, 0, 4096, 8192, 20000]))
+    if split and rng.random() < 0.5:
+        os.environ["R433_SPLIT_BLIND"] = "1"
+    else:
+        os.environ.pop("R433_SPLIT_BLIND", None)
+    g = host.emu_run(caps, ss, rate, devs, fpdm=fpdm, taps=True, enable_fm=enable_fm, split=split, **kw)
+    cfg = po.default_flow_cfg(ss, rate, fpdm=fpdm, enable_fm=enable_fm, **kw)
+    pk, ev, base = b"", b"", 0
+    for s, a in enumerate(caps):
+        o = po.oracle_flow(a, devs, cfg, stream_index=s, pkg_base=base, taps=True)
+        n = a.nbytes // ss
+        if n and not (np.array_equal(g["taps"][1][s, :n], o["am"]) and np.array_equal(g["taps"][2][s, :n], o["fm"])
+                      and np.array_equal(g["taps"][0][s, :n], o["env"])):
+            return f"taps differ (capture {s})"
+        pk += o["packages"]
+        ev += o["events"]
+        base += o["n_packages"]
+    if g["packages"][0] != pk:
+        return f"packages differ ({g['n_packages']} vs {base})"
+    if g["events"][0] != ev:
+        return "events differ"
+    return None
+
+
+if __name__ == "__main__":
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    t0 = time.time()
+    bad = []
+    for seed in range(first, first + n_cases):
+        try:
+            r = one_case(seed)
+        except Exception as e:  # noqa
+            r = "exception: " + repr(e)
+            traceback.print_exc()
+        if r:
+            bad.append(seed)
+            print(f"seed {seed}: {r}", flush=True)
+    print(f"{n_cases} cases, {len(bad)} failures {bad} in {time.time() - t0:.0f} s")
