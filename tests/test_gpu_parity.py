@@ -207,3 +207,16 @@ def test_split_captures(blind, default_devices, monkeypatch):
         base += o["n_packages"]
     assert st["segments"] > 50
     assert pk == pk_o and ev == ev_o
+
+
+@pytest.mark.parametrize("seed", [3, 19, 42, 77, 104, 1189, 5003, 5011])
+def test_fuzz_cases_on_gpu(seed, monkeypatch):
+    """The seeded fuzz slice of tests/test_fuzz_emu.py through the product library (tools/fuzz_emu.py --gpu)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_emu
+    monkeypatch.delenv("R433_SPLIT_BLIND", raising=False)
+    try:
+        assert fuzz_emu.one_case(seed, fuzz_emu.gpu_run) is None
+    finally:
+        os.environ.pop("R433_SPLIT_BLIND", None)

@@ -1,5 +1,6 @@
-"""CPU fuzzing of the kernel sources (wave emulator) against the oracle: random signals x random flow options.
-    python tools/fuzz_emu.py [n_cases] [first_seed]
+"""Fuzzing against the oracle: random signals x random flow options, on the wave emulator (CPU, default) or on
+the MI355X through the product library (--gpu).
+    python tools/fuzz_emu.py [--gpu] [n_cases] [first_seed]
 Every case: 1-3 captures in one launch, byte-for-byte comparison of package and event records and of the
 am/fm taps.  Prints the seed of every failing case."""
 import os, sys, time, traceback
@@ -81,7 +82,9 @@ def make_capture(rng, ss, rate):
     return out
 
 
-def one_case(seed):
+def one_case(seed, run=None):
+    """run(caps, ss, rate, devs, fpdm=, taps=, enable_fm=, split=, **flow options) -> dict like tests.emu.host.emu_run"""
+    run = run or host.emu_run
     rng = np.random.default_rng(seed)
     ss = int(rng.choice([2, 2, 2, 4]))
     rate = int(rng.choice([250000, 250000, 1000000, 1024000, 2000000, 48000]))
@@ -115,7 +118,7 @@ def one_case(seed):
         os.environ["R433_SPLIT_BLIND"] = "1"
     else:
         os.environ.pop("R433_SPLIT_BLIND", None)
-    g = host.emu_run(caps, ss, rate, devs, fpdm=fpdm, taps=True, enable_fm=enable_fm, split=split, **kw)
+    g = run(caps, ss, rate, devs, fpdm=fpdm, taps=True, enable_fm=enable_fm, split=split, **kw)
     cfg = po.default_flow_cfg(ss, rate, fpdm=fpdm, enable_fm=enable_fm, **kw)
     pk, ev, base = b"", b"", 0
     for s, a in enumerate(caps):
@@ -134,14 +137,40 @@ def one_case(seed):
     return None
 
 
+def gpu_run(caps, ss, rate, devs, fpdm=0, taps=False, enable_fm=1, split=0, **kw):
+    """The same contract on the MI355X through the product library."""
+    import torch
+    from rtl_433_amd.engine import BatchEngine, flow_cfg
+    n = len(caps)
+    lens = np.array([a.nbytes for a in caps], dtype=np.uint32)
+    stride = max(16, int((lens.max() + 15) // 16 * 16))
+    hostbuf = np.zeros((n, stride), dtype=np.uint8)
+    for i, a in enumerate(caps):
+        hostbuf[i, :a.nbytes] = a.view(np.uint8)
+    eng = BatchEngine(flow_cfg(ss, rate, fpdm=fpdm, enable_fm=enable_fm, **kw), devs)
+    eng.set_split(split)
+    if taps:
+        eng.enable_taps(n, max(1, stride // ss))
+    npk = eng.run(torch.from_numpy(hostbuf).cuda(), lens)
+    out = dict(n_packages=npk, packages=eng.packages(), events=eng.events(), split=eng.split_stats())
+    if taps:
+        out["taps"] = eng.taps()
+    eng.close()
+    return out
+
+
 if __name__ == "__main__":
+    runner = None
+    if "--gpu" in sys.argv:
+        sys.argv.remove("--gpu")
+        runner = gpu_run
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     t0 = time.time()
     bad = []
     for seed in range(first, first + n_cases):
         try:
-            r = one_case(seed)
+            r = one_case(seed, runner)
         except Exception as e:  # noqa
             r = "exception: " + repr(e)
             traceback.print_exc()
