@@ -1,4 +1,5 @@
 // Microbenchmark: what does one wavefront alone on a SIMD pay per dependent instruction?
+// build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench/chain tools/ubench/chain.hip   (binary is git-ignored)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
