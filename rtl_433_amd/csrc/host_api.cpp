@@ -273,6 +273,9 @@ void digest_publish()
 
 } // namespace
 
+struct r433_batch;
+static hipError_t stream_wait(r433_batch *b, hipStream_t st);
+
 struct r433_batch {
     r433_flow_cfg cfg;
     DetCfg det;
@@ -312,6 +315,7 @@ struct r433_batch {
     void *tap_env = nullptr, *tap_am = nullptr, *tap_fm = nullptr;
     uint64_t tap_stride = 0;
 
+    hipEvent_t sync_ev = nullptr; // blocking (sleeping) wait: host threads of other pipeline stages need the cores
     bool profiling = false;
     hipEvent_t ev[8] = {};
     bool ev_made = false;
@@ -322,6 +326,17 @@ struct r433_batch {
     r433_pulse_data *pulses = nullptr;
     Pool pool;
 };
+
+static hipError_t stream_wait(r433_batch *b, hipStream_t st)
+{
+    if (!b->sync_ev) {
+        hipError_t e = hipEventCreateWithFlags(&b->sync_ev, hipEventBlockingSync | hipEventDisableTiming);
+        if (e != hipSuccess)
+            return e;
+    }
+    hipError_t e = hipEventRecord(b->sync_ev, st);
+    return e != hipSuccess ? e : hipEventSynchronize(b->sync_ev);
+}
 
 extern "C" {
 
@@ -475,6 +490,8 @@ void r433_batch_destroy(r433_batch *b)
     if (b->ev_made)
         for (auto &e : b->ev)
             (void)hipEventDestroy(e);
+    if (b->sync_ev)
+        (void)hipEventDestroy(b->sync_ev);
     free(b->bits);
     free(b->pulses);
     delete b;
@@ -599,7 +616,7 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(b->h_frame_sums.p, b->d_frame_sums.p, (size_t)n_streams * frames_cap * sizeof(uint32_t),
                 hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(stream_wait(b, st));
         b->h_frame_min_high.assign((size_t)n_streams * frames_cap, b->det.min_high);
         int const is_mag = ss == 4 || b->cfg.use_mag_est;
         for (uint32_t s = 0; s < n_streams; ++s) {
@@ -660,7 +677,7 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
                 tiles_cap, b->d_tile_max.p, st);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(b->h_tile_max.p, b->d_tile_max.p, (size_t)n_streams * tiles_cap * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(stream_wait(b, st));
         // A tile is quiet when it carries no more energy than the noise floor: mean envelope at most 1.5x
         // the capture's median tile, or -- for captures that are mostly signal -- below half the
         // falling-edge level of the lowest threshold the detector can have (pulse_detect.c:300-304).
@@ -830,13 +847,13 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
                 launch_stream(sr, ss, st);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(b->h_state.p + n_have, b->d_state.p + n_have, launch_list.size() * sizeof(StreamState), hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
+                HIP_TRY(stream_wait(b, st));
                 n_have += (uint32_t)launch_list.size();
                 launch_list.clear();
                 return 0;
             };
             HIP_TRY(hipMemcpyAsync(b->h_state.p, b->d_state.p, (size_t)n_planned * sizeof(StreamState), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(stream_wait(b, st));
             // (1) cuts neither variant could start from (no provable filter carry or floor: digital
             // silence does that) are known now, all at once: merge across them in one extra launch
             for (uint32_t c = 0; c < n_streams; ++c) {
@@ -924,7 +941,7 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
         launch_pkg_scan(b->d_state.p, d_order, n_order, b->d_pkg_base.p, b->d_scal.p, st);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(b->h_scal.p, b->d_scal.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(stream_wait(b, st));
         total_pkgs = b->h_scal.p[0];
         if (!b->h_scal.p[1])
             break;
@@ -995,7 +1012,7 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
     if (b->profiling)
         HIP_TRY(hipEventRecord(b->ev[4], st));
     HIP_TRY(hipMemcpyAsync(b->h_scal.p, b->d_scal.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(stream_wait(b, st));
     size_t const pkg_bytes = b->h_scal.p[2];
     size_t const evt_bytes = b->h_scal.p[3];
     if (evt_bytes > 0xf0000000ull)
@@ -1032,7 +1049,7 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
             hipMemcpyDeviceToHost, st));
     if (b->profiling)
         HIP_TRY(hipEventRecord(b->ev[6], st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(stream_wait(b, st));
     b->pkg_bytes = pkg_bytes;
     b->evt_bytes = evt_bytes;
     b->events_counted = false;

@@ -204,6 +204,7 @@ static double now_ms()
     return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6;
 }
 hipError_t hipEventCreate(hipEvent_t *e) { *e = new EmuEvent{0}; return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = now_ms(); return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }

@@ -224,6 +224,8 @@ hipError_t hipDeviceSynchronize();
 hipError_t hipGetDeviceCount(int *n);
 hipError_t hipGetLastError();
 char const *hipGetErrorString(hipError_t e);
+enum { hipEventBlockingSync = 1, hipEventDisableTiming = 2 };
+hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned flags);
 hipError_t hipEventCreate(hipEvent_t *e);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t st);
