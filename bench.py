@@ -129,8 +129,8 @@ def main():
     ctx = _lib.DigestCtx(0, 0)
     rdev_arr, rdev_objs = make_rdevices(devs, digest_plugin_addr(), C.addressof(ctx), names, protocols)
 
-    # Two engines on two HIP streams: while the host threads replay step k's bitbuffers into the
-    # decoders, the GPU already works on step k+1.  Every step is still one complete pass of the hot
+    # Several engines on their own HIP streams: while the host threads replay step k's bitbuffers into
+    # the decoders, the GPU already works on steps k+1, k+2.  Every step is still one complete pass of the hot
     # path over the batch, and all K of them finish inside the timed region.
     from concurrent.futures import ThreadPoolExecutor
     from rtl_433_amd import shard

@@ -29,7 +29,7 @@ def gather_bytes(local, dst=0, device=None, group=None):
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
     dev = torch.device("cpu") if device is None else device
-    buf = np.frombuffer(bytes(local), dtype=np.uint8) if not isinstance(local, np.ndarray) else local.view(np.uint8).ravel()
+    buf = (np.frombuffer(bytes(local), dtype=np.uint8) if not isinstance(local, np.ndarray) else local.view(np.uint8).ravel()).copy()
     n = torch.tensor([buf.size], dtype=torch.int64, device=dev)
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
