@@ -51,7 +51,13 @@ typedef struct r433_flow_cfg {
     float min_snr_db;       /* -Y minsnr, default 9.0 */
     float auto_level;       /* -Y autolevel > 0 */
     uint32_t center_frequency; /* only for reporting (freq fields of calc_rssi_snr) */
+    uint32_t input_format;  /* R433_IN_NATIVE, or a file format the reference converts on load (src/rtl_433.c:1811-1834):
+                             * R433_IN_CS8 (sample_size 2: int8 pairs -> cu8) / R433_IN_CF32 (sample_size 4: float pairs -> cs16).
+                             * Strides and lengths given to r433_batch_run are then in the input format's bytes. */
 } r433_flow_cfg;
+#define R433_IN_NATIVE 0u
+#define R433_IN_CS8 1u
+#define R433_IN_CF32 2u
 
 void r433_flow_cfg_default(r433_flow_cfg *cfg, uint32_t sample_size, uint32_t samp_rate);
 
@@ -166,6 +172,11 @@ int r433_envelope_detect(void const *d_iq, void *d_env, uint32_t n, uint32_t *d_
 /* magnitude_est_cu8 (src/baseband.c:65-79) / magnitude_est_cs16 (:96-110) */
 int r433_magnitude_est_cu8(void const *d_iq, void *d_env, uint32_t n, uint32_t *d_sum, void *stream);
 int r433_magnitude_est_cs16(void const *d_iq, void *d_env, uint32_t n, uint32_t *d_sum, void *stream);
+/* The file loop's input conversions (src/rtl_433.c:1811-1834) on device buffers: n = number of components
+ * (2 per IQ sample).  cs8 -> cu8: +128.  cf32 -> cs16: (int)(f * 32767) clamped to +-32767, with C-on-x86
+ * semantics for values no int can hold (they become -32767). */
+int r433_convert_cs8_cu8(void const *d_in, void *d_out, uint64_t n, void *stream);
+int r433_convert_cf32_cs16(void const *d_in, void *d_out, uint64_t n, void *stream);
 /* AMP_TO_DB / MAG_TO_DB of a frame sum (include/baseband.h:36-37, src/baseband.c:44,78) */
 float r433_level_db(uint32_t sum, uint32_t n, int is_magnitude);
 

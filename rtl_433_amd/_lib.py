@@ -13,7 +13,8 @@ class FlowCfg(C.Structure):
     _fields_ = [("sample_size", C.c_uint32), ("samp_rate", C.c_uint32), ("frame_samples", C.c_uint32),
                 ("fpdm", C.c_uint32), ("use_mag_est", C.c_uint32), ("enable_fm", C.c_uint32),
                 ("fm_low_pass", C.c_float), ("level_limit_db", C.c_float), ("min_level_db", C.c_float),
-                ("min_snr_db", C.c_float), ("auto_level", C.c_float), ("center_frequency", C.c_uint32)]
+                ("min_snr_db", C.c_float), ("auto_level", C.c_float), ("center_frequency", C.c_uint32),
+                ("input_format", C.c_uint32)]
 
 
 class BatchTiming(C.Structure):
@@ -54,7 +55,7 @@ EXPORTS = [
     "r433_batch_split_stats", "r433_batch_set_profiling",
     "r433_batch_get_timing", "r433_batch_debug_state", "r433_batch_dispatch", "r433_batch_dispatch_mt", "r433_dispatch_current",
     "r433_plugin_digest_decode", "r433_envelope_detect", "r433_magnitude_est_cu8",
-    "r433_magnitude_est_cs16",
+    "r433_magnitude_est_cs16", "r433_convert_cs8_cu8", "r433_convert_cf32_cs16",
 ]
 
 
@@ -111,6 +112,9 @@ def bind(L):
     L.r433_batch_dispatch_mt.argtypes = [vp, vp, C.c_uint32, vp, vp, C.c_uint32]
     L.r433_dispatch_current.restype = C.c_int
     L.r433_dispatch_current.argtypes = [vp]
+    for f in (L.r433_convert_cs8_cu8, L.r433_convert_cf32_cs16):
+        f.restype = C.c_int
+        f.argtypes = [vp, vp, C.c_uint64, vp]
     for f in (L.r433_envelope_detect, L.r433_magnitude_est_cu8, L.r433_magnitude_est_cs16):
         f.restype = C.c_int
         f.argtypes = [vp, vp, C.c_uint32, vp, vp]

@@ -4,6 +4,8 @@
 // 65-79, 96-110): one 16-byte load per lane (8 cu8 or 4 cs16 samples), one 16/8-byte store,
 // per-wave shuffle reduction and a single atomicAdd per block for the frame sum (the reference's
 // uint32 accumulator wraps; addition mod 2^32 is associative, so the parallel sum is exact).
+#include <algorithm>
+
 #include "dsp_device.hpp"
 #include "r433_internal.hpp"
 
@@ -101,6 +103,52 @@ template <int KIND> __global__ __launch_bounds__(256) void k_frame_sums(uint8_t 
         sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
+// The reference converts two file formats while loading (src/rtl_433.c:1811-1834); here they are
+// HBM-bound maps in front of the detection kernel.  Row-wise so that padded capture strides work.
+__global__ __launch_bounds__(256) void k_cs8_to_cu8(uint8_t const *in, uint64_t in_stride, uint8_t *out, uint64_t out_stride,
+        uint64_t row_bytes, uint32_t bx)
+{
+    uint32_t const row = blockIdx.x / bx, part = blockIdx.x % bx; // bx blocks per capture
+    uint8_t const *src = in + (uint64_t)row * in_stride;
+    uint8_t *dst = out + (uint64_t)row * out_stride;
+    uint64_t const n_vec = row_bytes / 16;
+    for (uint64_t v = (uint64_t)part * 256 + threadIdx.x; v < n_vec; v += (uint64_t)bx * 256) {
+        uint4 w = ((uint4 const *)src)[v];
+        ((uint4 *)dst)[v] = make_uint4(w.x ^ 0x80808080u, w.y ^ 0x80808080u, w.z ^ 0x80808080u, w.w ^ 0x80808080u); // int8 + 128
+    }
+    if (part == 0)
+        for (uint64_t i = n_vec * 16 + threadIdx.x; i < row_bytes; i += 256)
+            dst[i] = (uint8_t)(src[i] ^ 0x80u);
+}
+
+__device__ __forceinline__ int cf32_to_s16(float f)
+{
+    float const p = __fmul_rn(f, 32767.0f);
+    // C converts out-of-range and NaN products to INT_MIN on x86 (cvttss2si); everything then clamps to -32767
+    int s = (p >= 2147483648.0f || p < -2147483648.0f || p != p) ? INT32_MIN : (int)p;
+    return s < -32767 ? -32767 : (s > 32767 ? 32767 : s);
+}
+
+__global__ __launch_bounds__(256) void k_cf32_to_cs16(float const *in, uint64_t in_stride_bytes, int16_t *out, uint64_t out_stride_bytes,
+        uint64_t row_components, uint32_t bx)
+{
+    uint32_t const row = blockIdx.x / bx, part = blockIdx.x % bx;
+    float const *src = (float const *)((uint8_t const *)in + (uint64_t)row * in_stride_bytes);
+    int16_t *dst = (int16_t *)((uint8_t *)out + (uint64_t)row * out_stride_bytes);
+    uint64_t const n_vec = row_components / 4;
+    for (uint64_t v = (uint64_t)part * 256 + threadIdx.x; v < n_vec; v += (uint64_t)bx * 256) {
+        uint4 const raw = ((uint4 const *)src)[v];
+        float fx, fy, fz, fw;
+        __builtin_memcpy(&fx, &raw.x, 4), __builtin_memcpy(&fy, &raw.y, 4), __builtin_memcpy(&fz, &raw.z, 4), __builtin_memcpy(&fw, &raw.w, 4);
+        uint32_t const a = (uint32_t)cf32_to_s16(fx) & 0xffffu, b = (uint32_t)cf32_to_s16(fy) & 0xffffu;
+        uint32_t const c = (uint32_t)cf32_to_s16(fz) & 0xffffu, d = (uint32_t)cf32_to_s16(fw) & 0xffffu;
+        ((uint2 *)dst)[v] = make_uint2(a | (b << 16), c | (d << 16));
+    }
+    if (part == 0)
+        for (uint64_t i = n_vec * 4 + threadIdx.x; i < row_components; i += 256)
+            dst[i] = (int16_t)cf32_to_s16(src[i]);
+}
+
 // Mean raw envelope of every 2048-sample tile (as a sum): where a long capture may be cut into
 // independently processed segments -- tiles that carry no more energy than the noise floor.  A
 // heuristic only: every cut is verified after the fact.
@@ -134,6 +182,21 @@ template <int KIND> __global__ __launch_bounds__(64) void k_tile_max(uint8_t con
 }
 
 } // namespace
+
+void launch_convert(int input_format, void const *d_in, uint64_t in_stride_bytes, void *d_out, uint64_t out_stride_bytes,
+        uint64_t row_in_bytes, uint32_t n_rows, hipStream_t st)
+{
+    if (n_rows == 0 || row_in_bytes == 0)
+        return;
+    uint32_t bx = (uint32_t)std::min<uint64_t>(1024, (row_in_bytes / 16 + 255) / 256 + 1);
+    dim3 grid(bx * n_rows), block(256);
+    if (input_format == 1)
+        hipLaunchKernelGGL(k_cs8_to_cu8, grid, block, 0, st, (uint8_t const *)d_in, in_stride_bytes, (uint8_t *)d_out, out_stride_bytes,
+                row_in_bytes, bx);
+    else
+        hipLaunchKernelGGL(k_cf32_to_cs16, grid, block, 0, st, (float const *)d_in, in_stride_bytes, (int16_t *)d_out, out_stride_bytes,
+                row_in_bytes / 4, bx);
+}
 
 void launch_tile_max(int kind, void const *d_iq, uint64_t stride_bytes, uint32_t const *stream_bytes, uint32_t uniform_bytes,
         uint32_t n_streams, uint32_t tiles_cap, uint32_t *tile_max, hipStream_t st)

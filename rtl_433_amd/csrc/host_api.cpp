@@ -300,7 +300,8 @@ struct r433_batch {
     PinBuf<StreamState> h_state;
     uint32_t last_segments = 0, last_redone = 0;
     DevBuf<uint32_t> d_dir_stream, d_dir_off, d_rec_bytes, d_rec_off, d_sizes, d_pkg_bytes, d_pkg_off;
-    DevBuf<uint8_t> d_pkg_blob, d_events, d_stage;
+    DevBuf<uint8_t> d_pkg_blob, d_events, d_stage, d_converted;
+    std::vector<uint32_t> conv_bytes;
     PinBuf<uint32_t> h_scal, h_frame_sums;
     PinBuf<uint8_t> h_pkg_blob, h_events;
     PinBuf<uint32_t> h_pkg_off, h_rec_off; // per package: byte offset of its first event / of its record
@@ -389,6 +390,11 @@ r433_batch *r433_batch_create(r433_flow_cfg const *cfg, r433_dev_timing const *d
     }
     if (n_devs > 2048) {
         fail(R433_EINVAL, "at most 2048 devices per batch engine");
+        return nullptr;
+    }
+    if ((cfg->input_format == R433_IN_CS8 && cfg->sample_size != 2) || (cfg->input_format == R433_IN_CF32 && cfg->sample_size != 4)
+            || cfg->input_format > R433_IN_CF32) {
+        fail(R433_EINVAL, "input_format: cs8 goes with sample_size 2, cf32 with sample_size 4");
         return nullptr;
     }
     if (r433_device_count() < 0)
@@ -481,6 +487,7 @@ void r433_batch_destroy(r433_batch *b)
     b->d_pkg_blob.release();
     b->d_events.release();
     b->d_stage.release();
+    b->d_converted.release();
     b->h_scal.release();
     b->h_frame_sums.release();
     b->h_pkg_blob.release();
@@ -569,6 +576,29 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
         return fail(R433_EINVAL, "captures are limited to 4 GiB each");
     hipStream_t st = (hipStream_t)stream;
     uint32_t const ss = b->cfg.sample_size;
+    if (b->cfg.input_format != R433_IN_NATIVE) {
+        // The reference converts these formats while it loads a file (src/rtl_433.c:1811-1834): one HBM-bound
+        // map into an internal buffer, then everything below sees cu8 / cs16 like the reference's flow does.
+        uint32_t const shrink = b->cfg.input_format == R433_IN_CF32 ? 2 : 1; // 8 B -> 4 B per sample
+        uint64_t in_max = 0;
+        b->conv_bytes.resize(n_streams);
+        for (uint32_t i = 0; i < n_streams; ++i) {
+            uint64_t const nb = stream_bytes ? stream_bytes[i] : stride_bytes;
+            if (nb > stride_bytes)
+                return fail(R433_EINVAL, "capture %u is longer than the stride", i);
+            in_max = std::max(in_max, nb);
+            b->conv_bytes[i] = (uint32_t)(nb / (shrink * ss) * ss); // whole samples
+        }
+        uint64_t const out_stride = ((in_max / shrink) + 15) & ~15ull;
+        int rc0;
+        if ((rc0 = b->d_converted.ensure((size_t)n_streams * out_stride + 16)))
+            return rc0;
+        launch_convert((int)b->cfg.input_format, d_iq, stride_bytes, b->d_converted.p, out_stride, in_max, n_streams, st);
+        HIP_TRY(hipGetLastError());
+        d_iq = b->d_converted.p;
+        stride_bytes = out_stride;
+        stream_bytes = b->conv_bytes.data();
+    }
     uint32_t max_bytes = 0;
     if (stream_bytes) {
         for (uint32_t i = 0; i < n_streams; ++i) {
@@ -1435,6 +1465,30 @@ static int run_envelope(int kind, void const *d_iq, void *d_env, uint32_t n, uin
     launch_envelope(kind, d_iq, (uint16_t *)d_env, n, d_sum, st);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+static int run_convert(int fmt, void const *d_in, void *d_out, uint64_t n, void *stream)
+{
+    if (r433_device_count() < 0)
+        return R433_ENODEV;
+    if (!d_in || !d_out)
+        return fail(R433_EINVAL, "null buffer");
+    if (((uintptr_t)d_in & 15u) || ((uintptr_t)d_out & 15u))
+        return fail(R433_EINVAL, "buffers must be 16-byte aligned");
+    uint64_t const in_bytes = fmt == 1 ? n : n * 4;
+    launch_convert(fmt, d_in, in_bytes, d_out, fmt == 1 ? n : n * 2, in_bytes, 1, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int r433_convert_cs8_cu8(void const *d_in, void *d_out, uint64_t n, void *stream)
+{
+    return run_convert(1, d_in, d_out, n, stream);
+}
+
+int r433_convert_cf32_cs16(void const *d_in, void *d_out, uint64_t n, void *stream)
+{
+    return run_convert(2, d_in, d_out, n, stream);
 }
 
 int r433_envelope_detect(void const *d_iq, void *d_env, uint32_t n, uint32_t *d_sum, void *stream)

@@ -38,9 +38,9 @@ def load_device_table(path=DEFAULT_DEVICE_TABLE):
 
 def flow_cfg(sample_size=2, samp_rate=250000, fpdm=0, enable_fm=1, use_mag_est=0, fm_low_pass=0.0,
              level_limit_db=0.0, min_level_db=-12.1442, min_snr_db=9.0, auto_level=0.0, frame_samples=0,
-             center_frequency=433920000):
+             center_frequency=433920000, input_format=0):
     return FlowCfg(sample_size, samp_rate, frame_samples, fpdm, use_mag_est, enable_fm, fm_low_pass,
-                   level_limit_db, min_level_db, min_snr_db, auto_level, center_frequency)
+                   level_limit_db, min_level_db, min_snr_db, auto_level, center_frequency, input_format)
 
 
 class BatchEngine:

@@ -37,7 +37,7 @@ def emu_run(iq_list, ss, rate, devs, fpdm=0, taps=False, enable_fm=1, center_fre
         eng.set_split(split)
     tap_bufs = None
     if taps:
-        ns = max(1, stride // ss)
+        ns = max(1, stride // (ss * (2 if kw.get('input_format') == 2 else 1)))
         tap_bufs = [np.zeros((n, ns), dtype=np.uint16), np.zeros((n, ns), dtype=np.int16), np.zeros((n, ns), dtype=np.int16)]
         _lib.check(eng.L.r433_batch_set_taps(eng.h, *[C.c_void_p(t.ctypes.data) for t in tap_bufs], ns), "set_taps")
     npk = eng.run_ptr(arena.ctypes.data, stride, n, lens)

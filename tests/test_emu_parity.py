@@ -209,3 +209,37 @@ def test_mixed_2000k_autolevel_filter(default_devices):
     n = iq.nbytes // 2
     assert np.array_equal(g["taps"][1][0, :n], o["am"]) and np.array_equal(g["taps"][2][0, :n], o["fm"])
     assert g["packages"][0] == o["packages"] and g["events"][0] == o["events"]
+
+
+def _cf32_to_cs16_like_c(f):
+    """(int)(f * INT16_MAX) clamped to +-INT16_MAX as the reference's file loop does it on x86 (src/rtl_433.c:1814-1824)."""
+    p = f.astype(np.float32) * np.float32(32767.0)
+    bad = ~np.isfinite(p) | (p >= np.float32(2147483648.0)) | (p < np.float32(-2147483648.0))
+    s = np.where(bad, np.int64(-2147483648), np.trunc(np.where(bad, 0, p)).astype(np.int64))
+    return np.clip(s, -32767, 32767).astype(np.int16)
+
+
+def test_input_formats_cs8_cf32(default_devices):
+    """cs8 and cf32 inputs are converted on the device like the reference converts them on load."""
+    from tests.emu import host
+    devs = default_devices[0][:30]
+    cu8 = [synth.ook_stream(60, 30000)[0], synth.fsk_stream_cu8(61, 20001)]
+    cs8 = [(a ^ 0x80) for a in cu8]  # the int8 file a cs8 recorder would have written
+    cfg = po.default_flow_cfg(2, 250000)
+    pk, ev, _ = _oracle_batch(cu8, devs, cfg)
+    g = host.emu_run(cs8, 2, 250000, devs, input_format=1)
+    assert g["packages"][0] == pk and g["events"][0] == ev
+
+    rng = np.random.default_rng(62)
+    cs16 = synth.fsk_stream_cs16(63, 30000)
+    f = (cs16.astype(np.float32) / np.float32(32767.0)) * np.float32(1.3)  # some samples clip
+    f[100:110] = [np.nan, np.inf, -np.inf, 1e20, -1e20, 65536.5, -65536.5, 1.0, -1.0, 0.99999]
+    f += rng.normal(0, 1e-6, f.size).astype(np.float32)
+    want16 = _cf32_to_cs16_like_c(f)
+    cfg4 = po.default_flow_cfg(4, 1024000, fpdm=1)
+    pk, ev, _ = _oracle_batch([want16], devs, cfg4)
+    g = host.emu_run([f.view(np.uint8)], 4, 1024000, devs, fpdm=1, center_frequency=868000000, input_format=2, taps=True)
+    o = po.oracle_flow(want16, devs, cfg4, taps=True)
+    n = want16.size // 2
+    assert np.array_equal(g["taps"][0][0, :n], o["env"])
+    assert g["packages"][0] == pk and g["events"][0] == ev

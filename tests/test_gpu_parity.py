@@ -220,3 +220,41 @@ def test_fuzz_cases_on_gpu(seed, monkeypatch):
         assert fuzz_emu.one_case(seed, fuzz_emu.gpu_run) is None
     finally:
         os.environ.pop("R433_SPLIT_BLIND", None)
+
+
+def test_input_formats_cs8_cf32(default_devices):
+    """cs8 / cf32 inputs converted on the device (reference src/rtl_433.c:1811-1834), incl. NaN / out-of-range floats."""
+    import torch
+    from rtl_433_amd import synth
+    from rtl_433_amd.engine import BatchEngine, flow_cfg
+    from tests.test_emu_parity import _cf32_to_cs16_like_c
+    devs = default_devices[0]
+
+    def run(arr_list, ss, rate, **kw):
+        lens = np.array([a.nbytes for a in arr_list], dtype=np.uint32)
+        stride = int((lens.max() + 15) // 16 * 16)
+        hostbuf = np.zeros((len(arr_list), stride), dtype=np.uint8)
+        for i, a in enumerate(arr_list):
+            hostbuf[i, :a.nbytes] = a.view(np.uint8)
+        eng = BatchEngine(flow_cfg(ss, rate, **kw), devs)
+        eng.run(torch.from_numpy(hostbuf).cuda(), lens)
+        out = eng.packages()[0], eng.events()[0]
+        eng.close()
+        return out
+
+    cu8 = [synth.ook_stream(60, 300000)[0], synth.fsk_stream_cu8(61, 200001)]
+    cfg = po.default_flow_cfg(2, 250000)
+    pk_o, ev_o, base = b"", b"", 0
+    for s, a in enumerate(cu8):
+        o = po.oracle_flow(a, devs, cfg, stream_index=s, pkg_base=base)
+        pk_o, ev_o, base = pk_o + o["packages"], ev_o + o["events"], base + o["n_packages"]
+    assert run([a ^ 0x80 for a in cu8], 2, 250000, input_format=1) == (pk_o, ev_o)
+
+    rng = np.random.default_rng(62)
+    cs16 = synth.fsk_stream_cs16(63, 300000)
+    f = (cs16.astype(np.float32) / np.float32(32767.0)) * np.float32(1.3)
+    f[100:110] = [np.nan, np.inf, -np.inf, 1e20, -1e20, 65536.5, -65536.5, 1.0, -1.0, 0.99999]
+    f += rng.normal(0, 1e-6, f.size).astype(np.float32)
+    want16 = _cf32_to_cs16_like_c(f)
+    o = po.oracle_flow(want16, devs, po.default_flow_cfg(4, 1024000, fpdm=1))
+    assert run([f.view(np.uint8)], 4, 1024000, fpdm=1, center_frequency=868000000, input_format=2) == (o["packages"], o["events"])
