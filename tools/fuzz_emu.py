@@ -82,6 +82,21 @@ def make_capture(rng, ss, rate):
     return out
 
 
+BIG = False  # --gpu: some cases are captures long enough for the automatic split (>= 2^20 samples)
+
+
+def long_ook(rng, rate):
+    n = int(rng.integers(1100000, 2600000))
+    segs = [(int(rng.integers(500, 30000)), False)]
+    while sum(s[0] for s in segs) < n:
+        short = int(rng.integers(20, 300))
+        for _b in range(int(rng.integers(8, 120))):
+            segs += [(short * int(rng.integers(1, 4)), True), (short * int(rng.integers(1, 4)), False)]
+        segs.append((int(rng.integers(2000, 300000)), False))
+    mask = synth._segments_to_mask(segs, n)
+    return synth.modulate_cu8(mask, rng, rate, float(rng.uniform(-80e3, 80e3)), float(rng.choice([15, 40, 100])), float(rng.choice([0, 1, 2, 4, 9])))
+
+
 def one_case(seed, run=None):
     """run(caps, ss, rate, devs, fpdm=, taps=, enable_fm=, split=, **flow options) -> dict like tests.emu.host.emu_run"""
     run = run or host.emu_run
@@ -114,6 +129,10 @@ def one_case(seed, run=None):
             devs = None
     caps = [make_capture(rng, ss, rate) for _ in range(int(rng.integers(1, 4)))]
     split = int(rng.choice([0, 0, 4096, 8192, 20000]))
+    if BIG and ss == 2 and rng.random() < 0.25:
+        caps = [long_ook(rng, rate)] + caps[:1]
+        split = int(rng.choice([1, 1, 65536, 200000]))  # 1 = R433_SPLIT_AUTO
+        kw.pop("frame_samples", None) if kw.get("frame_samples", 65536) < 2048 else None
     if split and rng.random() < 0.5:
         os.environ["R433_SPLIT_BLIND"] = "1"
     else:
@@ -164,6 +183,7 @@ if __name__ == "__main__":
     if "--gpu" in sys.argv:
         sys.argv.remove("--gpu")
         runner = gpu_run
+        BIG = True
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     t0 = time.time()
