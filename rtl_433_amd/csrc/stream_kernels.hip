@@ -156,6 +156,11 @@ __device__ __forceinline__ v2s pk_max(v2s a, v2s b)
     v2s const m = a > b; // -1 where a is larger
     return (a & m) | (b & ~m);
 }
+__device__ __forceinline__ v2s pk_min(v2s a, v2s b)
+{
+    v2s const m = a < b;
+    return (a & m) | (b & ~m);
+}
 
 // C division by 64 / 1024 (truncating toward zero) without a divider
 __device__ __forceinline__ int div64(int v)
@@ -683,6 +688,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
         int am_l = 0, fm_l = 0;    // my sample of that block
         int a64_l = 0, f64_l = 0;  // am / 64, fm / 64 (C division) for the level and carrier averages
         int in_pk_l = 0;           // the two of them packed as 16-bit halves
+        int in_pkn_l = 0;          // the same with the carrier half negated (|f1| form of the average)
         int bmax = 0, bmin = 0;
         // chunk statistics (lane = chunk) and their suffix extrema, for jumping over whole chunks
         int const my_cmax = s_cmax[lane], my_cmin = s_cmin[lane];
@@ -835,6 +841,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                 a64_l = div64(am_l);
                 f64_l = div64(fm_l);
                 in_pk_l = (a64_l & 0xffff) | (f64_l << 16);
+                in_pkn_l = (a64_l & 0xffff) | (-f64_l << 16);
                 bmax = uni(max(s_cmax[base >> 5], s_cmax[(base >> 5) + 1]));
                 bmin = uni(min(s_cmin[base >> 5], s_cmin[(base >> 5) + 1]));
                 loaded = base;
@@ -915,7 +922,10 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                 unsigned long long cand = __ballot(in_seg && am_l < thr_ub - hys_ub);
                 int h = det.high, f1 = det.ook_f1;
                 bool const feed = det.ook_num == 0; // first pulse of a package: the FSK sub-detector listens (pulse_detect.c:368-375)
-                bool const packed = !feed && h >= 0 && h <= 32767 && cfg.min_high >= 0 && cfg.min_high <= 32767;
+                bool const packed = uni((int)(!feed && h >= 0 && h <= 32767 && cfg.min_high >= 0 && cfg.min_high <= 32767)) != 0;
+                int const fl6 = uni(cfg.min_high >> 6);
+                unsigned long long const okp = __ballot(a64_l >= fl6 && f64_l >= 0);
+                unsigned long long const okn = __ballot(a64_l >= fl6 && f64_l <= 0 && f64_l > -512);
                 int j = i;
                 for (;;) {
                     k = cand ? base + (__ffsll(cand) - 1) : e;
@@ -924,21 +934,59 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                     // leaves the hull of its start value and its inputs), so one packed instruction
                     // stream advances the two of them together.
                     if (packed) {
+                        // Where the plain form of the two averages is exact: the level cannot fall below its
+                        // floor while in/64 >= floor/64 (v - v/64 is monotone in v), and the carrier average
+                        // keeps its sign while its inputs have that sign -- then, with |f1| in the second half,
+                        // both C divisions are plain shifts (trunc(v / 64) = sign * (|v| >> 6)) and the clamp
+                        // never acts: 3 packed instructions per sample instead of 7.  The inputs of such a run
+                        // are rotated to lane 0 first: v_readlane with a constant lane costs a lone wavefront
+                        // far less than one with a computed lane (tools/ubench/ema.hip: 23 vs 35 clocks/sample).
+                        j = uni(j);
+                        int const kk = uni(k);
                         v2s hv = {(short)h, (short)f1};
                         v2s const floor_v = {(short)cfg.min_high, (short)-32768};
                         v2s const m63 = {63, 63};
-                        for (; j + 8 <= k; j += 8) { // taken branches are the expensive instruction here
+                        while (j < kk) {
+                            int const f1s = uni((int)hv[1]);
+                            bool const neg = f1s < 0;
+                            unsigned long long const bad = ~((neg ? okn : okp) >> (j - base));
+                            int const run = uni(f1s == -32768 ? 0 : min(kk - j, bad ? (int)__builtin_ctzll(bad) : 64));
+                            if (run >= 8) {
+                                v2s const sv = {1, (short)(neg ? -1 : 1)};
+                                int const rot = __builtin_amdgcn_ds_bpermute(((int)lane + (j - base)) << 2, neg ? in_pkn_l : in_pk_l);
+                                int const nb = run >> 3;
+                                v2s x = hv * sv;
 #pragma unroll
-                            for (int u = 0; u < 8; ++u) {
-                                v2s const in = as_v2s(__builtin_amdgcn_readlane(in_pk_l, j - base + u));
-                                v2s const q = (hv + ((hv >> 15) & m63)) >> 6; // hv / 64, truncating toward zero
-                                hv = pk_max(hv - q + in, floor_v);
+                                for (int b8 = 0; b8 < 8; ++b8) {
+                                    if (b8 >= nb)
+                                        break;
+#pragma unroll
+                                    for (int u = 0; u < 8; ++u) {
+                                        v2s const in = as_v2s(__builtin_amdgcn_readlane(rot, b8 * 8 + u));
+                                        x = x + (in - (x >> 6));
+                                    }
+                                }
+                                hv = x * sv; // the sign cannot have flipped (the magnitude may have reached 0: either sign then)
+                                j += nb * 8;
+                                continue;
                             }
-                        }
-                        for (; j < k; ++j) {
-                            v2s const in = as_v2s(__builtin_amdgcn_readlane(in_pk_l, j - base));
-                            v2s const q = (hv + ((hv >> 15) & m63)) >> 6;
-                            hv = pk_max(hv - q + in, floor_v);
+                            int const cnt = uni(min(8, kk - j));
+                            if (cnt == 8) {
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) {
+                                    v2s const in = as_v2s(__builtin_amdgcn_readlane(in_pk_l, j - base + u));
+                                    v2s const q = (hv + ((hv >> 15) & m63)) >> 6; // hv / 64, truncating toward zero
+                                    hv = pk_max(hv - q + in, floor_v);
+                                }
+                            }
+                            else {
+                                for (int u = 0; u < cnt; ++u) {
+                                    v2s const in = as_v2s(__builtin_amdgcn_readlane(in_pk_l, j - base + u));
+                                    v2s const q = (hv + ((hv >> 15) & m63)) >> 6;
+                                    hv = pk_max(hv - q + in, floor_v);
+                                }
+                            }
+                            j += cnt;
                         }
                         h = hv[0];
                         f1 = hv[1];
