@@ -202,6 +202,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     det_ms, tot_ms, disp_s, n_pkgs = run_steps(args.steps)
+    if os.environ.get("R433_BENCH_TRACE"):  # per-step host/GPU leg times, for pipeline diagnosis
+        print("trace host_ms", [round(x * 1e3, 2) for x in disp_s], "leg_ms", [round(x, 2) for x in tot_ms], file=sys.stderr)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()

@@ -172,7 +172,7 @@ __device__ __forceinline__ int div1024(int v)
     return (v + ((v >> 31) & 1023)) >> 10;
 }
 
-template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wave(StreamParams p)
+template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_wave(StreamParams p)
 {
     using G = Geom<SS>;
     __shared__ __attribute__((aligned(16))) uint8_t s_env[64 * kPitch16];
@@ -228,7 +228,18 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
 
     // profiling aid (RUN_DBG_TIMING): shader-clock ticks per phase, returned in unused StreamState slots
     bool const timing = (p.flags & RUN_DBG_TIMING) != 0;
-    long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // A+B, idle, gap, pulse, gap-start, general step, resolve, iterations
+    // phase timing (RUN_DBG_TIMING only): A+B, idle, gap, pulse, gap-start, general step, resolve, iterations.
+    // In LDS behind a scalar branch: an array in registers costs a select chain per update even when unused.
+    __shared__ long long s_tk[8];
+    if (timing && lane < 8)
+        s_tk[lane] = 0;
+    auto tick = [&](int slot, long long since) {
+        if (timing) {
+            long long const d = (long long)clock64() - since;
+            if (lane == 0)
+                s_tk[slot] += d;
+        }
+    };
     auto now = [&]() -> long long { return timing ? (long long)clock64() : 0ll; };
 
     uint4 pf[G::loads];
@@ -681,7 +692,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
             }
         }
 
-        tk[0] += now() - t_tile;
+        tick(0, t_tile);
         // ================= phase C: pulse detector =================
         int i = (p.flags & RUN_DBG_SKIP_DETECT) ? n_t : 0;
         int loaded = -1;           // block whose samples the lanes hold
@@ -755,7 +766,8 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
         while (i < n_t) {
             long long const t_it = now();
             int const st_it = det.state;
-            tk[7] += 1;
+            if (timing && lane == 0)
+                s_tk[7] += 1;
             if (dc == 0) { // a new frame == a new push_sdr_flow call
                 flen = (int)min(my_n - (t0 + (uint32_t)i), F);
                 if (p.frame_min_high) // pulse_detect_set_levels before this frame's detection, r_flow.c:180-186
@@ -828,7 +840,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                         frame += 1;
                         dc = 0;
                     }
-                    tk[st_it == ST_IDLE ? 1 : 2] += now() - t_it;
+                    tick(st_it == ST_IDLE ? 1 : 2, t_it);
                     continue;
                 }
             }
@@ -850,6 +862,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
             int const st = det.state;
 
             int k = i; // fast paths run [i, k); the general step takes over at k
+            bool settled = false; // ... unless the fast path has also dealt with what happens at the end of its run
             if (st == ST_IDLE) {
                 if (det.lead_in <= 1024) { // no pulse can start during the lead-in (pulse_detect.c:310)
                     k = min(e, i + (1025 - det.lead_in));
@@ -910,6 +923,14 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                 int const ke = togo < (long long)(e - i) ? i + (int)togo : e;
                 k = min(ka, ke);
                 det.run += k - i;
+                if (ka <= ke && ka < e && !det.eop_spurious && det.ook_num + 1 < R433_PD_MAX_PULSES) {
+                    // the next pulse begins at ka (pulse_detect.c:425-440): the pair is complete
+                    ook_push_pair(det, det.run + 1);
+                    det.run = 0;
+                    det.state = ST_PULSE;
+                    k = ka + 1;
+                    settled = true;
+                }
             }
             else if (st == ST_PULSE) {
                 // the level estimate cannot climb above max(high, block max); below the threshold that
@@ -927,6 +948,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                 unsigned long long const okp = __ballot(a64_l >= fl6 && f64_l >= 0);
                 unsigned long long const okn = __ballot(a64_l >= fl6 && f64_l <= 0 && f64_l > -512);
                 int j = i;
+                bool fall = false;
                 for (;;) {
                     k = cand ? base + (__ffsll(cand) - 1) : e;
                     // pulse arm without the falling edge, pulse_detect.c:359-366: the level and carrier
@@ -1008,8 +1030,10 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                         thr = (int)(int16_t)cfg.fixed_high;
                     int const hys = (int)(int16_t)(thr / 8);
                     int const am_k = __builtin_amdgcn_readlane(am_l, k - base);
-                    if (am_k < thr - hys)
-                        break; // falling edge: the general step takes it from here
+                    if (am_k < thr - hys) {
+                        fall = true;
+                        break;
+                    }
                     h += __builtin_amdgcn_readlane(a64_l, k - base) - div64(h);
                     h = max(h, cfg.min_high);
                     f1 += __builtin_amdgcn_readlane(f64_l, k - base) - div64(f1);
@@ -1021,6 +1045,17 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                 det.high = h;
                 det.ook_f1 = f1;
                 det.run += k - i;
+                if (fall && !feed && det.run + 1 >= 10) {
+                    // the pulse ends at k (pulse_detect.c:340-357, the regular case): its width is known, the
+                    // debounce of the gap begins.  (Spurious short pulses and the first pulse of a package,
+                    // which the FSK detector listens to, go through the general step.)
+                    det.cur_pulse = det.run + 1;
+                    det.max_pulse = max(det.cur_pulse, det.max_pulse);
+                    det.run = 0;
+                    det.state = ST_GAP_START;
+                    k += 1;
+                    settled = true;
+                }
             }
             else if (st == ST_GAP_START && det.ook_num > 0 && det.fsk_num <= 16) {
                 // debouncing the end of a pulse (pulse_detect.c:376-421) once the FSK candidate is out of
@@ -1050,7 +1085,9 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                     det.run += e - i;
                     k = e;
                 }
-                // everything up to k is done: skip the general step this round
+                settled = true;
+            }
+            if (settled) { // everything up to k is done: no general step this round
                 int const done = k - i;
                 i += done;
                 dc += done;
@@ -1059,12 +1096,12 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                     frame += 1;
                     dc = 0;
                 }
-                tk[4] += now() - t_it;
+                tick(st_it == ST_IDLE ? 1 : st_it == ST_GAP ? 2 : st_it == ST_PULSE ? 3 : 4, t_it);
                 continue;
             }
 
+            tick(st_it == ST_IDLE ? 1 : st_it == ST_GAP ? 2 : st_it == ST_PULSE ? 3 : 4, t_it);
             long long const t_fast = now();
-            tk[st_it == ST_IDLE ? 1 : st_it == ST_GAP ? 2 : st_it == ST_PULSE ? 3 : 4] += t_fast - t_it;
             int consumed = k - i;
             if (k < e) { // the exact general step: candidate samples, and the states that need every sample
                 int j = k;
@@ -1088,11 +1125,11 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
                 frame += 1;
                 dc = 0;
             }
-            tk[5] += now() - t_fast;
+            tick(5, t_fast);
         }
         long long const t_res = now();
         resolve_low(n_t);
-        tk[6] += now() - t_res; // the samples leave LDS with the tile
+        tick(6, t_res); // the samples leave LDS with the tile
     }
 
     int const end_state = det.state, end_high = det.high; // before the flush: what the next segment has to agree with
@@ -1113,8 +1150,8 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) void k_wa
         S.input_pos = input_pos;
         S.frame = frame;
         if (timing) {
-            S.lpf_y = (int)(tk[0] >> 6), S.lpf_x = (int)(tk[1] >> 6), S.fm_xr = (int)(tk[2] >> 6), S.fm_xi = (int)(tk[3] >> 6);
-            S.fm_xf = (int)(tk[4] >> 6), S.fm_yf = (int)(tk[5] >> 6), S.state = (int)(tk[6] >> 6), S.run = (int)tk[7];
+            S.lpf_y = (int)(s_tk[0] >> 6), S.lpf_x = (int)(s_tk[1] >> 6), S.fm_xr = (int)(s_tk[2] >> 6), S.fm_xi = (int)(s_tk[3] >> 6);
+            S.fm_xf = (int)(s_tk[4] >> 6), S.fm_yf = (int)(s_tk[5] >> 6), S.state = (int)(s_tk[6] >> 6), S.run = (int)s_tk[7];
         }
     }
 }
