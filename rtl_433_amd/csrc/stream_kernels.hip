@@ -858,234 +858,242 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                 bmin = uni(min(s_cmin[base >> 5], s_cmin[(base >> 5) + 1]));
                 loaded = base;
             }
-            bool const in_seg = base + lane >= i && base + lane < e;
-            int const st = det.state;
-
-            int k = i; // fast paths run [i, k); the general step takes over at k
-            bool settled = false; // ... unless the fast path has also dealt with what happens at the end of its run
-            if (st == ST_IDLE) {
-                if (det.lead_in <= 1024) { // no pulse can start during the lead-in (pulse_detect.c:310)
-                    k = min(e, i + (1025 - det.lead_in));
-                    det.lead_in += k - i;
-                    int lo_est = det.low; // idle arm, pulse_detect.c:326-334
-                    for (int j = i; j < k; ++j) {
-                        int const dl = __builtin_amdgcn_readlane(am_l, j - base) - lo_est;
-                        lo_est += div1024(dl);
-                        lo_est += dl > 0 ? 1 : -1;
-                    }
-                    det.low = lo_est;
-                    det.high = max(cfg.ratio * lo_est, cfg.min_high);
-                }
-                else {
-                    // lowest threshold the idle state can present while it chases the noise floor in this block
-                    int const l_lo = min(det.low, min(lz_min, bmin)) - 1;
-                    int const l_hi = max(det.low, max(lz_max, bmax)) + 1;
-                    int thr = (int)(int16_t)((l_lo + min(cfg.min_high, cfg.max_high)) / 2);
-                    if (cfg.fixed_high != 0)
-                        thr = (int)(int16_t)cfg.fixed_high;
-                    int const hys = (int)(int16_t)(thr / 8);
-                    unsigned long long const m = __ballot(in_seg && am_l > thr + hys);
-                    k = m ? base + (__ffsll(m) - 1) : e;
-                    if (l_hi - l_lo < 1000) { // |am - low| < 1024 over everything pending: count, do not walk
-                        if (lz_n == 0)
-                            lz_from = i;
-                        lz_n += k - i;
-                        lz_min = min(lz_min, bmin);
-                        lz_max = max(lz_max, bmax);
-                    }
-                    else {
-                        resolve_low(i);
-                        int lo_est = det.low; // idle arm without the (impossible) pulse start, pulse_detect.c:326-334
-                        for (int j = i; j < k; ++j) {
+            // Legs inside this block.  A fast path covers [i0, k) and, where it can, also what happens at k (a
+            // regular pulse end, the end of the debounce, the next pulse's start): then the next leg starts
+            // right there, without going round the outer loop.  Otherwise the general step takes over at k.
+            int k = i;
+            bool settled = false;
+            for (;;) {
+                int const i0 = k;
+                bool const in_seg = base + lane >= i0 && base + lane < e;
+                int const st = det.state;
+                settled = false;
+                if (st == ST_IDLE) {
+                    if (det.lead_in <= 1024) { // no pulse can start during the lead-in (pulse_detect.c:310)
+                        k = min(e, i0 + (1025 - det.lead_in));
+                        det.lead_in += k - i0;
+                        int lo_est = det.low; // idle arm, pulse_detect.c:326-334
+                        for (int j = i0; j < k; ++j) {
                             int const dl = __builtin_amdgcn_readlane(am_l, j - base) - lo_est;
                             lo_est += div1024(dl);
                             lo_est += dl > 0 ? 1 : -1;
                         }
-                        if (k > i) {
-                            det.low = lo_est;
-                            det.high = max(cfg.ratio * lo_est, cfg.min_high);
-                        }
-                    }
-                    if (k < e)
-                        resolve_low(k); // a pulse may start at k: the general step needs the exact floor
-                }
-            }
-            else if (st == ST_GAP) {
-                int thr = (int)(int16_t)((det.low + min(det.high, cfg.max_high)) / 2);
-                if (cfg.fixed_high != 0)
-                    thr = (int)(int16_t)cfg.fixed_high;
-                int const hys = (int)(int16_t)(thr / 8);
-                unsigned long long const m = __ballot(in_seg && am_l > thr + hys);
-                int const ka = m ? base + (__ffsll(m) - 1) : e;
-                // first sample whose gap count ends the package (pulse_detect.c:446-450)
-                long long const lim = min(max(10ll * det.max_pulse, 10ll * cfg.per_ms), 100ll * cfg.per_ms);
-                long long const togo = det.eop_spurious ? 0 : max(0ll, lim - (long long)det.run);
-                int const ke = togo < (long long)(e - i) ? i + (int)togo : e;
-                k = min(ka, ke);
-                det.run += k - i;
-                if (ka <= ke && ka < e && !det.eop_spurious && det.ook_num + 1 < R433_PD_MAX_PULSES) {
-                    // the next pulse begins at ka (pulse_detect.c:425-440): the pair is complete
-                    ook_push_pair(det, det.run + 1);
-                    det.run = 0;
-                    det.state = ST_PULSE;
-                    k = ka + 1;
-                    settled = true;
-                }
-            }
-            else if (st == ST_PULSE) {
-                // the level estimate cannot climb above max(high, block max); below the threshold that
-                // belongs to it no sample can be a falling edge
-                int const h_ub = max(det.high, bmax) + 1;
-                int thr_ub = (int)(int16_t)((det.low + min(h_ub, cfg.max_high)) / 2);
-                if (cfg.fixed_high != 0)
-                    thr_ub = (int)(int16_t)cfg.fixed_high;
-                int const hys_ub = (int)(int16_t)(thr_ub / 8);
-                unsigned long long cand = __ballot(in_seg && am_l < thr_ub - hys_ub);
-                int h = det.high, f1 = det.ook_f1;
-                bool const feed = det.ook_num == 0; // first pulse of a package: the FSK sub-detector listens (pulse_detect.c:368-375)
-                bool const packed = uni((int)(!feed && h >= 0 && h <= 32767 && cfg.min_high >= 0 && cfg.min_high <= 32767)) != 0;
-                int const fl6 = uni(cfg.min_high >> 6);
-                unsigned long long const okp = __ballot(a64_l >= fl6 && f64_l >= 0);
-                unsigned long long const okn = __ballot(a64_l >= fl6 && f64_l <= 0 && f64_l > -512);
-                int j = i;
-                bool fall = false;
-                for (;;) {
-                    k = cand ? base + (__ffsll(cand) - 1) : e;
-                    // pulse arm without the falling edge, pulse_detect.c:359-366: the level and carrier
-                    // averages v += in/64 - v/64 (C division).  Both live in 16 bits (an average never
-                    // leaves the hull of its start value and its inputs), so one packed instruction
-                    // stream advances the two of them together.
-                    if (packed) {
-                        // Where the plain form of the two averages is exact: the level cannot fall below its
-                        // floor while in/64 >= floor/64 (v - v/64 is monotone in v), and the carrier average
-                        // keeps its sign while its inputs have that sign -- then, with |f1| in the second half,
-                        // both C divisions are plain shifts (trunc(v / 64) = sign * (|v| >> 6)) and the clamp
-                        // never acts: 3 packed instructions per sample instead of 7.  The inputs of such a run
-                        // are rotated to lane 0 first: v_readlane with a constant lane costs a lone wavefront
-                        // far less than one with a computed lane (tools/ubench/ema.hip: 23 vs 35 clocks/sample).
-                        j = uni(j);
-                        int const kk = uni(k);
-                        v2s hv = {(short)h, (short)f1};
-                        v2s const floor_v = {(short)cfg.min_high, (short)-32768};
-                        v2s const m63 = {63, 63};
-                        while (j < kk) {
-                            int const f1s = uni((int)hv[1]);
-                            bool const neg = f1s < 0;
-                            unsigned long long const bad = ~((neg ? okn : okp) >> (j - base));
-                            int const run = uni(f1s == -32768 ? 0 : min(kk - j, bad ? (int)__builtin_ctzll(bad) : 64));
-                            if (run >= 8) {
-                                v2s const sv = {1, (short)(neg ? -1 : 1)};
-                                int const rot = __builtin_amdgcn_ds_bpermute(((int)lane + (j - base)) << 2, neg ? in_pkn_l : in_pk_l);
-                                int const nb = run >> 3;
-                                v2s x = hv * sv;
-#pragma unroll
-                                for (int b8 = 0; b8 < 8; ++b8) {
-                                    if (b8 >= nb)
-                                        break;
-#pragma unroll
-                                    for (int u = 0; u < 8; ++u) {
-                                        v2s const in = as_v2s(__builtin_amdgcn_readlane(rot, b8 * 8 + u));
-                                        x = x + (in - (x >> 6));
-                                    }
-                                }
-                                hv = x * sv; // the sign cannot have flipped (the magnitude may have reached 0: either sign then)
-                                j += nb * 8;
-                                continue;
-                            }
-                            int const cnt = uni(min(8, kk - j));
-                            if (cnt == 8) {
-#pragma unroll
-                                for (int u = 0; u < 8; ++u) {
-                                    v2s const in = as_v2s(__builtin_amdgcn_readlane(in_pk_l, j - base + u));
-                                    v2s const q = (hv + ((hv >> 15) & m63)) >> 6; // hv / 64, truncating toward zero
-                                    hv = pk_max(hv - q + in, floor_v);
-                                }
-                            }
-                            else {
-                                for (int u = 0; u < cnt; ++u) {
-                                    v2s const in = as_v2s(__builtin_amdgcn_readlane(in_pk_l, j - base + u));
-                                    v2s const q = (hv + ((hv >> 15) & m63)) >> 6;
-                                    hv = pk_max(hv - q + in, floor_v);
-                                }
-                            }
-                            j += cnt;
-                        }
-                        h = hv[0];
-                        f1 = hv[1];
+                        det.low = lo_est;
+                        det.high = max(cfg.ratio * lo_est, cfg.min_high);
                     }
                     else {
-                        for (; j < k; ++j) {
-                            h += __builtin_amdgcn_readlane(a64_l, j - base) - div64(h);
-                            h = max(h, cfg.min_high);
-                            f1 += __builtin_amdgcn_readlane(f64_l, j - base) - div64(f1);
-                            if (feed)
-                                fsk_feed(det, cfg, __builtin_amdgcn_readlane(fm_l, j - base));
+                        // lowest threshold the idle state can present while it chases the noise floor in this block
+                        int const l_lo = min(det.low, min(lz_min, bmin)) - 1;
+                        int const l_hi = max(det.low, max(lz_max, bmax)) + 1;
+                        int thr = (int)(int16_t)((l_lo + min(cfg.min_high, cfg.max_high)) / 2);
+                        if (cfg.fixed_high != 0)
+                            thr = (int)(int16_t)cfg.fixed_high;
+                        int const hys = (int)(int16_t)(thr / 8);
+                        unsigned long long const m = __ballot(in_seg && am_l > thr + hys);
+                        k = m ? base + (__ffsll(m) - 1) : e;
+                        if (l_hi - l_lo < 1000) { // |am - low| < 1024 over everything pending: count, do not walk
+                            if (lz_n == 0)
+                                lz_from = i0;
+                            lz_n += k - i0;
+                            lz_min = min(lz_min, bmin);
+                            lz_max = max(lz_max, bmax);
                         }
+                        else {
+                            resolve_low(i0);
+                            int lo_est = det.low; // idle arm without the (impossible) pulse start, pulse_detect.c:326-334
+                            for (int j = i0; j < k; ++j) {
+                                int const dl = __builtin_amdgcn_readlane(am_l, j - base) - lo_est;
+                                lo_est += div1024(dl);
+                                lo_est += dl > 0 ? 1 : -1;
+                            }
+                            if (k > i0) {
+                                det.low = lo_est;
+                                det.high = max(cfg.ratio * lo_est, cfg.min_high);
+                            }
+                        }
+                        if (k < e)
+                            resolve_low(k); // a pulse may start at k: the general step needs the exact floor
                     }
-                    if (k >= e)
-                        break;
-                    // candidate: decide with the exact level.  Not an edge -> it is one more pulse sample.
-                    int thr = (int)(int16_t)((det.low + min(h, cfg.max_high)) / 2);
+                }
+                else if (st == ST_GAP) {
+                    int thr = (int)(int16_t)((det.low + min(det.high, cfg.max_high)) / 2);
                     if (cfg.fixed_high != 0)
                         thr = (int)(int16_t)cfg.fixed_high;
                     int const hys = (int)(int16_t)(thr / 8);
-                    int const am_k = __builtin_amdgcn_readlane(am_l, k - base);
-                    if (am_k < thr - hys) {
-                        fall = true;
-                        break;
+                    unsigned long long const m = __ballot(in_seg && am_l > thr + hys);
+                    int const ka = m ? base + (__ffsll(m) - 1) : e;
+                    // first sample whose gap count ends the package (pulse_detect.c:446-450)
+                    long long const lim = min(max(10ll * det.max_pulse, 10ll * cfg.per_ms), 100ll * cfg.per_ms);
+                    long long const togo = det.eop_spurious ? 0 : max(0ll, lim - (long long)det.run);
+                    int const ke = togo < (long long)(e - i0) ? i0 + (int)togo : e;
+                    k = min(ka, ke);
+                    det.run += k - i0;
+                    if (ka <= ke && ka < e && !det.eop_spurious && det.ook_num + 1 < R433_PD_MAX_PULSES) {
+                        // the next pulse begins at ka (pulse_detect.c:425-440): the pair is complete
+                        ook_push_pair(det, det.run + 1);
+                        det.run = 0;
+                        det.state = ST_PULSE;
+                        k = ka + 1;
+                        settled = true;
                     }
-                    h += __builtin_amdgcn_readlane(a64_l, k - base) - div64(h);
-                    h = max(h, cfg.min_high);
-                    f1 += __builtin_amdgcn_readlane(f64_l, k - base) - div64(f1);
-                    if (feed)
-                        fsk_feed(det, cfg, __builtin_amdgcn_readlane(fm_l, k - base));
-                    j = k + 1;
-                    cand &= cand - 1; // next candidate
                 }
-                det.high = h;
-                det.ook_f1 = f1;
-                det.run += k - i;
-                if (fall && !feed && det.run + 1 >= 10) {
-                    // the pulse ends at k (pulse_detect.c:340-357, the regular case): its width is known, the
-                    // debounce of the gap begins.  (Spurious short pulses and the first pulse of a package,
-                    // which the FSK detector listens to, go through the general step.)
-                    det.cur_pulse = det.run + 1;
-                    det.max_pulse = max(det.cur_pulse, det.max_pulse);
-                    det.run = 0;
-                    det.state = ST_GAP_START;
-                    k += 1;
+                else if (st == ST_PULSE) {
+                    // the level estimate cannot climb above max(high, block max); below the threshold that
+                    // belongs to it no sample can be a falling edge
+                    int const h_ub = max(det.high, bmax) + 1;
+                    int thr_ub = (int)(int16_t)((det.low + min(h_ub, cfg.max_high)) / 2);
+                    if (cfg.fixed_high != 0)
+                        thr_ub = (int)(int16_t)cfg.fixed_high;
+                    int const hys_ub = (int)(int16_t)(thr_ub / 8);
+                    unsigned long long cand = __ballot(in_seg && am_l < thr_ub - hys_ub);
+                    int h = det.high, f1 = det.ook_f1;
+                    bool const feed = det.ook_num == 0; // first pulse of a package: the FSK sub-detector listens (pulse_detect.c:368-375)
+                    bool const packed = uni((int)(!feed && h >= 0 && h <= 32767 && cfg.min_high >= 0 && cfg.min_high <= 32767)) != 0;
+                    int const fl6 = uni(cfg.min_high >> 6);
+                    unsigned long long const okp = __ballot(a64_l >= fl6 && f64_l >= 0);
+                    unsigned long long const okn = __ballot(a64_l >= fl6 && f64_l <= 0 && f64_l > -512);
+                    int j = i0;
+                    bool fall = false;
+                    for (;;) {
+                        k = cand ? base + (__ffsll(cand) - 1) : e;
+                        // pulse arm without the falling edge, pulse_detect.c:359-366: the level and carrier
+                        // averages v += in/64 - v/64 (C division).  Both live in 16 bits (an average never
+                        // leaves the hull of its start value and its inputs), so one packed instruction
+                        // stream advances the two of them together.
+                        if (packed) {
+                            // Where the plain form of the two averages is exact: the level cannot fall below its
+                            // floor while in/64 >= floor/64 (v - v/64 is monotone in v), and the carrier average
+                            // keeps its sign while its inputs have that sign -- then, with |f1| in the second half,
+                            // both C divisions are plain shifts (trunc(v / 64) = sign * (|v| >> 6)) and the clamp
+                            // never acts: 3 packed instructions per sample instead of 7.  The inputs of such a run
+                            // are rotated to lane 0 first: v_readlane with a constant lane costs a lone wavefront
+                            // far less than one with a computed lane (tools/ubench/ema.hip: 23 vs 35 clocks/sample).
+                            j = uni(j);
+                            int const kk = uni(k);
+                            v2s hv = {(short)h, (short)f1};
+                            v2s const floor_v = {(short)cfg.min_high, (short)-32768};
+                            v2s const m63 = {63, 63};
+                            while (j < kk) {
+                                int const f1s = uni((int)hv[1]);
+                                bool const neg = f1s < 0;
+                                unsigned long long const bad = ~((neg ? okn : okp) >> (j - base));
+                                int const run = uni(f1s == -32768 ? 0 : min(kk - j, bad ? (int)__builtin_ctzll(bad) : 64));
+                                if (run >= 8) {
+                                    v2s const sv = {1, (short)(neg ? -1 : 1)};
+                                    int const rot = __builtin_amdgcn_ds_bpermute(((int)lane + (j - base)) << 2, neg ? in_pkn_l : in_pk_l);
+                                    int const nb = run >> 3;
+                                    v2s x = hv * sv;
+    #pragma unroll
+                                    for (int b8 = 0; b8 < 8; ++b8) {
+                                        if (b8 >= nb)
+                                            break;
+    #pragma unroll
+                                        for (int u = 0; u < 8; ++u) {
+                                            v2s const in = as_v2s(__builtin_amdgcn_readlane(rot, b8 * 8 + u));
+                                            x = x + (in - (x >> 6));
+                                        }
+                                    }
+                                    hv = x * sv; // the sign cannot have flipped (the magnitude may have reached 0: either sign then)
+                                    j += nb * 8;
+                                    continue;
+                                }
+                                int const cnt = uni(min(8, kk - j));
+                                if (cnt == 8) {
+    #pragma unroll
+                                    for (int u = 0; u < 8; ++u) {
+                                        v2s const in = as_v2s(__builtin_amdgcn_readlane(in_pk_l, j - base + u));
+                                        v2s const q = (hv + ((hv >> 15) & m63)) >> 6; // hv / 64, truncating toward zero
+                                        hv = pk_max(hv - q + in, floor_v);
+                                    }
+                                }
+                                else {
+                                    for (int u = 0; u < cnt; ++u) {
+                                        v2s const in = as_v2s(__builtin_amdgcn_readlane(in_pk_l, j - base + u));
+                                        v2s const q = (hv + ((hv >> 15) & m63)) >> 6;
+                                        hv = pk_max(hv - q + in, floor_v);
+                                    }
+                                }
+                                j += cnt;
+                            }
+                            h = hv[0];
+                            f1 = hv[1];
+                        }
+                        else {
+                            for (; j < k; ++j) {
+                                h += __builtin_amdgcn_readlane(a64_l, j - base) - div64(h);
+                                h = max(h, cfg.min_high);
+                                f1 += __builtin_amdgcn_readlane(f64_l, j - base) - div64(f1);
+                                if (feed)
+                                    fsk_feed(det, cfg, __builtin_amdgcn_readlane(fm_l, j - base));
+                            }
+                        }
+                        if (k >= e)
+                            break;
+                        // candidate: decide with the exact level.  Not an edge -> it is one more pulse sample.
+                        int thr = (int)(int16_t)((det.low + min(h, cfg.max_high)) / 2);
+                        if (cfg.fixed_high != 0)
+                            thr = (int)(int16_t)cfg.fixed_high;
+                        int const hys = (int)(int16_t)(thr / 8);
+                        int const am_k = __builtin_amdgcn_readlane(am_l, k - base);
+                        if (am_k < thr - hys) {
+                            fall = true;
+                            break;
+                        }
+                        h += __builtin_amdgcn_readlane(a64_l, k - base) - div64(h);
+                        h = max(h, cfg.min_high);
+                        f1 += __builtin_amdgcn_readlane(f64_l, k - base) - div64(f1);
+                        if (feed)
+                            fsk_feed(det, cfg, __builtin_amdgcn_readlane(fm_l, k - base));
+                        j = k + 1;
+                        cand &= cand - 1; // next candidate
+                    }
+                    det.high = h;
+                    det.ook_f1 = f1;
+                    det.run += k - i0;
+                    if (fall && !feed && det.run + 1 >= 10) {
+                        // the pulse ends at k (pulse_detect.c:340-357, the regular case): its width is known, the
+                        // debounce of the gap begins.  (Spurious short pulses and the first pulse of a package,
+                        // which the FSK detector listens to, go through the general step.)
+                        det.cur_pulse = det.run + 1;
+                        det.max_pulse = max(det.cur_pulse, det.max_pulse);
+                        det.run = 0;
+                        det.state = ST_GAP_START;
+                        k += 1;
+                        settled = true;
+                    }
+                }
+                else if (st == ST_GAP_START && det.ook_num > 0 && det.fsk_num <= 16) {
+                    // debouncing the end of a pulse (pulse_detect.c:376-421) once the FSK candidate is out of
+                    // the picture: either the signal comes back before the count reaches 10, or the gap begins.
+                    // (The candidate can still be in the picture after the first pulse: the sample that ends the
+                    // first debounce is fed to the FSK detector AFTER the `> 16 pulses` test, so the 17th FSK
+                    // pulse may arrive there and the reference then returns the FSK package at the end of the
+                    // NEXT pulse -- the general step does that.)
+                    int thr = (int)(int16_t)((det.low + min(det.high, cfg.max_high)) / 2);
+                    if (cfg.fixed_high != 0)
+                        thr = (int)(int16_t)cfg.fixed_high;
+                    int const hys = (int)(int16_t)(thr / 8);
+                    unsigned long long const m = __ballot(in_seg && am_l > thr + hys);
+                    int const ka = m ? base + (__ffsll(m) - 1) : e;   // first sample above the threshold again
+                    int const kg = i0 + max(0, 9 - det.run);            // sample at which the count reaches 10
+                    if (ka <= kg && ka < e) {
+                        det.run += (ka - i0) + 1 + det.cur_pulse;
+                        det.state = ST_PULSE;
+                        k = ka + 1;
+                    }
+                    else if (kg < e) {
+                        det.run += (kg - i0) + 1;
+                        det.state = ST_GAP;
+                        k = kg + 1;
+                    }
+                    else {
+                        det.run += e - i0;
+                        k = e;
+                    }
                     settled = true;
                 }
-            }
-            else if (st == ST_GAP_START && det.ook_num > 0 && det.fsk_num <= 16) {
-                // debouncing the end of a pulse (pulse_detect.c:376-421) once the FSK candidate is out of
-                // the picture: either the signal comes back before the count reaches 10, or the gap begins.
-                // (The candidate can still be in the picture after the first pulse: the sample that ends the
-                // first debounce is fed to the FSK detector AFTER the `> 16 pulses` test, so the 17th FSK
-                // pulse may arrive there and the reference then returns the FSK package at the end of the
-                // NEXT pulse -- the general step does that.)
-                int thr = (int)(int16_t)((det.low + min(det.high, cfg.max_high)) / 2);
-                if (cfg.fixed_high != 0)
-                    thr = (int)(int16_t)cfg.fixed_high;
-                int const hys = (int)(int16_t)(thr / 8);
-                unsigned long long const m = __ballot(in_seg && am_l > thr + hys);
-                int const ka = m ? base + (__ffsll(m) - 1) : e;   // first sample above the threshold again
-                int const kg = i + max(0, 9 - det.run);            // sample at which the count reaches 10
-                if (ka <= kg && ka < e) {
-                    det.run += (ka - i) + 1 + det.cur_pulse;
-                    det.state = ST_PULSE;
-                    k = ka + 1;
-                }
-                else if (kg < e) {
-                    det.run += (kg - i) + 1;
-                    det.state = ST_GAP;
-                    k = kg + 1;
-                }
-                else {
-                    det.run += e - i;
-                    k = e;
-                }
-                settled = true;
+                if (!settled || k >= e)
+                    break;
             }
             if (settled) { // everything up to k is done: no general step this round
                 int const done = k - i;

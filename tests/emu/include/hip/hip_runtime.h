@@ -164,6 +164,7 @@ static inline uint32_t __builtin_amdgcn_mbcnt_hi(uint32_t mask, uint32_t add)
     uint32_t m = lane <= 32 ? 0u : (mask & ((1u << (lane - 32)) - 1u));
     return add + (uint32_t)__builtin_popcount(m);
 }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline int __mul24(int a, int b) { return (int)((uint32_t)((a << 8) >> 8) * (uint32_t)((b << 8) >> 8)); }
 static inline long long clock64() { return 0; }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
