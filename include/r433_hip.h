@@ -177,6 +177,22 @@ int r433_magnitude_est_cs16(void const *d_iq, void *d_env, uint32_t n, uint32_t 
  * semantics for values no int can hold (they become -32767). */
 int r433_convert_cs8_cu8(void const *d_in, void *d_out, uint64_t n, void *stream);
 int r433_convert_cf32_cs16(void const *d_in, void *d_out, uint64_t n, void *stream);
+/* The -w dump formats (src/r_flow.c:385-489, named as in include/fileformat.h): what the reference writes next to
+ * its input, as one HBM-bound map on device buffers.  sample_size says what d_in holds (2 = cu8 IQ, 4 = cs16 IQ);
+ * for R433_DUMP_F32_AM / _FM d_in is the am / fm int16 stream (r433_batch_set_taps, the S16_AM / S16_FM dumps
+ * themselves).  n_out = number of output values: IQ components (2 per sample) for the *_IQ formats, samples for
+ * the others.  A format that equals the input (cu8 from cu8, cs16 from cs16, S16_AM, S16_FM) is a plain copy. */
+#define R433_DUMP_CU8_IQ 1  /* from cs16: x / 256 + 128 */
+#define R433_DUMP_CS16_IQ 2 /* from cu8: x * 256 - 32768 */
+#define R433_DUMP_CS8_IQ 3  /* cu8: x - 128, cs16: x >> 8 */
+#define R433_DUMP_CF32_IQ 4 /* cu8: (x - 128) / 128.0f, cs16: x / 32768.0f */
+#define R433_DUMP_S16_AM 5
+#define R433_DUMP_S16_FM 6
+#define R433_DUMP_F32_AM 7  /* am * (1.0f / 0x8000) */
+#define R433_DUMP_F32_FM 8
+#define R433_DUMP_F32_I 9   /* cu8: (I - 128) * (1.0f / 0x80), cs16: I * (1.0f / 0x8000) */
+#define R433_DUMP_F32_Q 10
+int r433_dump_convert(int format, uint32_t sample_size, void const *d_in, void *d_out, uint64_t n_out, void *stream);
 /* AMP_TO_DB / MAG_TO_DB of a frame sum (include/baseband.h:36-37, src/baseband.c:44,78) */
 float r433_level_db(uint32_t sum, uint32_t n, int is_magnitude);
 

@@ -379,3 +379,42 @@ def canonical_events(blob):
         at += total
     recs.sort(key=lambda r: r[0])
     return b"".join(r[1] for r in recs)
+
+
+# ---- -w dump formats: numpy restatement of reference src/r_flow.c:385-489 (TEST INFRASTRUCTURE) ----
+DUMP_FORMATS = ("cu8", "cs16", "cs8", "cf32", "am.s16", "fm.s16", "am.f32", "fm.f32", "i.f32", "q.f32")
+
+
+def dump_convert(fmt, sample_size, data):
+    """What the reference's dumper writes for `fmt` given the IQ stream (sample_size 2: uint8 components,
+    4: int16 components) -- or, for am.* / fm.*, given the am / fm int16 stream.  Returns bytes."""
+    if fmt in ("am.s16", "fm.s16"):                       # r_flow.c:436-443: the buffers as they are
+        return np.asarray(data, dtype=np.int16).tobytes()
+    if fmt in ("am.f32", "fm.f32"):                       # r_flow.c:444-455: v * (1.0f / 0x8000)
+        return (np.asarray(data, dtype=np.int16).astype(np.float32) * np.float32(1.0 / 0x8000)).tobytes()
+    if sample_size == 2:
+        c = np.asarray(data, dtype=np.uint8).astype(np.int32)
+        if fmt == "cu8":                                  # r_flow.c:396: iq_buf itself
+            return c.astype(np.uint8).tobytes()
+        if fmt == "cs16":                                 # :404-408  x * 256 - 32768
+            return (c * 256 - 32768).astype(np.int16).tobytes()
+        if fmt == "cs8":                                  # :412-415  x - 128
+            return (c - 128).astype(np.int8).tobytes()
+        if fmt == "cf32":                                 # :424-427  (x - 128) / 128.0f
+            return ((c - 128).astype(np.float32) / np.float32(128.0)).tobytes()
+        if fmt in ("i.f32", "q.f32"):                     # :456-479  (x - 128) * (1.0f / 0x80)
+            return ((c[(fmt == "q.f32")::2] - 128).astype(np.float32) * np.float32(1.0 / 0x80)).tobytes()
+    else:
+        c = np.asarray(data, dtype=np.int16).astype(np.int32)
+        if fmt == "cs16":
+            return c.astype(np.int16).tobytes()
+        if fmt == "cu8":                                  # :397-400  x / 256 + 128, C division, stored to uint8
+            q = np.where(c < 0, -((-c) // 256), c // 256)
+            return ((q + 128) & 0xFF).astype(np.uint8).tobytes()
+        if fmt == "cs8":                                  # :416-419  x >> 8
+            return (c >> 8).astype(np.int8).tobytes()
+        if fmt == "cf32":                                 # :428-431  x / 32768.0f
+            return (c.astype(np.float32) / np.float32(32768.0)).tobytes()
+        if fmt in ("i.f32", "q.f32"):                     # :466-468, :476-478  x * (1.0f / 0x8000)
+            return (c[(fmt == "q.f32")::2].astype(np.float32) * np.float32(1.0 / 0x8000)).tobytes()
+    raise ValueError(f"unknown dump format {fmt!r} for sample size {sample_size}")

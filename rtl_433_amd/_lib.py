@@ -48,6 +48,10 @@ PACKAGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p)
 
 _lib = None
 
+# -w dump formats (include/r433_hip.h R433_DUMP_*)
+DUMP_FORMATS = {"cu8": 1, "cs16": 2, "cs8": 3, "cf32": 4, "am.s16": 5, "fm.s16": 6, "am.f32": 7, "fm.f32": 8,
+                "i.f32": 9, "q.f32": 10}
+
 EXPORTS = [
     "r433_version", "r433_last_error", "r433_device_count", "r433_flow_cfg_default", "r433_level_db",
     "r433_batch_create", "r433_batch_destroy", "r433_batch_run", "r433_batch_packages", "r433_batch_events",
@@ -55,7 +59,7 @@ EXPORTS = [
     "r433_batch_split_stats", "r433_batch_set_profiling",
     "r433_batch_get_timing", "r433_batch_debug_state", "r433_batch_dispatch", "r433_batch_dispatch_mt", "r433_dispatch_current",
     "r433_plugin_digest_decode", "r433_envelope_detect", "r433_magnitude_est_cu8",
-    "r433_magnitude_est_cs16", "r433_convert_cs8_cu8", "r433_convert_cf32_cs16",
+    "r433_magnitude_est_cs16", "r433_convert_cs8_cu8", "r433_convert_cf32_cs16", "r433_dump_convert",
 ]
 
 
@@ -115,6 +119,8 @@ def bind(L):
     for f in (L.r433_convert_cs8_cu8, L.r433_convert_cf32_cs16):
         f.restype = C.c_int
         f.argtypes = [vp, vp, C.c_uint64, vp]
+    L.r433_dump_convert.restype = C.c_int
+    L.r433_dump_convert.argtypes = [C.c_int, C.c_uint32, vp, vp, C.c_uint64, vp]
     for f in (L.r433_envelope_detect, L.r433_magnitude_est_cu8, L.r433_magnitude_est_cs16):
         f.restype = C.c_int
         f.argtypes = [vp, vp, C.c_uint32, vp, vp]

@@ -7,6 +7,7 @@
 #include <algorithm>
 
 #include "dsp_device.hpp"
+#include "r433_hip.h"
 #include "r433_internal.hpp"
 
 namespace r433 {
@@ -181,6 +182,128 @@ template <int KIND> __global__ __launch_bounds__(64) void k_tile_max(uint8_t con
         tile_sum[blockIdx.x] = acc;
 }
 
+
+// ---- -w dump formats (reference src/r_flow.c:385-489): what the reference writes next to its input, as
+// HBM-bound maps.  A group is what one lane turns out per step: 8 values of one or two bytes, or 4 floats (one
+// 16-byte store per lane, so every store instruction of a wavefront covers one contiguous kilobyte), made
+// from as many components of the IQ stream (or of an am/fm s16 stream) -- twice as many for the I (Q) halves.
+// IN16: the input components are int16 (cs16 IQ, am.s16, fm.s16), else uint8.
+template <int NW> __device__ __forceinline__ void load_words(void const *in, uint64_t idx, uint32_t (&w)[NW])
+{
+    if (NW == 1) {
+        w[0] = ((uint32_t const *)in)[idx];
+    }
+    else if (NW == 2) {
+        uint2 const t = ((uint2 const *)in)[idx];
+        w[0] = t.x;
+        w[NW > 1 ? 1 : 0] = t.y;
+    }
+    else {
+        uint4 const t = ((uint4 const *)in)[idx];
+        w[0] = t.x;
+        w[NW > 1 ? 1 : 0] = t.y;
+        w[NW > 2 ? 2 : 0] = t.z;
+        w[NW > 3 ? 3 : 0] = t.w;
+    }
+}
+
+template <int FMT> struct DumpGeom {
+    static constexpr bool kFloat = FMT == R433_DUMP_CF32_IQ || FMT == R433_DUMP_F32_AM || FMT == R433_DUMP_F32_FM
+            || FMT == R433_DUMP_F32_I || FMT == R433_DUMP_F32_Q;
+    static constexpr bool kHalf = FMT == R433_DUMP_F32_I || FMT == R433_DUMP_F32_Q; // one float per IQ pair
+    static constexpr int kOut = kFloat ? 4 : 8;                                     // values per group
+    static constexpr int kIn = kHalf ? 2 * kOut : kOut;                             // components consumed per group
+};
+
+template <int FMT, bool IN16> __device__ __forceinline__ void dump_group(void const *in, void *out, uint64_t g, uint32_t cnt)
+{
+    using G = DumpGeom<FMT>;
+    constexpr int kIn = G::kIn, kOut = G::kOut;
+    int v[kIn];
+    if (cnt == (uint32_t)kOut) { // whole group: one vector load
+        constexpr int NW = kIn * (IN16 ? 2 : 1) / 4;
+        uint32_t w[NW];
+        load_words<NW>(in, g, w);
+#pragma unroll
+        for (int k = 0; k < kIn; ++k)
+            v[k] = IN16 ? (int)(int16_t)((w[k >> 1] >> (16 * (k & 1))) & 0xffffu) : (int)((w[k >> 2] >> (8 * (k & 3))) & 0xffu);
+    }
+    else { // the ragged tail
+        for (int k = 0; k < kIn; ++k) {
+            uint64_t const idx = g * kIn + (uint64_t)k;
+            bool const ok = (uint32_t)(G::kHalf ? k / 2 : k) < cnt;
+            v[k] = !ok ? 0 : IN16 ? (int)((int16_t const *)in)[idx] : (int)((uint8_t const *)in)[idx];
+        }
+    }
+    if (FMT == R433_DUMP_CU8_IQ || FMT == R433_DUMP_CS8_IQ) { // one byte per component
+        uint32_t o[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int b;
+            if (FMT == R433_DUMP_CU8_IQ)
+                b = v[k % kIn] / 256 + 128;                      // cs16 -> cu8, r_flow.c:397-400 (C division)
+            else
+                b = IN16 ? v[k % kIn] >> 8 : v[k % kIn] - 128;   // -> cs8, r_flow.c:412-419
+            o[k >> 2] |= ((uint32_t)b & 0xffu) << (8 * (k & 3));
+        }
+        if (cnt == 8)
+            ((uint2 *)out)[g] = make_uint2(o[0], o[1]);
+        else
+            for (uint32_t k = 0; k < cnt; ++k)
+                ((uint8_t *)out)[g * 8 + k] = (uint8_t)(o[k >> 2] >> (8 * (k & 3)));
+    }
+    else if (FMT == R433_DUMP_CS16_IQ) { // cu8 -> cs16, r_flow.c:404-408
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            o[k] = ((uint32_t)(v[(2 * k) % kIn] * 256 - 32768) & 0xffffu) | ((uint32_t)(v[(2 * k + 1) % kIn] * 256 - 32768) << 16);
+        if (cnt == 8)
+            ((uint4 *)out)[g] = make_uint4(o[0], o[1], o[2], o[3]);
+        else
+            for (uint32_t k = 0; k < cnt; ++k)
+                ((int16_t *)out)[g * 8 + k] = (int16_t)(v[k % kIn] * 256 - 32768);
+    }
+    else { // float outputs, 4 per group
+        float f[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (FMT == R433_DUMP_CF32_IQ)
+                f[k] = IN16 ? (float)v[k % kIn] / 32768.0f : (float)(v[k % kIn] - 128) / 128.0f; // r_flow.c:424-431
+            else if (FMT == R433_DUMP_F32_AM || FMT == R433_DUMP_F32_FM)
+                f[k] = (float)v[k % kIn] * (1.0f / 0x8000);                                       // r_flow.c:444-455
+            else { // F32_I / F32_Q, r_flow.c:456-479
+                int const c = v[(2 * k + (FMT == R433_DUMP_F32_Q ? 1 : 0)) % kIn];
+                f[k] = IN16 ? (float)c * (1.0f / 0x8000) : (float)(c - 128) * (1.0f / 0x80);
+            }
+        }
+        if (cnt == 4)
+            ((float4 *)out)[g] = make_float4(f[0], f[1], f[2], f[3]);
+        else
+            for (uint32_t k = 0; k < cnt; ++k)
+                ((float *)out)[g * 4 + k] = f[k];
+    }
+}
+
+template <int FMT, bool IN16> __global__ __launch_bounds__(256) void k_dump(void const *in, void *out, uint64_t n_out)
+{
+    constexpr uint64_t kOut = DumpGeom<FMT>::kOut;
+    uint64_t const groups = (n_out + kOut - 1) / kOut;
+    for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += (uint64_t)gridDim.x * 256) {
+        uint64_t const left = n_out - g * kOut;
+        dump_group<FMT, IN16>(in, out, g, left >= kOut ? (uint32_t)kOut : (uint32_t)left);
+    }
+}
+
+template <int FMT> void launch_dump_fmt(bool in16, void const *d_in, void *d_out, uint64_t n_out, hipStream_t st)
+{
+    uint64_t const groups = (n_out + DumpGeom<FMT>::kOut - 1) / DumpGeom<FMT>::kOut;
+    uint32_t const blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8192, (groups + 255) / 256)); // 256 CUs x 32 + grid stride
+    if (in16)
+        hipLaunchKernelGGL((k_dump<FMT, true>), dim3(blocks), dim3(256), 0, st, d_in, d_out, n_out);
+    else
+        hipLaunchKernelGGL((k_dump<FMT, false>), dim3(blocks), dim3(256), 0, st, d_in, d_out, n_out);
+}
+
 } // namespace
 
 void launch_convert(int input_format, void const *d_in, uint64_t in_stride_bytes, void *d_out, uint64_t out_stride_bytes,
@@ -240,6 +363,39 @@ void launch_envelope(int kind, void const *d_iq, uint16_t *d_env, uint32_t n, ui
         hipLaunchKernelGGL(k_envelope<ENV_MAG_CU8>, dim3(blocks), dim3(256), 0, st, iq, d_env, n, d_sum);
     else
         hipLaunchKernelGGL(k_envelope<ENV_MAG_CS16>, dim3(blocks), dim3(256), 0, st, iq, d_env, n, d_sum);
+}
+
+int launch_dump(int format, uint32_t sample_size, void const *d_in, void *d_out, uint64_t n_out, hipStream_t st)
+{
+    bool const in16 = sample_size == 4 || format == R433_DUMP_F32_AM || format == R433_DUMP_F32_FM;
+    switch (format) {
+    case R433_DUMP_CU8_IQ:
+        launch_dump_fmt<R433_DUMP_CU8_IQ>(true, d_in, d_out, n_out, st);
+        return 0;
+    case R433_DUMP_CS16_IQ:
+        launch_dump_fmt<R433_DUMP_CS16_IQ>(false, d_in, d_out, n_out, st);
+        return 0;
+    case R433_DUMP_CS8_IQ:
+        launch_dump_fmt<R433_DUMP_CS8_IQ>(in16, d_in, d_out, n_out, st);
+        return 0;
+    case R433_DUMP_CF32_IQ:
+        launch_dump_fmt<R433_DUMP_CF32_IQ>(in16, d_in, d_out, n_out, st);
+        return 0;
+    case R433_DUMP_F32_AM:
+        launch_dump_fmt<R433_DUMP_F32_AM>(true, d_in, d_out, n_out, st);
+        return 0;
+    case R433_DUMP_F32_FM:
+        launch_dump_fmt<R433_DUMP_F32_FM>(true, d_in, d_out, n_out, st);
+        return 0;
+    case R433_DUMP_F32_I:
+        launch_dump_fmt<R433_DUMP_F32_I>(in16, d_in, d_out, n_out, st);
+        return 0;
+    case R433_DUMP_F32_Q:
+        launch_dump_fmt<R433_DUMP_F32_Q>(in16, d_in, d_out, n_out, st);
+        return 0;
+    default:
+        return -1;
+    }
 }
 
 } // namespace r433

@@ -1591,6 +1591,33 @@ int r433_convert_cf32_cs16(void const *d_in, void *d_out, uint64_t n, void *stre
     return run_convert(2, d_in, d_out, n, stream);
 }
 
+int r433_dump_convert(int format, uint32_t sample_size, void const *d_in, void *d_out, uint64_t n_out, void *stream)
+{
+    if (format < R433_DUMP_CU8_IQ || format > R433_DUMP_F32_Q)
+        return fail(R433_EINVAL, "unknown dump format %d", format);
+    if (sample_size != 2 && sample_size != 4)
+        return fail(R433_EINVAL, "sample_size must be 2 (cu8) or 4 (cs16)");
+    if (n_out == 0)
+        return 0;
+    if (!d_in || !d_out || ((uintptr_t)d_in & 15u) || ((uintptr_t)d_out & 15u))
+        return fail(R433_EINVAL, "dump buffers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    // the reference writes its own buffers for these (src/r_flow.c:396,403,436-443): a copy
+    size_t same = 0;
+    if (format == R433_DUMP_CU8_IQ && sample_size == 2)
+        same = n_out;
+    else if ((format == R433_DUMP_CS16_IQ && sample_size == 4) || format == R433_DUMP_S16_AM || format == R433_DUMP_S16_FM)
+        same = n_out * 2;
+    if (same) {
+        HIP_TRY(hipMemcpyAsync(d_out, d_in, same, hipMemcpyDeviceToDevice, st));
+        return 0;
+    }
+    if (launch_dump(format, sample_size, d_in, d_out, n_out, st))
+        return fail(R433_EINVAL, "dump format %d is not a conversion", format);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int r433_envelope_detect(void const *d_iq, void *d_env, uint32_t n, uint32_t *d_sum, void *stream)
 {
     return run_envelope(ENV_AMP_CU8, d_iq, d_env, n, d_sum, stream);

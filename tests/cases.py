@@ -104,3 +104,12 @@ def mixed_2000k_capture(seed=77, n=900000):
     out[0::2] = np.clip(np.rint(i), 0, 255)
     out[1::2] = np.clip(np.rint(q), 0, 255)
     return out, rate
+
+
+def dump_capture(name):
+    """Inputs of the -w dump-format vectors (tests/golden/gen_dump_golden.py): (iq, sample_size, file name).
+    Lengths that are no multiple of the kernels' group size, so the ragged tail is covered."""
+    if name == "cu8":
+        return synth.ook_batch(1, 32768, 250000, seed0=5)[0][: 2 * 32765].copy(), 2, "g_433.92M_250k.cu8"
+    iq = np.asarray(synth.fsk_stream_cs16(3, 40003))
+    return iq[: 2 * 40003].copy(), 4, "g_868M_1024k.cs16"
