@@ -177,6 +177,19 @@ int r433_magnitude_est_cs16(void const *d_iq, void *d_env, uint32_t n, uint32_t 
  * semantics for values no int can hold (they become -32767). */
 int r433_convert_cs8_cu8(void const *d_in, void *d_out, uint64_t n, void *stream);
 int r433_convert_cf32_cs16(void const *d_in, void *d_out, uint64_t n, void *stream);
+/* The pulse-data side door (`-r file.ook`, src/rtl_433.c:1755-1794): packages detected elsewhere go straight to the
+ * decoder fan-out.  pulses: n_packages structs in the reference's pulse_data_t layout (host memory); a package goes
+ * to the FSK decoders if its fsk_f2_est is non-zero, as the reference decides.  Results are read and dispatched exactly
+ * as after r433_batch_run (package k carries stream = k).  Returns the number of packages, negative on error. */
+int r433_batch_run_pulses(r433_batch *b, r433_pulse_data const *pulses, uint32_t n_packages, void *stream);
+/* pulse_data_load (src/pulse_data.c:122-176) over a whole `.ook` text in memory: every package up to the first empty
+ * one, like the file loop reads them.  (rfraw lines, src/rfraw.c, are not understood.)  Returns the number of packages
+ * written to out (at most max_packages). */
+int r433_pulse_text_load(char const *text, size_t len, uint32_t sample_rate, r433_pulse_data *out, uint32_t max_packages);
+/* pulse_data_dump (src/pulse_data.c:193-224): one package as `.ook` text; `received` is the time string of the
+ * ";received" line (NULL: no such line).  snprintf convention: returns the full length, writes at most cap bytes. */
+int r433_pulse_text_dump(r433_pulse_data const *data, char const *received, char *buf, size_t cap);
+
 /* The -w dump formats (src/r_flow.c:385-489, named as in include/fileformat.h): what the reference writes next to
  * its input, as one HBM-bound map on device buffers.  sample_size says what d_in holds (2 = cu8 IQ, 4 = cs16 IQ);
  * for R433_DUMP_F32_AM / _FM d_in is the am / fm int16 stream (r433_batch_set_taps, the S16_AM / S16_FM dumps

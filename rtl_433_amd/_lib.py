@@ -36,6 +36,15 @@ RDevice._fields_ = [
     ("decode_messages", C.c_uint), ("decode_fails", C.c_uint * 5), ("decode_ctx", C.c_void_p),
     ("output_ctx", C.c_void_p)]
 
+class PulseData(C.Structure):
+    """pulse_data_t (reference include/pulse_data.h:30-50) == r433_pulse_data (include/r433_abi.h)."""
+    _fields_ = [("offset", C.c_uint64), ("sample_rate", C.c_uint32), ("depth_bits", C.c_uint), ("start_ago", C.c_uint),
+                ("end_ago", C.c_uint), ("num_pulses", C.c_uint), ("pulse", C.c_int * 1200), ("gap", C.c_int * 1200),
+                ("ook_low_estimate", C.c_int), ("ook_high_estimate", C.c_int), ("fsk_f1_est", C.c_int),
+                ("fsk_f2_est", C.c_int), ("freq1_hz", C.c_float), ("freq2_hz", C.c_float), ("centerfreq_hz", C.c_float),
+                ("range_db", C.c_float), ("rssi_db", C.c_float), ("snr_db", C.c_float), ("noise_db", C.c_float)]
+
+
 class DigestCtx(C.Structure):
     _fields_ = [("sum", C.c_uint64), ("events", C.c_uint64)]
 
@@ -60,6 +69,7 @@ EXPORTS = [
     "r433_batch_get_timing", "r433_batch_debug_state", "r433_batch_dispatch", "r433_batch_dispatch_mt", "r433_dispatch_current",
     "r433_plugin_digest_decode", "r433_envelope_detect", "r433_magnitude_est_cu8",
     "r433_magnitude_est_cs16", "r433_convert_cs8_cu8", "r433_convert_cf32_cs16", "r433_dump_convert",
+    "r433_batch_run_pulses", "r433_pulse_text_load", "r433_pulse_text_dump",
 ]
 
 
@@ -119,6 +129,12 @@ def bind(L):
     for f in (L.r433_convert_cs8_cu8, L.r433_convert_cf32_cs16):
         f.restype = C.c_int
         f.argtypes = [vp, vp, C.c_uint64, vp]
+    L.r433_batch_run_pulses.restype = C.c_int
+    L.r433_batch_run_pulses.argtypes = [vp, vp, C.c_uint32, vp]
+    L.r433_pulse_text_load.restype = C.c_int
+    L.r433_pulse_text_load.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, vp, C.c_uint32]
+    L.r433_pulse_text_dump.restype = C.c_int
+    L.r433_pulse_text_dump.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_size_t]
     L.r433_dump_convert.restype = C.c_int
     L.r433_dump_convert.argtypes = [C.c_int, C.c_uint32, vp, vp, C.c_uint64, vp]
     for f in (L.r433_envelope_detect, L.r433_magnitude_est_cu8, L.r433_magnitude_est_cs16):

@@ -303,7 +303,7 @@ struct r433_batch {
     DevBuf<uint8_t> d_pkg_blob, d_events, d_stage, d_converted;
     std::vector<uint32_t> conv_bytes;
     PinBuf<uint32_t> h_scal, h_frame_sums;
-    PinBuf<uint8_t> h_pkg_blob, h_events;
+    PinBuf<uint8_t> h_pkg_blob, h_events, h_arena_stage;
     PinBuf<uint32_t> h_pkg_off, h_rec_off; // per package: byte offset of its first event / of its record
 
     uint32_t arena_stride = 0;
@@ -1202,6 +1202,84 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
     return run_slice_and_mirror(r);
 }
 
+int r433_batch_run_pulses(r433_batch *b, r433_pulse_data const *pulses, uint32_t n_packages, void *stream)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    if (n_packages == 0) {
+        b->n_streams = 0;
+        b->n_pkgs = b->n_events = 0;
+        b->pkg_bytes = b->evt_bytes = 0;
+        return 0;
+    }
+    if (!pulses)
+        return fail(R433_EINVAL, "null pulse data");
+    RunCtx r;
+    r.b = b;
+    r.st = (hipStream_t)stream;
+    r.ss = b->cfg.sample_size;
+    r.d_iq = nullptr;
+    r.stride_bytes = 0;
+    r.stream_bytes = nullptr;
+    r.n_streams = n_packages;
+    r.frames_cap = 1;
+    r.n_order = n_packages;
+    // one arena slot per package, laid out exactly as the detection kernel leaves a capture with one package
+    uint32_t max_pulses = 0;
+    for (uint32_t k = 0; k < n_packages; ++k) {
+        if (pulses[k].num_pulses > R433_PD_MAX_PULSES)
+            return fail(R433_EINVAL, "package %u has %u pulses (at most %u)", k, pulses[k].num_pulses, (unsigned)R433_PD_MAX_PULSES);
+        max_pulses = std::max(max_pulses, pulses[k].num_pulses);
+    }
+    uint32_t const stride = ((uint32_t)sizeof(r433_pkg_rec) + 8u * max_pulses + 15u) & ~15u;
+    int rc;
+    if ((rc = b->d_arena.ensure((size_t)n_packages * stride)) || (rc = b->d_state.ensure(n_packages))
+            || (rc = b->d_pkg_base.ensure(n_packages)) || (rc = b->d_frame_sums.ensure(n_packages))
+            || (rc = b->h_arena_stage.ensure((size_t)n_packages * stride)) || (rc = b->h_state.ensure(n_packages)))
+        return rc;
+    b->arena_stride = stride;
+    b->frames_cap = 1;
+    b->n_streams = n_packages;
+    memset(b->h_arena_stage.p, 0, (size_t)n_packages * stride);
+    memset(b->h_state.p, 0, (size_t)n_packages * sizeof(StreamState));
+    for (uint32_t k = 0; k < n_packages; ++k) {
+        r433_pulse_data const &pd = pulses[k];
+        uint8_t *rec = b->h_arena_stage.p + (size_t)k * stride;
+        r433_pkg_rec h;
+        memset(&h, 0, sizeof(h));
+        h.total_bytes = (uint32_t)sizeof(h) + 8u * pd.num_pulses;
+        h.stream = k;
+        h.type = pd.fsk_f2_est ? R433_PKG_FSK : R433_PKG_OOK; // as the reference decides, src/rtl_433.c:1774
+        h.num_pulses = pd.num_pulses;
+        h.offset = pd.offset;
+        h.start_ago = pd.start_ago;
+        h.end_ago = pd.end_ago;
+        h.ook_low = pd.ook_low_estimate;
+        h.ook_high = pd.ook_high_estimate;
+        h.fsk_f1 = pd.fsk_f1_est;
+        h.fsk_f2 = pd.fsk_f2_est;
+        h.sample_rate = pd.sample_rate ? pd.sample_rate : b->cfg.samp_rate;
+        memcpy(rec, &h, sizeof(h));
+        int32_t *pairs = (int32_t *)(rec + sizeof(h));
+        for (uint32_t i = 0; i < pd.num_pulses; ++i) {
+            pairs[2 * i] = pd.pulse[i];
+            pairs[2 * i + 1] = pd.gap[i];
+        }
+        b->h_state.p[k].n_pkgs = 1;
+        b->h_state.p[k].cursor = h.total_bytes;
+    }
+    if (b->profiling)
+        for (int e = 0; e < 2; ++e)
+            HIP_TRY(hipEventRecord(b->ev[e], r.st));
+    HIP_TRY(hipMemcpyAsync(b->d_arena.p, b->h_arena_stage.p, (size_t)n_packages * stride, hipMemcpyHostToDevice, r.st));
+    HIP_TRY(hipMemcpyAsync(b->d_state.p, b->h_state.p, (size_t)n_packages * sizeof(StreamState), hipMemcpyHostToDevice, r.st));
+    HIP_TRY(hipMemsetAsync(b->d_frame_sums.p, 0, (size_t)n_packages * sizeof(uint32_t), r.st));
+    launch_pkg_scan(b->d_state.p, nullptr, n_packages, b->d_pkg_base.p, b->d_scal.p, r.st);
+    HIP_TRY(hipGetLastError());
+    r.total_pkgs = n_packages;
+    return run_slice_and_mirror(r);
+}
+
 int r433_batch_packages(r433_batch *b, uint8_t const **blob, size_t *len, uint32_t *count)
 {
     if (!b)
@@ -1616,6 +1694,104 @@ int r433_dump_convert(int format, uint32_t sample_size, void const *d_in, void *
         return fail(R433_EINVAL, "dump format %d is not a conversion", format);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+// pulse_data_load, reference src/pulse_data.c:122-176, over a text in memory: one call of the reference reads one
+// package; the file loop calls it until a package comes back empty (src/rtl_433.c:1757-1761).
+int r433_pulse_text_load(char const *text, size_t len, uint32_t sample_rate, r433_pulse_data *out, uint32_t max_packages)
+{
+    if ((!text && len) || (!out && max_packages))
+        return fail(R433_EINVAL, "null argument");
+    size_t at = 0;
+    uint32_t n_out = 0;
+    double const to_sample = sample_rate / 1e6;
+    // fgets(s, 1024, file): at most 1023 characters, up to and including the newline
+    auto next_line = [&](char *s) -> bool {
+        if (at >= len)
+            return false;
+        size_t k = 0;
+        while (k < 1023 && at < len) {
+            char const c = text[at++];
+            s[k++] = c;
+            if (c == '\n')
+                break;
+        }
+        s[k] = '\0';
+        return true;
+    };
+    for (;;) {
+        r433_pulse_data *data = n_out < max_packages ? &out[n_out] : nullptr;
+        if (!data)
+            break;
+        memset(data, 0, sizeof(*data)); // pulse_data_clear
+        data->sample_rate = sample_rate;
+        char s[1024];
+        int i = 0;
+        while (i < R433_MAX_PULSES && next_line(s)) {
+            if (!strncmp(s, ";freq1", 6))
+                data->freq1_hz = (float)strtol(s + 6, nullptr, 10);
+            if (!strncmp(s, ";freq2", 6))
+                data->freq2_hz = (float)strtol(s + 6, nullptr, 10);
+            if (*s == ';') {
+                if (i)
+                    break; // end or next header found
+                continue;  // still reading a header
+            }
+            char const *p = s;
+            char *endptr;
+            long const mark = strtol(p, &endptr, 10);
+            p = endptr + 1;
+            long const space = strtol(p, &endptr, 10);
+            if (mark < 0 || space < 0)
+                continue; // the reference warns and skips the line
+            data->pulse[i] = (int)(to_sample * mark);
+            data->gap[i++] = (int)(to_sample * space);
+        }
+        data->num_pulses = (unsigned)i;
+        if (i == 0)
+            break; // the file loop stops at the first empty package
+        n_out += 1;
+    }
+    return (int)n_out;
+}
+
+// pulse_data_dump, reference src/pulse_data.c:193-224.  Returns the length of the text (like snprintf: the text
+// is cut if it does not fit cap, the full length is returned either way).
+int r433_pulse_text_dump(r433_pulse_data const *data, char const *received, char *buf, size_t cap)
+{
+    if (!data || (!buf && cap))
+        return fail(R433_EINVAL, "null argument");
+    size_t len = 0;
+#define PUT(...)                                                                                                     \
+    do {                                                                                                             \
+        int const n_ = snprintf(len < cap ? buf + len : nullptr, len < cap ? cap - len : 0, __VA_ARGS__);           \
+        if (n_ > 0)                                                                                                  \
+            len += (size_t)n_;                                                                                       \
+    } while (0)
+    if (received)
+        PUT(";received %s\n", received);
+    if (data->fsk_f2_est) {
+        PUT(";fsk %u pulses\n", data->num_pulses);
+        PUT(";freq1 %.0f\n", (double)data->freq1_hz);
+        PUT(";freq2 %.0f\n", (double)data->freq2_hz);
+    }
+    else {
+        PUT(";ook %u pulses\n", data->num_pulses);
+        PUT(";freq1 %.0f\n", (double)data->freq1_hz);
+    }
+    PUT(";centerfreq %.0f Hz\n", (double)data->centerfreq_hz);
+    PUT(";samplerate %u Hz\n", data->sample_rate);
+    PUT(";sampledepth %u bits\n", data->depth_bits);
+    PUT(";range %.1f dB\n", (double)data->range_db);
+    PUT(";rssi %.1f dB\n", (double)data->rssi_db);
+    PUT(";snr %.1f dB\n", (double)data->snr_db);
+    PUT(";noise %.1f dB\n", (double)data->noise_db);
+    double const to_us = 1e6 / data->sample_rate;
+    for (unsigned i = 0; i < data->num_pulses && i < R433_MAX_PULSES; ++i)
+        PUT("%.0f %.0f\n", data->pulse[i] * to_us, data->gap[i] * to_us);
+    PUT(";end\n");
+#undef PUT
+    return (int)len;
 }
 
 int r433_envelope_detect(void const *d_iq, void *d_env, uint32_t n, uint32_t *d_sum, void *stream)

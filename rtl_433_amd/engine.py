@@ -140,6 +140,11 @@ class BatchEngine:
         _lib.check(self.L.r433_batch_get_timing(self.h, C.byref(t)), "r433_batch_get_timing", self.L)
         return {n: getattr(t, n) for n, _ in t._fields_}
 
+    def run_pulses(self, pulses, stream=None):
+        """The `.ook` side door: `pulses` is a ctypes array of _lib.PulseData; straight to the decoder fan-out."""
+        rc = self.L.r433_batch_run_pulses(self.h, C.cast(pulses, C.c_void_p), len(pulses), stream)
+        return _lib.check(rc, "r433_batch_run_pulses", self.L)
+
     def dispatch(self, rdevices, pkg_cb=None, user=None, n_threads=1):
         """rdevices: ctypes array of POINTER(RDevice) in registration order."""
         cb = C.cast(pkg_cb, C.c_void_p) if pkg_cb is not None else None
@@ -173,3 +178,19 @@ def make_rdevices(devs, decode_fn_addr=None, ctx_addr=None, names=None, protocol
 def digest_plugin_addr():
     """Address of the library's checksum decode_fn (r433_plugin_digest_decode)."""
     return C.cast(_lib.lib().r433_plugin_digest_decode, C.c_void_p).value
+
+
+def load_pulse_text(text, sample_rate, max_packages=4096, library=None):
+    """`.ook` text (bytes) -> ctypes array of _lib.PulseData, like the reference's file loop reads it."""
+    L = library or _lib.lib()
+    arr = (_lib.PulseData * max_packages)()
+    n = _lib.check(L.r433_pulse_text_load(text, len(text), sample_rate, C.cast(arr, C.c_void_p), max_packages), "r433_pulse_text_load", L)
+    return (_lib.PulseData * n).from_buffer(arr) if n else (_lib.PulseData * 0)()
+
+
+def dump_pulse_text(pd, received=None, library=None):
+    """One package as `.ook` text (bytes), reference pulse_data_dump."""
+    L = library or _lib.lib()
+    buf = C.create_string_buffer(64 * 1024)
+    n = _lib.check(L.r433_pulse_text_dump(C.byref(pd), received, buf, len(buf)), "r433_pulse_text_dump", L)
+    return buf.raw[:n]
