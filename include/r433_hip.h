@@ -190,6 +190,15 @@ int r433_pulse_text_load(char const *text, size_t len, uint32_t sample_rate, r43
  * ";received" line (NULL: no such line).  snprintf convention: returns the full length, writes at most cap bytes. */
 int r433_pulse_text_dump(r433_pulse_data const *data, char const *received, char *buf, size_t cap);
 
+/* The pulse analyzer (`-A`, src/pulse_analyzer.c:279-556) over every package of the last run (r433_batch_run or
+ * r433_batch_run_pulses): histograms and modulation guess on the device, one wavefront per package; out[k] belongs to
+ * package k.  Returns the number of results written (at most max_packages). */
+int r433_batch_analyze(r433_batch *b, r433_analysis *out, uint32_t max_packages, void *stream);
+/* The reference's report for package pkg of the last run, from "Analyzing pulses..." through the flex-decoder
+ * suggestion (what the trial demodulation prints after that is the slicers' business: feed `a->device` to a batch).
+ * snprintf convention: returns the full length, writes at most cap bytes. */
+int r433_analysis_text(r433_batch *b, uint32_t pkg, r433_analysis const *a, char *buf, size_t cap);
+
 /* The -w dump formats (src/r_flow.c:385-489, named as in include/fileformat.h): what the reference writes next to
  * its input, as one HBM-bound map on device buffers.  sample_size says what d_in holds (2 = cu8 IQ, 4 = cs16 IQ);
  * for R433_DUMP_F32_AM / _FM d_in is the am / fm int16 stream (r433_batch_set_taps, the S16_AM / S16_FM dumps

@@ -82,6 +82,47 @@ typedef struct r433_dev_timing {
     uint32_t priority;
 } r433_dev_timing;
 
+/* Pulse analyzer result for one package (reference src/pulse_analyzer.c:20-35 histogram_t, :279-430): the five
+ * width histograms as the reference prints them (fused, in first-seen order) and the decoder it guesses. */
+#define R433_HIST_BINS 16 /* MAX_HIST_BINS */
+typedef struct r433_hist_bin {
+    uint32_t count;
+    int32_t sum;
+    int32_t mean;
+    int32_t min;
+    int32_t max;
+} r433_hist_bin;
+
+typedef struct r433_histogram {
+    uint32_t bins_count;
+    r433_hist_bin bins[R433_HIST_BINS];
+} r433_histogram;
+
+#define R433_GUESS_NO_PULSES 0
+#define R433_GUESS_SINGLE_PULSE 1      /* "Single pulse detected. Probably Frequency Shift Keying or just noise..." */
+#define R433_GUESS_UNMODULATED 2       /* "Un-modulated signal. Maybe a preamble..." */
+#define R433_GUESS_PPM 3               /* "Pulse Position Modulation with fixed pulse width" */
+#define R433_GUESS_PWM_FIXED_GAP 4     /* "Pulse Width Modulation with fixed gap" */
+#define R433_GUESS_PWM_FIXED_PERIOD 5  /* "Pulse Width Modulation with fixed period" */
+#define R433_GUESS_MANCHESTER 6        /* "Manchester coding" */
+#define R433_GUESS_PWM_MULTI 7         /* "Pulse Width Modulation with multiple packets" */
+#define R433_GUESS_NRZ 8               /* "Non Return to Zero coding (Pulse Code)" */
+#define R433_GUESS_PWM_SYNC 9          /* "Pulse Width Modulation with sync/delimiter" */
+#define R433_GUESS_NO_CLUE 10          /* "No clue..." */
+
+typedef struct r433_analysis {
+    uint32_t num_pulses;
+    int32_t total_period; /* samples from the first pulse to the end of the last one */
+    uint32_t guess;       /* R433_GUESS_* */
+    uint32_t reserved;
+    r433_histogram pulses;
+    r433_histogram gaps;       /* without the last gap */
+    r433_histogram periods_pg; /* pulse + following gap, without the last */
+    r433_histogram periods_gp; /* preceding gap + pulse */
+    r433_histogram timings;    /* pulses and gaps together */
+    r433_dev_timing device;    /* the guessed decoder as pulse_analyzer leaves it in its r_device; modulation 0: none */
+} r433_analysis;
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,26 @@ class PulseData(C.Structure):
                 ("range_db", C.c_float), ("rssi_db", C.c_float), ("snr_db", C.c_float), ("noise_db", C.c_float)]
 
 
+class HistBin(C.Structure):
+    _fields_ = [("count", C.c_uint32), ("sum", C.c_int32), ("mean", C.c_int32), ("min", C.c_int32), ("max", C.c_int32)]
+
+
+class Histogram(C.Structure):
+    _fields_ = [("bins_count", C.c_uint32), ("bins", HistBin * 16)]
+
+
+class DevTimingRow(C.Structure):
+    _fields_ = [("modulation", C.c_uint32), ("short_width", C.c_float), ("long_width", C.c_float), ("reset_limit", C.c_float),
+                ("gap_limit", C.c_float), ("sync_width", C.c_float), ("tolerance", C.c_float), ("priority", C.c_uint32)]
+
+
+class Analysis(C.Structure):
+    """r433_analysis (include/r433_records.h)."""
+    _fields_ = [("num_pulses", C.c_uint32), ("total_period", C.c_int32), ("guess", C.c_uint32), ("reserved", C.c_uint32),
+                ("pulses", Histogram), ("gaps", Histogram), ("periods_pg", Histogram), ("periods_gp", Histogram),
+                ("timings", Histogram), ("device", DevTimingRow)]
+
+
 class DigestCtx(C.Structure):
     _fields_ = [("sum", C.c_uint64), ("events", C.c_uint64)]
 
@@ -69,7 +89,7 @@ EXPORTS = [
     "r433_batch_get_timing", "r433_batch_debug_state", "r433_batch_dispatch", "r433_batch_dispatch_mt", "r433_dispatch_current",
     "r433_plugin_digest_decode", "r433_envelope_detect", "r433_magnitude_est_cu8",
     "r433_magnitude_est_cs16", "r433_convert_cs8_cu8", "r433_convert_cf32_cs16", "r433_dump_convert",
-    "r433_batch_run_pulses", "r433_pulse_text_load", "r433_pulse_text_dump",
+    "r433_batch_run_pulses", "r433_pulse_text_load", "r433_pulse_text_dump", "r433_batch_analyze", "r433_analysis_text",
 ]
 
 
@@ -135,6 +155,10 @@ def bind(L):
     L.r433_pulse_text_load.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, vp, C.c_uint32]
     L.r433_pulse_text_dump.restype = C.c_int
     L.r433_pulse_text_dump.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_size_t]
+    L.r433_batch_analyze.restype = C.c_int
+    L.r433_batch_analyze.argtypes = [vp, vp, C.c_uint32, vp]
+    L.r433_analysis_text.restype = C.c_int
+    L.r433_analysis_text.argtypes = [vp, C.c_uint32, vp, C.c_char_p, C.c_size_t]
     L.r433_dump_convert.restype = C.c_int
     L.r433_dump_convert.argtypes = [C.c_int, C.c_uint32, vp, vp, C.c_uint64, vp]
     for f in (L.r433_envelope_detect, L.r433_magnitude_est_cu8, L.r433_magnitude_est_cs16):

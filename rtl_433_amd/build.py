@@ -17,7 +17,7 @@ INC = os.path.join(HERE, "..", "include")
 OUT_DIR = os.path.join(HERE, "lib")
 OUT = os.path.join(OUT_DIR, "librtl433hip.so")
 
-SOURCES = ["stream_kernels.hip", "slicer_kernels.hip", "baseband_kernels.hip", "host_api.cpp"]
+SOURCES = ["stream_kernels.hip", "slicer_kernels.hip", "baseband_kernels.hip", "analyzer_kernels.hip", "host_api.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function", "-x", "hip"]
 

@@ -301,6 +301,7 @@ struct r433_batch {
     uint32_t last_segments = 0, last_redone = 0;
     DevBuf<uint32_t> d_dir_stream, d_dir_off, d_rec_bytes, d_rec_off, d_sizes, d_pkg_bytes, d_pkg_off;
     DevBuf<uint8_t> d_pkg_blob, d_events, d_stage, d_converted;
+    DevBuf<r433_analysis> d_analysis;
     std::vector<uint32_t> conv_bytes;
     PinBuf<uint32_t> h_scal, h_frame_sums;
     PinBuf<uint8_t> h_pkg_blob, h_events, h_arena_stage;
@@ -1694,6 +1695,218 @@ int r433_dump_convert(int format, uint32_t sample_size, void const *d_in, void *
         return fail(R433_EINVAL, "dump format %d is not a conversion", format);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+int r433_batch_analyze(r433_batch *b, r433_analysis *out, uint32_t max_packages, void *stream)
+{
+    if (!b || (!out && max_packages))
+        return fail(R433_EINVAL, "null argument");
+    uint32_t const n = std::min(b->n_pkgs, max_packages);
+    if (n == 0)
+        return 0;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = b->d_analysis.ensure(n)))
+        return rc;
+    // the arena and the package directory of the last run are still on the device
+    launch_analyze(b->d_arena.p, b->arena_stride, b->d_dir_stream.p, b->d_dir_off.p, n, b->d_analysis.p, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, b->d_analysis.p, (size_t)n * sizeof(r433_analysis), hipMemcpyDeviceToHost, st));
+    HIP_TRY(stream_wait(b, st));
+    return (int)n;
+}
+
+namespace {
+
+// histogram_find_bin_index, reference src/pulse_analyzer.c:157-165
+int find_bin(r433_histogram const &h, int width)
+{
+    for (uint32_t n = 0; n < h.bins_count && n < R433_HIST_BINS; ++n)
+        if (h.bins[n].min <= width && width <= h.bins[n].max)
+            return (int)n;
+    return -1;
+}
+
+// hexstr_t, reference src/pulse_analyzer.c:180-209
+struct HexStr {
+    uint8_t p[1024];
+    unsigned idx = 0;
+    void byte(uint8_t v)
+    {
+        if (idx < sizeof(p))
+            p[idx++] = v;
+    }
+    void word(uint16_t v)
+    {
+        if (idx + 1 < sizeof(p)) {
+            p[idx++] = (uint8_t)(v >> 8);
+            p[idx++] = (uint8_t)(v & 0xff);
+        }
+    }
+};
+
+} // namespace
+
+int r433_analysis_text(r433_batch *b, uint32_t pkg, r433_analysis const *a, char *buf, size_t cap)
+{
+    if (!b || !a || (!buf && cap))
+        return fail(R433_EINVAL, "null argument");
+    if (pkg >= b->n_pkgs)
+        return fail(R433_EINVAL, "package %u of %u", pkg, b->n_pkgs);
+    size_t len = 0;
+#define PUT(...)                                                                                                     \
+    do {                                                                                                             \
+        int const n_ = snprintf(len < cap ? buf + len : nullptr, len < cap ? cap - len : 0, __VA_ARGS__);           \
+        if (n_ > 0)                                                                                                  \
+            len += (size_t)n_;                                                                                       \
+    } while (0)
+    if (a->num_pulses == 0) { // src/pulse_analyzer.c:281-284
+        PUT("No pulses detected.\n");
+        return (int)len;
+    }
+    uint8_t const *rec = b->h_pkg_blob.p + b->h_rec_off.p[pkg];
+    r433_pkg_rec ph;
+    memcpy(&ph, rec, sizeof(ph));
+    int32_t const *pairs = (int32_t const *)(rec + sizeof(ph));
+    uint32_t const num = std::min<uint32_t>(ph.num_pulses, R433_MAX_PULSES);
+    uint32_t const rate = ph.sample_rate;
+    double const to_ms = 1e3 / rate, to_us = 1e6 / rate;
+    r433_pulse_data lv; // only the level fields are used
+    lv.ook_low_estimate = ph.ook_low;
+    lv.ook_high_estimate = ph.ook_high;
+    lv.fsk_f1_est = ph.fsk_f1;
+    lv.fsk_f2_est = ph.fsk_f2;
+    fill_levels(b->cfg, lv);
+
+    auto print_hist = [&](char const *title, r433_histogram const &h) { // histogram_print, :168-178
+        PUT("%s\n", title);
+        for (uint32_t n = 0; n < h.bins_count && n < R433_HIST_BINS; ++n)
+            PUT(" [%2u] count: %4u,  width: %4.0f us [%.0f;%.0f]\t(%4i S)\n", n, h.bins[n].count, h.bins[n].mean * 1e6 / rate,
+                    h.bins[n].min * 1e6 / rate, h.bins[n].max * 1e6 / rate, h.bins[n].mean);
+    };
+    PUT("Analyzing pulses...\n"); // :326-346
+    PUT("Total count: %4u,  width: %4.2f ms\t\t(%5i S)\n", a->num_pulses, a->total_period * to_ms, a->total_period);
+    print_hist("Pulse width distribution:", a->pulses);
+    print_hist("Gap width distribution:", a->gaps);
+    print_hist("Pulse+gap period distribution:", a->periods_pg);
+    print_hist("Gap+pulse period distribution:", a->periods_gp);
+    print_hist("Timing distribution:", a->timings);
+    PUT("Level estimates [high, low]: %6i, %6i\n", ph.ook_high, ph.ook_low);
+    PUT("RSSI: %.1f dB SNR: %.1f dB Noise: %.1f dB\n", (double)lv.rssi_db, (double)lv.snr_db, (double)lv.noise_db);
+    PUT("Frequency offsets [F1, F2]:  %6i, %6i\t(%+.1f kHz, %+.1f kHz)\n", ph.fsk_f1, ph.fsk_f2,
+            ((float)ph.fsk_f1 / INT16_MAX) * (rate / 2.0 / 1000.0), ((float)ph.fsk_f2 / INT16_MAX) * (rate / 2.0 / 1000.0));
+    static char const *const kGuess[] = {"", "Single pulse detected. Probably Frequency Shift Keying or just noise...",
+            "Un-modulated signal. Maybe a preamble...", "Pulse Position Modulation with fixed pulse width",
+            "Pulse Width Modulation with fixed gap", "Pulse Width Modulation with fixed period", "Manchester coding",
+            "Pulse Width Modulation with multiple packets", "Non Return to Zero coding (Pulse Code)",
+            "Pulse Width Modulation with sync/delimiter", "No clue..."};
+    PUT("Guessing modulation: %s\n", kGuess[a->guess <= R433_GUESS_NO_CLUE ? a->guess : 0]);
+
+    // RfRaw line, :432-513 (the guess sorted only copies of the pulse / gap histograms; their bin counts did not change,
+    // except that an FSK zero-bin left the pulse histogram, which this part does not look at)
+    r433_histogram const &T = a->timings;
+    if (T.bins_count <= 8) {
+        // gap bins by ascending mean, as the reference has sorted them by now
+        r433_hist_bin gs[R433_HIST_BINS];
+        uint32_t const ng = std::min<uint32_t>(a->gaps.bins_count, R433_HIST_BINS);
+        for (uint32_t k = 0; k < ng; ++k)
+            gs[k] = a->gaps.bins[k];
+        for (uint32_t n = 0; n + 1 < ng; ++n)
+            for (uint32_t m = n + 1; m < ng; ++m)
+                if (gs[m].mean < gs[n].mean)
+                    std::swap(gs[m], gs[n]);
+        auto push_bins = [&](HexStr &h) {
+            for (uint32_t k = 0; k < T.bins_count; ++k) {
+                double const w = std::max(0.0, T.bins[k].mean * to_us);
+                h.word((uint16_t)(w < 65535 ? w : 65535));
+            }
+        };
+        if (ng <= 2) {
+            HexStr h;
+            h.byte(0xaa);
+            h.byte(0xb1);
+            h.byte((uint8_t)T.bins_count);
+            push_bins(h);
+            for (uint32_t i = 0; i < num; ++i)
+                h.byte((uint8_t)(0x80 | (find_bin(T, pairs[2 * i]) << 4) | find_bin(T, pairs[2 * i + 1])));
+            h.byte(0x55);
+            PUT("view at https://triq.org/pdv/#");
+            for (unsigned k = 0; k < h.idx; ++k)
+                PUT("%02X", h.p[k]);
+            PUT("\n");
+        }
+        else {
+            int const limit = gs[std::min<uint32_t>(3, ng - 1)].min;
+            std::vector<HexStr> strs(32);
+            unsigned cnt = 0;
+            uint32_t i = 0;
+            while (i < num && cnt < 32) {
+                HexStr &h = strs[cnt];
+                h.idx = 0;
+                h.byte(0xaa);
+                h.byte(0xb0);
+                h.byte(0);
+                h.byte((uint8_t)T.bins_count);
+                h.byte(1);
+                push_bins(h);
+                for (; i < num; ++i) {
+                    h.byte((uint8_t)(0x80 | (find_bin(T, pairs[2 * i]) << 4) | find_bin(T, pairs[2 * i + 1])));
+                    if (pairs[2 * i + 1] >= limit) {
+                        ++i;
+                        break;
+                    }
+                }
+                h.byte(0x55);
+                h.p[2] = (uint8_t)(h.idx - 4 <= 255 ? h.idx - 4 : 0);
+                if (cnt > 0 && strs[cnt - 1].idx == h.idx && !memcmp(&strs[cnt - 1].p[5], &h.p[5], h.idx - 5)) {
+                    h.idx = 0;
+                    strs[cnt - 1].p[4] += 1;
+                }
+                else {
+                    cnt++;
+                }
+            }
+            PUT("view at https://triq.org/pdv/#");
+            for (unsigned j = 0; j < cnt; ++j) {
+                if (j > 0)
+                    PUT("+");
+                for (unsigned k = 0; k < strs[j].idx; ++k)
+                    PUT("%02X", strs[j].p[k]);
+            }
+            PUT("\n");
+            if (cnt >= 32)
+                PUT("Too many pulse groups (%u pulses missed in rfraw)\n", num - i);
+        }
+    }
+    r433_dev_timing const &d = a->device;
+    if (d.modulation) { // :516-556
+        PUT("Attempting demodulation... short_width: %.0f, long_width: %.0f, reset_limit: %.0f, sync_width: %.0f\n", (double)d.short_width,
+                (double)d.long_width, (double)d.reset_limit, (double)d.sync_width);
+        switch (d.modulation) {
+        case 16: // FSK_PULSE_PCM
+            PUT("Use a flex decoder with -X 'n=name,m=FSK_PCM,s=%.0f,l=%.0f,r=%.0f'\n", (double)d.short_width, (double)d.long_width,
+                    (double)d.reset_limit);
+            break;
+        case 5: // OOK_PULSE_PPM
+            PUT("Use a flex decoder with -X 'n=name,m=OOK_PPM,s=%.0f,l=%.0f,g=%.0f,r=%.0f'\n", (double)d.short_width, (double)d.long_width,
+                    (double)d.gap_limit, (double)d.reset_limit);
+            break;
+        case 6:  // OOK_PULSE_PWM
+        case 17: // FSK_PULSE_PWM
+            PUT("Use a flex decoder with -X 'n=name,m=%s,s=%.0f,l=%.0f,r=%.0f,g=%.0f,t=%.0f,y=%.0f'\n", d.modulation == 6 ? "OOK_PWM" : "FSK_PWM",
+                    (double)d.short_width, (double)d.long_width, (double)d.reset_limit, (double)d.gap_limit, (double)d.tolerance,
+                    (double)d.sync_width);
+            break;
+        case 3: // OOK_PULSE_MANCHESTER_ZEROBIT
+            PUT("Use a flex decoder with -X 'n=name,m=OOK_MC_ZEROBIT,s=%.0f,l=%.0f,r=%.0f'\n", (double)d.short_width, (double)d.long_width,
+                    (double)d.reset_limit);
+            break;
+        default:
+            PUT("Unsupported\n");
+        }
+    }
+#undef PUT
+    return (int)len;
 }
 
 // pulse_data_load, reference src/pulse_data.c:122-176, over a text in memory: one call of the reference reads one

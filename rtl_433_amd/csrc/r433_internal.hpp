@@ -149,6 +149,8 @@ void launch_slice_write(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st
 // ---- function-level baseband kernels (device pointers) ----
 enum { ENV_AMP_CU8 = 0, ENV_MAG_CU8 = 1, ENV_MAG_CS16 = 2 };
 // input_format 1: cs8 -> cu8, 2: cf32 -> cs16; n_rows captures, row_in_bytes input bytes each
+void launch_analyze(uint8_t const *arena, uint32_t arena_stride, uint32_t const *dir_stream, uint32_t const *dir_off, uint32_t n_pkgs,
+        r433_analysis *out, hipStream_t st);
 // -w dump formats (R433_DUMP_*): n_out output values; returns -1 for a format that is not a conversion
 int launch_dump(int format, uint32_t sample_size, void const *d_in, void *d_out, uint64_t n_out, hipStream_t st);
 void launch_convert(int input_format, void const *d_in, uint64_t in_stride_bytes, void *d_out, uint64_t out_stride_bytes,

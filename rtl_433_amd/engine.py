@@ -145,6 +145,18 @@ class BatchEngine:
         rc = self.L.r433_batch_run_pulses(self.h, C.cast(pulses, C.c_void_p), len(pulses), stream)
         return _lib.check(rc, "r433_batch_run_pulses", self.L)
 
+    def analyze(self, stream=None):
+        """Pulse analyzer (-A) over the packages of the last run -> ctypes array of _lib.Analysis."""
+        n = self.packages()[1]
+        arr = (_lib.Analysis * max(n, 1))()
+        got = _lib.check(self.L.r433_batch_analyze(self.h, C.cast(arr, C.c_void_p), n, stream), "r433_batch_analyze", self.L)
+        return (_lib.Analysis * got).from_buffer(arr) if got else (_lib.Analysis * 0)()
+
+    def analysis_text(self, pkg, analysis):
+        buf = C.create_string_buffer(64 * 1024)
+        n = _lib.check(self.L.r433_analysis_text(self.h, pkg, C.byref(analysis), buf, len(buf)), "r433_analysis_text", self.L)
+        return buf.raw[:n].decode()
+
     def dispatch(self, rdevices, pkg_cb=None, user=None, n_threads=1):
         """rdevices: ctypes array of POINTER(RDevice) in registration order."""
         cb = C.cast(pkg_cb, C.c_void_p) if pkg_cb is not None else None

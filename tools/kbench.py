@@ -13,6 +13,7 @@ ap.add_argument("--samples", type=int, default=65536)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--nodevs", action="store_true")
 ap.add_argument("--split", type=int, default=0)
+ap.add_argument("--analyze", action="store_true", help="also time the pulse analyzer (-A) over the packages of the run")
 ap.add_argument("--cs16", action="store_true", help="config 3 style: 1024 kS/s cs16 FSK Manchester bursts, minmax detector")
 a = ap.parse_args()
 if a.cs16:
@@ -34,6 +35,19 @@ for r in range(a.reps):
 best = min(ts, key=lambda t: t["detect_ms"])
 print(f"flags={os.environ.get('R433_DEBUG_FLAGS','0')} streams={a.streams} samples={a.samples} pkgs={n} " +
       " ".join(f"{k}={v:.3f}" for k, v in best.items()) + (f" split={eng.split_stats()}" if a.split else ""))
+
+if a.analyze:
+    import time
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    best = 1e9
+    for r in range(5):
+        t0 = time.perf_counter()
+        res = eng.analyze()
+        best = min(best, time.perf_counter() - t0)
+    hist = {}
+    for x in res:
+        hist[x.guess] = hist.get(x.guess, 0) + 1
+    print(f"analyze: {len(res)} packages in {best * 1e3:.3f} ms (kernel + {len(res) * 1668 / 1e6:.1f} MB D2H + sync), guesses {dict(sorted(hist.items()))}")
 
 if int(os.environ.get("R433_DEBUG_FLAGS", "0"), 0) & 1024:
     import ctypes as C
