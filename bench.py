@@ -30,7 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")  # separate rocprofv3 --pmc pass (tools/pmc_run.sh)
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_o_pmc_traffic.json")  # separate rocprofv3 --pmc pass (tools/pmc_run.sh)
 
 
 def pmc_traffic(n_streams, n_samples, det_s):
@@ -241,7 +241,7 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": pmc_traffic(n_streams, n_samples, det_s),
                          "note": "achieved = 2 B/sample x samples per launch / isolated kernel time (HIP events); traffic = PMC "
-                                 "FETCH_SIZE(x2, gfx950)+WRITE_SIZE per launch (profiles/r01_e_pmc_traffic.json) over the same time; "
+                                 "FETCH_SIZE(x2, gfx950)+WRITE_SIZE per launch (profiles/r01_o_pmc_traffic.json) over the same time; "
                                  "the kernel is bound by single-wavefront instruction issue, not by HBM (DESIGN.md 3.1)"},
             "breakdown_ms": {"k_wave_alone": round(solo_det_ms, 3), "gpu_leg_alone_incl_d2h": round(solo_tot_ms, 3),
                              "gpu_leg_overlapped": round(float(np.mean(tot_ms)), 3),
