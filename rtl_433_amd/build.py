@@ -17,7 +17,8 @@ INC = os.path.join(HERE, "..", "include")
 OUT_DIR = os.path.join(HERE, "lib")
 OUT = os.path.join(OUT_DIR, "librtl433hip.so")
 
-SOURCES = ["stream_kernels.hip", "slicer_kernels.hip", "baseband_kernels.hip", "analyzer_kernels.hip", "host_api.cpp"]
+SOURCES = ["stream_kernels.hip", "slicer_kernels.hip", "baseband_kernels.hip", "analyzer_kernels.hip", "host_api.cpp", "batch_run.cpp",
+           "dispatch.cpp", "reports.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function", "-x", "hip"]
 
@@ -57,7 +58,7 @@ def build(force=False, verbose=False):
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
         if verbose and out:
             print(out.decode(errors="replace"))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", OUT] + objs
     subprocess.check_call(cmd)
     for o in objs:
         os.remove(o)

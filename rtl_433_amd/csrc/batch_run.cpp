@@ -1,0 +1,730 @@
+// batch_run.cpp -- r433_batch_run / r433_batch_run_pulses: the kernel sequence of one pass of the hot path, stage by
+// stage (input conversion, autolevel, segment planning, detection + stitch, slicer fan-out, host mirrors).
+#include "host_common.hpp"
+
+using namespace r433;
+
+// ---- r433_batch_run, stage by stage --------------------------------------------------------------
+namespace {
+
+// What one r433_batch_run call carries from stage to stage.
+struct RunCtx {
+    r433_batch *b;
+    hipStream_t st;
+    uint32_t ss;                  // bytes per sample: 2 = cu8, 4 = cs16
+    void const *d_iq;             // the captures as the detector sees them (after input conversion)
+    uint64_t stride_bytes;
+    uint32_t const *stream_bytes; // host, per capture; null = every capture fills the stride
+    uint32_t n_streams;
+    uint32_t max_samples = 0, frames_cap = 0, want_stride = 0;
+    int const *d_min_high = nullptr; // per-frame detection level (-Y autolevel), device
+    // plan: one wavefront per capture, or several per long capture (speculative cuts)
+    bool split = false;
+    std::vector<SegDesc> segs;
+    std::vector<uint32_t> seg_first_of; // segs of capture c: [seg_first_of[c], seg_first_of[c+1])
+    std::vector<uint32_t> cap_n;        // samples per capture
+    uint32_t max_seg_samples = 0, n_planned = 0, n_slots = 0;
+    // detection result
+    uint32_t n_order = 0;              // slots that make up the result, in capture order
+    uint32_t const *d_order = nullptr; // null = slot i is capture i
+    std::vector<uint32_t> order;
+    uint32_t total_pkgs = 0;
+
+    uint32_t const *d_lens() const { return stream_bytes ? b->d_stream_bytes.p : nullptr; }
+    int env_kind() const { return ss == 4 ? ENV_MAG_CS16 : b->cfg.use_mag_est ? ENV_MAG_CU8 : ENV_AMP_CU8; }
+};
+
+
+// cs8 / cf32 input -> cu8 / cs16 in an internal buffer
+int run_convert_input(RunCtx &r)
+{
+    r433_batch *const b = r.b;
+    if (b->cfg.input_format == R433_IN_NATIVE)
+        return 0;
+    // The reference converts these formats while it loads a file (src/rtl_433.c:1811-1834): one HBM-bound
+    // map into an internal buffer, then everything below sees cu8 / cs16 like the reference's flow does.
+    uint32_t const shrink = b->cfg.input_format == R433_IN_CF32 ? 2 : 1; // 8 B -> 4 B per sample
+    uint64_t in_max = 0;
+    b->conv_bytes.resize(r.n_streams);
+    for (uint32_t i = 0; i < r.n_streams; ++i) {
+        uint64_t const nb = r.stream_bytes ? r.stream_bytes[i] : r.stride_bytes;
+        if (nb > r.stride_bytes)
+            return fail(R433_EINVAL, "capture %u is longer than the stride", i);
+        in_max = std::max(in_max, nb);
+        b->conv_bytes[i] = (uint32_t)(nb / (shrink * r.ss) * r.ss); // whole samples
+    }
+    uint64_t const out_stride = ((in_max / shrink) + 15) & ~15ull;
+    if (int rc = b->d_converted.ensure((size_t)r.n_streams * out_stride + 16))
+        return rc;
+    launch_convert((int)b->cfg.input_format, r.d_iq, r.stride_bytes, b->d_converted.p, out_stride, in_max, r.n_streams, r.st);
+    HIP_TRY(hipGetLastError());
+    r.d_iq = b->d_converted.p;
+    r.stride_bytes = out_stride;
+    r.stream_bytes = b->conv_bytes.data();
+    return 0;
+}
+
+// capture lengths to the device, per-capture scratch, first guess of the package arena
+int run_size_buffers(RunCtx &r)
+{
+    r433_batch *const b = r.b;
+    uint32_t max_bytes = 0;
+    if (r.stream_bytes) {
+        for (uint32_t i = 0; i < r.n_streams; ++i) {
+            if (r.stream_bytes[i] > r.stride_bytes)
+                return fail(R433_EINVAL, "capture %u is longer than the stride", i);
+            max_bytes = std::max(max_bytes, r.stream_bytes[i]);
+        }
+    }
+    else {
+        max_bytes = (uint32_t)r.stride_bytes;
+    }
+    r.max_samples = max_bytes / r.ss;
+    r.frames_cap = r.max_samples / b->cfg.frame_samples + 2;
+
+    int rc;
+    if ((rc = b->d_ring.ensure((size_t)r.n_streams * R433_PD_MAX_PULSES)) || (rc = b->d_state.ensure(r.n_streams))
+            || (rc = b->d_frame_sums.ensure((size_t)r.n_streams * r.frames_cap)) || (rc = b->d_pkg_base.ensure(r.n_streams)))
+        return rc;
+    if (r.stream_bytes) {
+        if ((rc = b->d_stream_bytes.ensure(r.n_streams)))
+            return rc;
+        HIP_TRY(hipMemcpyAsync(b->d_stream_bytes.p, r.stream_bytes, r.n_streams * sizeof(uint32_t), hipMemcpyHostToDevice, r.st));
+    }
+    b->frames_cap = r.frames_cap;
+    b->n_streams = r.n_streams;
+
+    // arena: worst case is one (pulse, gap) pair per 20 samples plus headers; start at ~1 B/sample
+    r.want_stride = std::max<uint32_t>(16384u, ((r.max_samples + 4096u) + 15u) & ~15u);
+    if (b->arena_stride < r.want_stride)
+        b->arena_stride = r.want_stride;
+
+    if (b->profiling)
+        HIP_TRY(hipEventRecord(b->ev[0], r.st));
+    return 0;
+}
+
+// -Y autolevel (reference src/r_flow.c:166-186): the detection level of a frame follows the noise
+// estimate, which follows the mean envelope of the frames so far -- a short recurrence in host
+// floats (same libm as the reference) over per-frame sums that one HBM-bound pass provides.
+int run_autolevel(RunCtx &r)
+{
+    r433_batch *const b = r.b;
+    if (!(b->cfg.auto_level > 0))
+        return 0;
+    int rc;
+    if ((rc = b->d_frame_min_high.ensure((size_t)r.n_streams * r.frames_cap)) || (rc = b->h_frame_sums.ensure((size_t)r.n_streams * r.frames_cap)))
+        return rc;
+    launch_frame_sums(r.env_kind(), r.d_iq, r.stride_bytes, r.d_lens(), (uint32_t)r.stride_bytes, r.n_streams,
+            b->cfg.frame_samples, r.frames_cap, b->d_frame_sums.p, r.st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(b->h_frame_sums.p, b->d_frame_sums.p, (size_t)r.n_streams * r.frames_cap * sizeof(uint32_t),
+            hipMemcpyDeviceToHost, r.st));
+    HIP_TRY(stream_wait(b, r.st));
+    b->h_frame_min_high.assign((size_t)r.n_streams * r.frames_cap, b->det.min_high);
+    int const is_mag = r.ss == 4 || b->cfg.use_mag_est;
+    for (uint32_t s = 0; s < r.n_streams; ++s) {
+        uint32_t const n = (r.stream_bytes ? r.stream_bytes[s] : (uint32_t)r.stride_bytes) / r.ss;
+        float noise_level = 0.0f, min_level_auto = 0.0f;
+        DetCfg lv = b->det;
+        for (uint32_t f = 0; f < r.frames_cap; ++f) {
+            uint64_t const start = (uint64_t)f * b->cfg.frame_samples;
+            if (start < n) {
+                uint32_t const cnt = (uint32_t)std::min<uint64_t>(b->cfg.frame_samples, n - start);
+                float const avg_db = r433_level_db(b->h_frame_sums.p[(size_t)s * r.frames_cap + f], cnt, is_mag);
+                if (min_level_auto == 0.0f)
+                    min_level_auto = b->cfg.min_level_db;
+                if (noise_level == 0.0f)
+                    noise_level = min_level_auto - 3.0f;
+                if (avg_db < noise_level + 3.0f) {
+                    noise_level = (noise_level * 7 + avg_db) / 8;
+                    if (noise_level < b->cfg.min_level_db - 3.0f && fabsf(min_level_auto - noise_level - 3.0f) > 1.0f) {
+                        min_level_auto = noise_level + 3.0f;
+                        levels_from_db(lv, (int)b->cfg.use_mag_est, b->cfg.level_limit_db, min_level_auto, b->cfg.min_snr_db);
+                    }
+                }
+                else {
+                    noise_level = (noise_level * 31 + avg_db) / 32;
+                }
+            }
+            b->h_frame_min_high[(size_t)s * r.frames_cap + f] = lv.min_high;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(b->d_frame_min_high.p, b->h_frame_min_high.data(), b->h_frame_min_high.size() * sizeof(int),
+            hipMemcpyHostToDevice, r.st));
+    r.d_min_high = b->d_frame_min_high.p;
+    return 0;
+}
+
+// Where long captures may be cut: at the end of 12.5 ms of quiet, about every split_samples samples.
+int run_plan_split(RunCtx &r, uint32_t split_samples)
+{
+    r433_batch *const b = r.b;
+    int rc;
+    constexpr uint32_t kTileS = 2048;
+    uint32_t const tiles_cap = r.max_samples / kTileS + 1;
+    if ((rc = b->d_tile_max.ensure((size_t)r.n_streams * tiles_cap)) || (rc = b->h_tile_max.ensure((size_t)r.n_streams * tiles_cap)))
+        return rc;
+    launch_tile_max(r.env_kind(), r.d_iq, r.stride_bytes, r.d_lens(), (uint32_t)r.stride_bytes, r.n_streams,
+            tiles_cap, b->d_tile_max.p, r.st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(b->h_tile_max.p, b->d_tile_max.p, (size_t)r.n_streams * tiles_cap * sizeof(uint32_t), hipMemcpyDeviceToHost, r.st));
+    HIP_TRY(stream_wait(b, r.st));
+    // A tile is quiet when it carries no more energy than the noise floor: mean envelope at most 1.5x
+    // the capture's median tile, or -- for captures that are mostly signal -- below half the
+    // falling-edge level of the lowest threshold the detector can have (pulse_detect.c:300-304).
+    int thr = (-1 + std::min(b->det.min_high, b->det.max_high)) / 2;
+    if (b->det.fixed_high)
+        thr = b->det.fixed_high;
+    uint64_t const abs_quiet = (uint64_t)std::max(1, (thr - thr / 8) / 2) * 2048u;
+    bool const blind = getenv("R433_SPLIT_BLIND") != nullptr; // tests: cut anywhere, let the verification sort it out
+    uint32_t const seg_len = (split_samples + kTileS - 1) / kTileS * kTileS;
+    // a package stays open until its last gap exceeds 10 pulse widths and 10 ms (pulse_detect.c:446-450):
+    // ask for 12.5 ms of quiet before a cut (pulses up to 1.25 ms; the stitch catches the rest)
+    uint32_t const quiet_tiles = std::max<uint32_t>(2u, (b->cfg.samp_rate / 80u + kTileS - 1) / kTileS);
+    r.max_seg_samples = 0;
+    for (uint32_t c = 0; c < r.n_streams; ++c) {
+        r.seg_first_of[c] = (uint32_t)r.segs.size();
+        uint32_t const n = r.cap_n[c];
+        uint32_t const *tm = b->h_tile_max.p + (size_t)c * tiles_cap;
+        uint64_t quiet_below = abs_quiet; // on tile sums
+        if (n >= 2 * kTileS) {
+            std::vector<uint32_t> med(tm, tm + n / kTileS);
+            std::nth_element(med.begin(), med.begin() + med.size() / 2, med.end());
+            quiet_below = std::max<uint64_t>(abs_quiet, (uint64_t)med[med.size() / 2] * 3 / 2);
+        }
+        std::vector<uint32_t> cuts;
+        uint32_t pos = seg_len;
+        while (n > seg_len && pos + seg_len / 2 < n) {
+            uint32_t cut = 0;
+            for (uint32_t P = pos; P < std::min(n, pos + seg_len) && P + kTileS <= n; P += kTileS) {
+                bool quiet = P / kTileS >= quiet_tiles;
+                for (uint32_t q = 1; quiet && q <= quiet_tiles; ++q)
+                    quiet = tm[P / kTileS - q] < quiet_below;
+                if (blind || quiet) {
+                    cut = P;
+                    break;
+                }
+            }
+            if (cut) {
+                cuts.push_back(cut);
+                pos = cut + seg_len;
+            }
+            else {
+                pos += seg_len;
+            }
+        }
+        uint32_t from = 0;
+        for (size_t k = 0; k <= cuts.size(); ++k) {
+            uint32_t const to = k < cuts.size() ? cuts[k] : n;
+            uint32_t const last = k == cuts.size() ? SEG_LAST : 0u;
+            if (k == 0) {
+                r.segs.push_back(SegDesc{c, 0u, to, SEG_FIRST | SEG_PRIMARY | last});
+            }
+            else { // both parities of the noise floor
+                r.segs.push_back(SegDesc{c, from, to, SEG_PRIMARY | last});
+                r.segs.push_back(SegDesc{c, from, to, SEG_ODD | last});
+            }
+            r.max_seg_samples = std::max(r.max_seg_samples, to - from + kTileS);
+            from = to;
+        }
+    }
+    r.seg_first_of[r.n_streams] = (uint32_t)r.segs.size();
+    return 0;
+}
+
+// one wavefront per capture, or several per long capture
+int run_plan(RunCtx &r)
+{
+    r433_batch *const b = r.b;
+    int rc;
+    r.seg_first_of.assign(r.n_streams + 1, 0);
+    r.cap_n.resize(r.n_streams);
+    for (uint32_t c = 0; c < r.n_streams; ++c)
+        r.cap_n[c] = (r.stream_bytes ? r.stream_bytes[c] : (uint32_t)r.stride_bytes) / r.ss;
+    // automatic: only where one wavefront per capture would leave the chip empty -- few, long captures.
+    // Aim at ~4096 segments, at least 32 Ki samples each.
+    uint32_t split_samples = b->split_samples;
+    if (split_samples == R433_SPLIT_AUTO) {
+        uint64_t total = 0;
+        for (uint32_t c = 0; c < r.n_streams; ++c)
+            total += r.cap_n[c];
+        split_samples = (r.n_streams <= 64 && r.max_samples >= (1u << 20)) ? (uint32_t)std::max<uint64_t>(32768, total / 4096) : 0u;
+    }
+    r.split = split_samples > 0;
+    r.max_seg_samples = r.max_samples;
+    r.n_order = r.n_streams;
+    if (r.split && (rc = run_plan_split(r, split_samples)))
+        return rc;
+    r.n_planned = r.split ? (uint32_t)r.segs.size() : r.n_streams;
+    r.n_slots = r.split ? 3 * r.n_planned : r.n_streams; // + re-run slots for cuts that have to be dropped
+    if (r.split && b->arena_stride == r.want_stride) // sized for whole captures above: segments need less
+        b->arena_stride = std::max<uint32_t>(16384u, ((r.max_seg_samples + 4096u) + 15u) & ~15u);
+    if ((rc = b->d_ring.ensure((size_t)r.n_slots * R433_PD_MAX_PULSES)) || (rc = b->d_state.ensure(r.n_slots))
+            || (rc = b->d_pkg_base.ensure(r.n_slots)) || (rc = b->h_state.ensure(r.n_slots)) || (rc = b->d_order.ensure(r.n_slots))
+            || (rc = b->d_segs.ensure(r.n_slots)))
+        return rc;
+    return 0;
+}
+
+// what every launch of the detection kernel in this run shares
+StreamParams stream_params(RunCtx const &r)
+{
+    r433_batch *const b = r.b;
+    StreamParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.iq = (uint8_t const *)r.d_iq;
+    sp.stride_bytes = r.stride_bytes;
+    sp.stream_bytes = r.d_lens();
+    sp.uniform_bytes = (uint32_t)r.stride_bytes;
+    sp.n_streams = r.n_planned;
+    sp.frame_samples = b->cfg.frame_samples;
+    sp.flags = 0;
+    if (char const *dbg = getenv("R433_DEBUG_FLAGS")) // phase timing experiments only (results are then incomplete)
+        sp.flags |= (uint32_t)strtoul(dbg, nullptr, 0) & (RUN_DBG_SKIP_DETECT | RUN_DBG_SKIP_FILTERS | RUN_DBG_TIMING);
+    sp.det = b->det;
+    sp.use_mag = (int)b->cfg.use_mag_est;
+    sp.enable_fm = (int)b->cfg.enable_fm;
+    sp.a16 = b->a16;
+    sp.b16 = b->b16;
+    sp.a32 = b->a32;
+    sp.b32 = b->b32;
+    sp.arena = b->d_arena.p;
+    sp.arena_stride = b->arena_stride;
+    sp.fsk_ring = b->d_ring.p;
+    sp.state = b->d_state.p;
+    sp.frame_sums = b->d_frame_sums.p;
+    sp.frames_cap = r.frames_cap;
+    sp.frame_min_high = r.d_min_high;
+    sp.tap_env = (uint16_t *)b->tap_env;
+    sp.tap_am = (int16_t *)b->tap_am;
+    sp.tap_fm = (int16_t *)b->tap_fm;
+    sp.tap_stride = b->tap_stride;
+    return sp;
+}
+
+// Stitch.  Per capture an ordered list of pieces; every piece but the first exists in two
+// parity variants (two slots).  Walk the pieces in order; at each cut keep the variant that
+// assumed exactly the floor (and the level estimate that an idle step leaves behind: a spurious
+// short pulse returns to idle without one) the piece before it really ended with, and require
+// that piece to have ended idle with the lead-in saturated -- that is the detector's whole
+// state between packages (everything else is reset when a pulse starts).  A cut that does not verify is
+// dropped: the piece before it is run again through to the end of the next piece, and the walk resumes from there.  Every
+// round removes at least one cut per capture that still has a problem, so this terminates.
+int run_stitch(RunCtx &r, StreamParams const &sp)
+{
+    r433_batch *const b = r.b;
+    int rc;
+    struct Piece {
+        SegDesc seg;      // flags without SEG_ODD / SEG_PRIMARY
+        uint32_t slot[2]; // even / odd parity variant (the first piece of a capture: slot[0] only)
+    };
+    std::vector<std::vector<Piece>> pieces(r.n_streams);
+    for (uint32_t c = 0; c < r.n_streams; ++c)
+        for (uint32_t k = r.seg_first_of[c]; k < r.seg_first_of[c + 1]; k += (k == r.seg_first_of[c] ? 1 : 2)) {
+            Piece pc;
+            pc.seg = r.segs[k];
+            pc.seg.flags &= ~(uint32_t)(SEG_ODD | SEG_PRIMARY);
+            pc.slot[0] = k;
+            pc.slot[1] = k == r.seg_first_of[c] ? k : k + 1;
+            pieces[c].push_back(pc);
+        }
+    uint32_t n_have = r.n_planned; // slots whose state is on the host
+    std::vector<SegDesc> slot_seg(r.segs), launch_list;
+    auto new_slot = [&](SegDesc const &d) {
+        launch_list.push_back(d);
+        slot_seg.push_back(d);
+        return n_have + (uint32_t)launch_list.size() - 1;
+    };
+    auto run_launch_list = [&]() -> int {
+        if (launch_list.empty())
+            return 0;
+        if (n_have + launch_list.size() > r.n_slots)
+            return fail(R433_EHIP, "r.split bookkeeping ran out of slots");
+        b->last_redone += (uint32_t)launch_list.size();
+        HIP_TRY(hipMemcpyAsync(b->d_segs.p + n_have, launch_list.data(), launch_list.size() * sizeof(SegDesc), hipMemcpyHostToDevice, r.st));
+        StreamParams sr = sp;
+        sr.n_streams = (uint32_t)launch_list.size();
+        sr.segs = b->d_segs.p + n_have;
+        sr.arena = b->d_arena.p + (size_t)n_have * b->arena_stride;
+        sr.fsk_ring = b->d_ring.p + (size_t)n_have * R433_PD_MAX_PULSES;
+        sr.state = b->d_state.p + n_have;
+        launch_stream(sr, r.ss, r.st);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(b->h_state.p + n_have, b->d_state.p + n_have, launch_list.size() * sizeof(StreamState), hipMemcpyDeviceToHost, r.st));
+        HIP_TRY(stream_wait(b, r.st));
+        n_have += (uint32_t)launch_list.size();
+        launch_list.clear();
+        return 0;
+    };
+    HIP_TRY(hipMemcpyAsync(b->h_state.p, b->d_state.p, (size_t)r.n_planned * sizeof(StreamState), hipMemcpyDeviceToHost, r.st));
+    HIP_TRY(stream_wait(b, r.st));
+    // (1) cuts neither variant could start from (no provable filter carry or floor: digital
+    // silence does that) are known now, all at once: merge across them in one extra launch
+    for (uint32_t c = 0; c < r.n_streams; ++c) {
+        std::vector<Piece> merged;
+        for (Piece const &pc : pieces[c]) {
+            bool const unstartable = !merged.empty() && b->h_state.p[pc.slot[0]].seg_fail && b->h_state.p[pc.slot[1]].seg_fail;
+            if (!unstartable) {
+                merged.push_back(pc);
+                continue;
+            }
+            Piece &m = merged.back();
+            m.seg.end = pc.seg.end;
+            m.seg.flags |= pc.seg.flags & SEG_LAST;
+            m.slot[0] = m.slot[1] = UINT32_MAX; // to be run again
+        }
+        for (Piece &m : merged)
+            if (m.slot[0] == UINT32_MAX) {
+                SegDesc d = m.seg;
+                d.flags |= SEG_PRIMARY;
+                m.slot[0] = new_slot(d);
+                m.slot[1] = m.slot[0];
+                if (!(d.flags & SEG_FIRST)) {
+                    d.flags = (d.flags & ~(uint32_t)SEG_PRIMARY) | SEG_ODD;
+                    m.slot[1] = new_slot(d);
+                }
+            }
+        pieces[c].swap(merged);
+    }
+    if ((rc = run_launch_list()))
+        return rc;
+    // (2) the walk proper
+    std::vector<std::vector<uint32_t>> chosen(r.n_streams);
+    std::vector<size_t> at(r.n_streams, 1);
+    std::vector<uint32_t> dropped(r.n_streams, 0);
+    for (uint32_t c = 0; c < r.n_streams; ++c)
+        chosen[c].push_back(pieces[c][0].slot[0]);
+    for (;;) {
+        for (uint32_t c = 0; c < r.n_streams; ++c) {
+            std::vector<Piece> &pcs = pieces[c];
+            while (at[c] < pcs.size()) {
+                uint32_t const cur = chosen[c].back();
+                StreamState const &P = b->h_state.p[cur];
+                Piece const &nx = pcs[at[c]];
+                uint32_t pick = UINT32_MAX;
+                if (P.seg_end_state == ST_IDLE && P.seg_end_lead == 1025)
+                    for (int v = 0; v < 2; ++v)
+                        if (!b->h_state.p[nx.slot[v]].seg_fail && b->h_state.p[nx.slot[v]].seg_init_low == P.seg_end_low
+                                && b->h_state.p[nx.slot[v]].seg_init_high == P.seg_end_high)
+                            pick = nx.slot[v];
+                if (pick != UINT32_MAX) {
+                    chosen[c].push_back(pick);
+                    at[c] += 1;
+                    dropped[c] = 0;
+                    continue;
+                }
+                // drop this cut: the standing piece continues through the next one.  (Three cuts in a
+                // row that fail are not worth a fourth try: the piece then runs to the capture's end.)
+                bool const give_up = ++dropped[c] >= 3;
+                if (getenv("R433_SPLIT_DEBUG"))
+                    fprintf(stderr, "r.split: capture %u cut at %u dropped (end state %d, floor %d vs %d/%d, fail %d/%d)\n", c, nx.seg.start,
+                            P.seg_end_state, P.seg_end_low, b->h_state.p[nx.slot[0]].seg_init_low, b->h_state.p[nx.slot[1]].seg_init_low,
+                            b->h_state.p[nx.slot[0]].seg_fail, b->h_state.p[nx.slot[1]].seg_fail);
+                SegDesc d = slot_seg[cur];
+                d.end = give_up ? r.cap_n[c] : nx.seg.end;
+                d.flags = (d.flags & ~(uint32_t)SEG_LAST) | (give_up ? (uint32_t)SEG_LAST : (nx.seg.flags & SEG_LAST));
+                chosen[c].back() = new_slot(d);
+                at[c] = give_up ? pcs.size() : at[c] + 1;
+                break; // its end state is not known yet: resume in the next round
+            }
+        }
+        if (launch_list.empty())
+            break;
+        if ((rc = run_launch_list()))
+            return rc;
+    }
+    r.order.clear();
+    for (uint32_t c = 0; c < r.n_streams; ++c)
+        r.order.insert(r.order.end(), chosen[c].begin(), chosen[c].end());
+    r.n_order = (uint32_t)r.order.size();
+    HIP_TRY(hipMemcpyAsync(b->d_order.p, r.order.data(), r.order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, r.st));
+    r.d_order = b->d_order.p;
+    return 0;
+}
+
+// envelope, filters, pulse detection: packages per slot in the arena (grown and repeated if it overflows)
+int run_detect(RunCtx &r)
+{
+    r433_batch *const b = r.b;
+    int rc;
+    for (int attempt = 0;; ++attempt) {
+        if ((rc = b->d_arena.ensure((size_t)r.n_slots * b->arena_stride)))
+            return rc;
+        StreamParams sp = stream_params(r);
+        if (r.split) { // segments overlap in frames and may be re-run: the sums come from their own HBM-bound pass
+            sp.frame_sums = nullptr;
+            launch_frame_sums(r.env_kind(), r.d_iq, r.stride_bytes, r.d_lens(), (uint32_t)r.stride_bytes, r.n_streams,
+                    b->cfg.frame_samples, r.frames_cap, b->d_frame_sums.p, r.st);
+        }
+        else {
+            HIP_TRY(hipMemsetAsync(b->d_frame_sums.p, 0, (size_t)r.n_streams * r.frames_cap * sizeof(uint32_t), r.st));
+        }
+        r.d_order = nullptr;
+        b->last_segments = r.n_planned;
+        b->last_redone = 0;
+        if (r.split) {
+            HIP_TRY(hipMemcpyAsync(b->d_segs.p, r.segs.data(), r.segs.size() * sizeof(SegDesc), hipMemcpyHostToDevice, r.st));
+            sp.segs = b->d_segs.p;
+        }
+        launch_stream(sp, r.ss, r.st);
+        HIP_TRY(hipGetLastError());
+        if (r.split && (rc = run_stitch(r, sp)))
+            return rc;
+        if (b->profiling && attempt == 0)
+            HIP_TRY(hipEventRecord(b->ev[1], r.st));
+        launch_pkg_scan(b->d_state.p, r.d_order, r.n_order, b->d_pkg_base.p, b->d_scal.p, r.st);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(b->h_scal.p, b->d_scal.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, r.st));
+        HIP_TRY(stream_wait(b, r.st));
+        r.total_pkgs = b->h_scal.p[0];
+        if (!b->h_scal.p[1])
+            break;
+        if (attempt >= 6 || b->arena_stride > (1u << 28))
+            return fail(R433_EOVERFLOW, "package arena overflow (stride %u)", b->arena_stride);
+        b->arena_stride *= 4;
+    }
+    return 0;
+}
+
+// package directory, slicer fan-out, results to the host mirrors
+int run_slice_and_mirror(RunCtx &r)
+{
+    r433_batch *const b = r.b;
+    int rc;
+    b->n_pkgs = r.total_pkgs;
+    b->n_events = 0;
+    b->pkg_bytes = b->evt_bytes = 0;
+    uint32_t const n_devs = (uint32_t)b->timing.size();
+    uint32_t const max_pkgs = std::max<uint32_t>(r.total_pkgs, 1);
+
+    if ((rc = b->d_dir_stream.ensure(max_pkgs)) || (rc = b->d_dir_off.ensure(max_pkgs))
+            || (rc = b->d_rec_bytes.ensure(max_pkgs)) || (rc = b->d_rec_off.ensure(max_pkgs))
+            || (rc = b->d_pkg_bytes.ensure(max_pkgs)) || (rc = b->d_pkg_off.ensure(max_pkgs))
+            || (rc = b->d_sizes.ensure((size_t)max_pkgs * std::max<uint32_t>(n_devs, 1))))
+        return rc;
+
+    launch_directory(b->d_arena.p, b->arena_stride, b->d_state.p, r.split ? b->d_order.p : nullptr, r.n_order, b->d_pkg_base.p,
+            b->d_dir_stream.p, b->d_dir_off.p, b->d_rec_bytes.p, max_pkgs, r.st);
+    launch_scan_u32(b->d_rec_bytes.p, b->d_rec_off.p, b->d_scal.p, max_pkgs, b->d_scal.p + 2, r.st);
+    HIP_TRY(hipGetLastError());
+    if (b->profiling)
+        HIP_TRY(hipEventRecord(b->ev[2], r.st));
+
+    SliceParams lp;
+    memset(&lp, 0, sizeof(lp));
+    lp.arena = b->d_arena.p;
+    lp.arena_stride = b->arena_stride;
+    lp.dir_stream = b->d_dir_stream.p;
+    lp.dir_off = b->d_dir_off.p;
+    lp.n_pkgs = b->d_scal.p;
+    lp.devs = b->d_rows.p;
+    lp.n_rows = (uint32_t)b->rows.size();
+    lp.n_devs = n_devs;
+    lp.sizes = b->d_sizes.p;
+    lp.pkg_bytes = b->d_pkg_bytes.p;
+    lp.pkg_off = b->d_pkg_off.p;
+    lp.max_pkgs = max_pkgs;
+    if (n_devs && r.total_pkgs) {
+        // One slicing pass into staging slots when they fit.  A default device set yields ~135 B per
+        // (package, device) on average but the heavy PCM rows reach a few KB, and those are exactly the
+        // slow lanes, so the slot is made as large as the arena budget allows (up to 4 KB); below 512 B
+        // the classic count + write pair runs instead.
+        constexpr size_t kStageMax = (size_t)6 << 30;
+        uint32_t stage_cap = 4096;
+        while (stage_cap >= 512 && (size_t)r.total_pkgs * b->rows.size() * stage_cap > kStageMax)
+            stage_cap >>= 1;
+        if (stage_cap >= 512 && !getenv("R433_TWO_PASS_SLICER")) {
+            if ((rc = b->d_stage.ensure((size_t)r.total_pkgs * b->rows.size() * stage_cap)))
+                return rc;
+            lp.stage = b->d_stage.p;
+            lp.stage_cap = stage_cap;
+        }
+        HIP_TRY(hipMemsetAsync(b->d_pkg_bytes.p, 0, (size_t)max_pkgs * sizeof(uint32_t), r.st));
+        launch_slice_count(lp, r.total_pkgs, r.st);
+        HIP_TRY(hipGetLastError());
+        if (b->profiling)
+            HIP_TRY(hipEventRecord(b->ev[3], r.st));
+        launch_scan_u32(b->d_pkg_bytes.p, b->d_pkg_off.p, b->d_scal.p, max_pkgs, b->d_scal.p + 3, r.st);
+    }
+    else {
+        HIP_TRY(hipMemsetAsync(b->d_scal.p + 3, 0, sizeof(uint32_t), r.st));
+        if (b->profiling)
+            HIP_TRY(hipEventRecord(b->ev[3], r.st));
+    }
+    if (b->profiling)
+        HIP_TRY(hipEventRecord(b->ev[4], r.st));
+    HIP_TRY(hipMemcpyAsync(b->h_scal.p, b->d_scal.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, r.st));
+    HIP_TRY(stream_wait(b, r.st));
+    size_t const pkg_bytes = b->h_scal.p[2];
+    size_t const evt_bytes = b->h_scal.p[3];
+    if (evt_bytes > 0xf0000000ull)
+        return fail(R433_EOVERFLOW, "event stream exceeds 4 GiB; r.split the batch");
+
+    if ((rc = b->d_pkg_blob.ensure(pkg_bytes + 16)) || (rc = b->h_pkg_blob.ensure(pkg_bytes + 16))
+            || (rc = b->d_events.ensure(evt_bytes + 16)) || (rc = b->h_events.ensure(evt_bytes + 16))
+            || (rc = b->h_frame_sums.ensure((size_t)r.n_streams * r.frames_cap)) || (rc = b->h_pkg_off.ensure(max_pkgs + 1))
+            || (rc = b->h_rec_off.ensure(max_pkgs + 1)))
+        return rc;
+    if (r.total_pkgs) {
+        launch_gather_packages(b->d_arena.p, b->arena_stride, b->d_dir_stream.p, b->d_dir_off.p, b->d_rec_off.p,
+                b->d_scal.p, max_pkgs, b->d_pkg_blob.p, (uint32_t)std::min<size_t>(b->d_pkg_blob.cap, 0xffffffffu),
+                r.total_pkgs, r.st);
+        if (n_devs && evt_bytes) {
+            lp.events = b->d_events.p;
+            lp.events_cap = (uint32_t)std::min<size_t>(b->d_events.cap, 0xffffffffu);
+            launch_slice_write(lp, r.total_pkgs, r.st);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    if (b->profiling)
+        HIP_TRY(hipEventRecord(b->ev[5], r.st));
+    if (pkg_bytes)
+        HIP_TRY(hipMemcpyAsync(b->h_pkg_blob.p, b->d_pkg_blob.p, pkg_bytes, hipMemcpyDeviceToHost, r.st));
+    if (evt_bytes)
+        HIP_TRY(hipMemcpyAsync(b->h_events.p, b->d_events.p, evt_bytes, hipMemcpyDeviceToHost, r.st));
+    if (r.total_pkgs) {
+        HIP_TRY(hipMemcpyAsync(b->h_rec_off.p, b->d_rec_off.p, r.total_pkgs * sizeof(uint32_t), hipMemcpyDeviceToHost, r.st));
+        if (n_devs)
+            HIP_TRY(hipMemcpyAsync(b->h_pkg_off.p, b->d_pkg_off.p, r.total_pkgs * sizeof(uint32_t), hipMemcpyDeviceToHost, r.st));
+    }
+    HIP_TRY(hipMemcpyAsync(b->h_frame_sums.p, b->d_frame_sums.p, (size_t)r.n_streams * r.frames_cap * sizeof(uint32_t),
+            hipMemcpyDeviceToHost, r.st));
+    if (b->profiling)
+        HIP_TRY(hipEventRecord(b->ev[6], r.st));
+    HIP_TRY(stream_wait(b, r.st));
+    b->pkg_bytes = pkg_bytes;
+    b->evt_bytes = evt_bytes;
+    b->events_counted = false;
+    b->h_rec_off.p[r.total_pkgs] = (uint32_t)pkg_bytes;
+    b->h_pkg_off.p[r.total_pkgs] = (uint32_t)evt_bytes;
+    if (!n_devs)
+        for (uint32_t i = 0; i < r.total_pkgs; ++i)
+            b->h_pkg_off.p[i] = 0;
+
+    if (b->profiling) {
+        r433_batch_timing &t = b->last_timing;
+        (void)hipEventElapsedTime(&t.detect_ms, b->ev[0], b->ev[1]);
+        (void)hipEventElapsedTime(&t.dir_ms, b->ev[1], b->ev[2]);
+        (void)hipEventElapsedTime(&t.count_ms, b->ev[2], b->ev[3]);
+        (void)hipEventElapsedTime(&t.scan_ms, b->ev[3], b->ev[4]);
+        (void)hipEventElapsedTime(&t.write_ms, b->ev[4], b->ev[5]);
+        (void)hipEventElapsedTime(&t.d2h_ms, b->ev[5], b->ev[6]);
+        (void)hipEventElapsedTime(&t.total_ms, b->ev[0], b->ev[6]);
+    }
+    return (int)r.total_pkgs;
+}
+
+} // namespace
+
+extern "C" {
+
+int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint32_t const *stream_bytes,
+        uint32_t n_streams, void *stream)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    if (n_streams == 0) {
+        b->n_streams = 0;
+        b->n_pkgs = b->n_events = 0;
+        b->pkg_bytes = b->evt_bytes = 0;
+        return 0;
+    }
+    if (!d_iq || (stride_bytes & 15u) || ((uintptr_t)d_iq & 15u))
+        return fail(R433_EINVAL, "capture base and stride must be 16-byte aligned");
+    if (stride_bytes > 0xfffffff0ull)
+        return fail(R433_EINVAL, "captures are limited to 4 GiB each");
+    RunCtx r;
+    r.b = b;
+    r.st = (hipStream_t)stream;
+    r.ss = b->cfg.sample_size;
+    r.d_iq = d_iq;
+    r.stride_bytes = stride_bytes;
+    r.stream_bytes = stream_bytes;
+    r.n_streams = n_streams;
+    int rc;
+    if ((rc = run_convert_input(r)) || (rc = run_size_buffers(r)) || (rc = run_autolevel(r)) || (rc = run_plan(r))
+            || (rc = run_detect(r)))
+        return rc;
+    return run_slice_and_mirror(r);
+}
+
+int r433_batch_run_pulses(r433_batch *b, r433_pulse_data const *pulses, uint32_t n_packages, void *stream)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    if (n_packages == 0) {
+        b->n_streams = 0;
+        b->n_pkgs = b->n_events = 0;
+        b->pkg_bytes = b->evt_bytes = 0;
+        return 0;
+    }
+    if (!pulses)
+        return fail(R433_EINVAL, "null pulse data");
+    RunCtx r;
+    r.b = b;
+    r.st = (hipStream_t)stream;
+    r.ss = b->cfg.sample_size;
+    r.d_iq = nullptr;
+    r.stride_bytes = 0;
+    r.stream_bytes = nullptr;
+    r.n_streams = n_packages;
+    r.frames_cap = 1;
+    r.n_order = n_packages;
+    // one arena slot per package, laid out exactly as the detection kernel leaves a capture with one package
+    uint32_t max_pulses = 0;
+    for (uint32_t k = 0; k < n_packages; ++k) {
+        if (pulses[k].num_pulses > R433_PD_MAX_PULSES)
+            return fail(R433_EINVAL, "package %u has %u pulses (at most %u)", k, pulses[k].num_pulses, (unsigned)R433_PD_MAX_PULSES);
+        max_pulses = std::max(max_pulses, pulses[k].num_pulses);
+    }
+    uint32_t const stride = ((uint32_t)sizeof(r433_pkg_rec) + 8u * max_pulses + 15u) & ~15u;
+    int rc;
+    if ((rc = b->d_arena.ensure((size_t)n_packages * stride)) || (rc = b->d_state.ensure(n_packages))
+            || (rc = b->d_pkg_base.ensure(n_packages)) || (rc = b->d_frame_sums.ensure(n_packages))
+            || (rc = b->h_arena_stage.ensure((size_t)n_packages * stride)) || (rc = b->h_state.ensure(n_packages)))
+        return rc;
+    b->arena_stride = stride;
+    b->frames_cap = 1;
+    b->n_streams = n_packages;
+    memset(b->h_arena_stage.p, 0, (size_t)n_packages * stride);
+    memset(b->h_state.p, 0, (size_t)n_packages * sizeof(StreamState));
+    for (uint32_t k = 0; k < n_packages; ++k) {
+        r433_pulse_data const &pd = pulses[k];
+        uint8_t *rec = b->h_arena_stage.p + (size_t)k * stride;
+        r433_pkg_rec h;
+        memset(&h, 0, sizeof(h));
+        h.total_bytes = (uint32_t)sizeof(h) + 8u * pd.num_pulses;
+        h.stream = k;
+        h.type = pd.fsk_f2_est ? R433_PKG_FSK : R433_PKG_OOK; // as the reference decides, src/rtl_433.c:1774
+        h.num_pulses = pd.num_pulses;
+        h.offset = pd.offset;
+        h.start_ago = pd.start_ago;
+        h.end_ago = pd.end_ago;
+        h.ook_low = pd.ook_low_estimate;
+        h.ook_high = pd.ook_high_estimate;
+        h.fsk_f1 = pd.fsk_f1_est;
+        h.fsk_f2 = pd.fsk_f2_est;
+        h.sample_rate = pd.sample_rate ? pd.sample_rate : b->cfg.samp_rate;
+        memcpy(rec, &h, sizeof(h));
+        int32_t *pairs = (int32_t *)(rec + sizeof(h));
+        for (uint32_t i = 0; i < pd.num_pulses; ++i) {
+            pairs[2 * i] = pd.pulse[i];
+            pairs[2 * i + 1] = pd.gap[i];
+        }
+        b->h_state.p[k].n_pkgs = 1;
+        b->h_state.p[k].cursor = h.total_bytes;
+    }
+    if (b->profiling)
+        for (int e = 0; e < 2; ++e)
+            HIP_TRY(hipEventRecord(b->ev[e], r.st));
+    HIP_TRY(hipMemcpyAsync(b->d_arena.p, b->h_arena_stage.p, (size_t)n_packages * stride, hipMemcpyHostToDevice, r.st));
+    HIP_TRY(hipMemcpyAsync(b->d_state.p, b->h_state.p, (size_t)n_packages * sizeof(StreamState), hipMemcpyHostToDevice, r.st));
+    HIP_TRY(hipMemsetAsync(b->d_frame_sums.p, 0, (size_t)n_packages * sizeof(uint32_t), r.st));
+    launch_pkg_scan(b->d_state.p, nullptr, n_packages, b->d_pkg_base.p, b->d_scal.p, r.st);
+    HIP_TRY(hipGetLastError());
+    r.total_pkgs = n_packages;
+    return run_slice_and_mirror(r);
+}
+
+} // extern "C"

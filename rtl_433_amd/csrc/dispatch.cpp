@@ -1,0 +1,310 @@
+// dispatch.cpp -- the host-side decoder dispatch that mirrors the reference's run_ook_demods / run_fsk_demods +
+// account_event (src/r_api.c:438-550, src/pulse_slicer.c:26-66), single- and multi-threaded, and the checksum plugin.
+#include "host_common.hpp"
+
+using namespace r433;
+
+namespace {
+
+// The checksum plugin accumulates per thread and publishes once per dispatch: a shared counter hit by
+// every bitbuffer from 32 threads is a cache-line ping-pong that costs more than the decoding.
+struct DigestLocal {
+    r433_digest_ctx *ctx = nullptr;
+    uint64_t sum = 0, events = 0;
+};
+thread_local DigestLocal g_digest;
+
+void digest_publish()
+{
+    if (g_digest.ctx && g_digest.events) {
+        __atomic_fetch_add(&g_digest.ctx->sum, g_digest.sum, __ATOMIC_RELAXED);
+        __atomic_fetch_add(&g_digest.ctx->events, g_digest.events, __ATOMIC_RELAXED);
+    }
+    g_digest = DigestLocal();
+}
+
+} // namespace
+
+namespace r433 {
+
+// calc_rssi_snr, reference src/r_flow.c:35-64
+void fill_levels(r433_flow_cfg const &cfg, r433_pulse_data &p)
+{
+    float hi = p.ook_high_estimate > 0 ? p.ook_high_estimate : 1;
+    float lo = p.ook_low_estimate > 0 ? p.ook_low_estimate : 1;
+    int const max_high = (int)powf(10, (0 + 42.1442f) / 10.0f);
+    float mx = hi < max_high ? hi : max_high;
+    float asnr = mx / lo;
+    float f1 = (float)p.fsk_f1_est / INT16_MAX * cfg.samp_rate / 2.0f;
+    float f2 = (float)p.fsk_f2_est / INT16_MAX * cfg.samp_rate / 2.0f;
+    p.freq1_hz = f1 + cfg.center_frequency;
+    p.freq2_hz = f2 + cfg.center_frequency;
+    p.centerfreq_hz = cfg.center_frequency;
+    p.depth_bits = cfg.sample_size * 4;
+    if (cfg.sample_size == 2 && !cfg.use_mag_est) {
+        p.range_db = 42.1442f;
+        p.rssi_db = 10.0f * log10f(hi) - 42.1442f;
+        p.noise_db = 10.0f * log10f(lo) - 42.1442f;
+        p.snr_db = 10.0f * log10f(asnr);
+    }
+    else {
+        p.range_db = 84.2884f;
+        p.rssi_db = 20.0f * log10f(hi) - 84.2884f;
+        p.noise_db = 20.0f * log10f(lo) - 84.2884f;
+        p.snr_db = 20.0f * log10f(asnr);
+    }
+}
+
+} // namespace r433
+
+extern "C" {
+
+// ---- decoder dispatch ----
+
+namespace {
+
+struct DevStats {
+    unsigned events = 0, ok = 0, messages = 0, fails[5] = {0, 0, 0, 0, 0};
+};
+
+thread_local r433_dispatch_info g_current;
+
+// Replays packages [p0, p1).  Returns decoded event count or a negative error code.
+int dispatch_range(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices, r433_package_fn pkg_cb, void *user,
+        uint32_t p0, uint32_t p1, std::vector<DevStats> &stats, std::string &err)
+{
+    r433_bitbuffer *bits = (r433_bitbuffer *)calloc(1, sizeof(r433_bitbuffer));
+    r433_pulse_data *pd = pkg_cb ? (r433_pulse_data *)calloc(1, sizeof(r433_pulse_data)) : nullptr;
+    uint8_t const *ev = b->h_events.p;
+    uint8_t const *pk = b->h_pkg_blob.p;
+    std::vector<uint32_t> first(n_devices, 0), count(n_devices, 0), touched, refs;
+    int decoded = 0;
+    int rc = 0;
+
+    for (uint32_t pkg = p0; pkg < p1 && rc == 0; ++pkg) {
+        r433_pkg_rec ph;
+        memcpy(&ph, pk + b->h_rec_off.p[pkg], sizeof(ph));
+        if (pkg_cb) {
+            memset(pd, 0, sizeof(*pd));
+            pd->offset = ph.offset;
+            pd->sample_rate = ph.sample_rate;
+            pd->start_ago = ph.start_ago;
+            pd->end_ago = ph.end_ago;
+            pd->num_pulses = ph.num_pulses;
+            int32_t const *pairs = (int32_t const *)(pk + b->h_rec_off.p[pkg] + sizeof(ph));
+            for (uint32_t i = 0; i < ph.num_pulses && i < R433_MAX_PULSES; ++i) {
+                pd->pulse[i] = pairs[2 * i];
+                pd->gap[i] = pairs[2 * i + 1];
+            }
+            pd->ook_low_estimate = ph.ook_low;
+            pd->ook_high_estimate = ph.ook_high;
+            pd->fsk_f1_est = ph.fsk_f1;
+            pd->fsk_f2_est = ph.fsk_f2;
+            fill_levels(b->cfg, *pd);
+            pkg_cb(user, ph.stream, ph.type, pd);
+        }
+
+        // index this package's events by device (they arrive sorted by device, then ordinal)
+        refs.clear();
+        touched.clear();
+        size_t eat = b->h_pkg_off.p[pkg];
+        size_t const eend = b->h_pkg_off.p[pkg + 1];
+        while (eat + sizeof(r433_evt_rec) <= eend) {
+            r433_evt_rec eh;
+            memcpy(&eh, ev + eat, sizeof(eh));
+            if (eh.pkg != pkg || eh.dev >= n_devices || eh.total_bytes < sizeof(eh) || eat + eh.total_bytes > eend) {
+                err = "corrupt event stream";
+                rc = R433_EHIP;
+                break;
+            }
+            if (count[eh.dev] == 0) {
+                first[eh.dev] = (uint32_t)refs.size();
+                touched.push_back(eh.dev);
+            }
+            count[eh.dev]++;
+            refs.push_back((uint32_t)eat);
+            eat += eh.total_bytes;
+        }
+
+        int p_events = 0;
+        for (uint32_t level : b->prio_levels) { // src/r_api.c:442-451: next level only while nothing decoded
+            if (p_events || rc)
+                break;
+            for (uint32_t dev : touched) {
+                if (b->timing[dev].priority != level || rc)
+                    continue;
+                r433_r_device *rd = devices[dev];
+                for (uint32_t k = 0; k < count[dev]; ++k) {
+                    uint8_t const *rec = ev + refs[first[dev] + k];
+                    r433_evt_rec eh;
+                    memcpy(&eh, rec, sizeof(eh));
+                    // inflate into the reference bitbuffer layout
+                    bits->num_rows = eh.num_rows;
+                    bits->free_row = eh.free_row;
+                    uint8_t const *rp = rec + sizeof(eh);
+                    for (uint32_t r = 0; r < eh.num_rows && r < R433_BITBUF_ROWS; ++r) {
+                        r433_row_rec rr;
+                        memcpy(&rr, rp, sizeof(rr));
+                        bits->bits_per_row[r] = rr.bits;
+                        bits->syncs_before_row[r] = rr.syncs;
+                        size_t room = (size_t)(R433_BITBUF_ROWS - r) * R433_BITBUF_COLS;
+                        memcpy(bits->bb[r], rp + sizeof(rr), rr.nbytes < room ? rr.nbytes : room);
+                        rp += sizeof(rr) + ((rr.nbytes + 3u) & ~3u);
+                    }
+                    uint32_t used_rows = std::max<uint32_t>(eh.num_rows, eh.free_row);
+
+                    g_current.stream = ph.stream;
+                    g_current.package = pkg;
+                    g_current.device = dev;
+                    g_current.ordinal = eh.ordinal;
+                    g_current.package_type = ph.type;
+                    g_current.start_ago = ph.start_ago;
+                    int ret = 0;
+                    if (rd && rd->decode_fn)
+                        ret = rd->decode_fn(rd, bits);
+                    DevStats &ds = stats[dev]; // statistics, src/pulse_slicer.c:35-47
+                    ds.events += 1;
+                    if (ret > 0) {
+                        ds.ok += 1;
+                        ds.messages += (unsigned)ret;
+                    }
+                    else if (ret >= R433_DECODE_FAIL_SANITY) {
+                        ds.fails[-ret] += 1;
+                        ret = 0;
+                    }
+                    else {
+                        char buf[200];
+                        snprintf(buf, sizeof(buf), "decoder \"%s\" gave invalid return value %d",
+                                rd && rd->name ? rd->name : "?", ret);
+                        err = buf;
+                        rc = R433_EDECODER;
+                        break;
+                    }
+                    if (ret > 0)
+                        p_events += ret;
+                    // bitbuffer_clear: only what can be dirty (the decoder may have grown the buffer)
+                    used_rows = std::max<uint32_t>(used_rows, std::max<uint32_t>(bits->num_rows, bits->free_row));
+                    if (used_rows > R433_BITBUF_ROWS)
+                        used_rows = R433_BITBUF_ROWS;
+                    memset(bits->bb, 0, (size_t)used_rows * R433_BITBUF_COLS);
+                    memset(bits, 0, offsetof(r433_bitbuffer, bb));
+                }
+            }
+        }
+        decoded += p_events;
+        for (uint32_t dev : touched)
+            count[dev] = 0;
+    }
+    free(bits);
+    free(pd);
+    return rc ? rc : decoded;
+}
+
+} // namespace
+
+int r433_dispatch_current(r433_dispatch_info *info)
+{
+    if (!info)
+        return fail(R433_EINVAL, "null argument");
+    *info = g_current;
+    return 0;
+}
+
+int r433_batch_dispatch_mt(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices, r433_package_fn pkg_cb,
+        void *user, uint32_t n_threads)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    if (n_devices != b->timing.size())
+        return fail(R433_EINVAL, "dispatch needs the %zu devices the engine was created with", b->timing.size());
+    uint32_t const np = b->n_pkgs;
+    if (n_threads < 1)
+        n_threads = 1;
+    if (n_threads > np)
+        n_threads = np ? np : 1;
+    std::vector<std::vector<DevStats>> stats(n_threads, std::vector<DevStats>(n_devices));
+    std::vector<int> results(n_threads, 0);
+    std::vector<std::string> errs(n_threads);
+    if (n_threads == 1) {
+        results[0] = dispatch_range(b, devices, n_devices, pkg_cb, user, 0, np, stats[0], errs[0]);
+        digest_publish();
+    }
+    else {
+        // packages are handed out in small contiguous runs from a shared cursor: event counts per
+        // package vary by orders of magnitude, static ranges leave most workers idle at the end
+        uint32_t const grain = std::max<uint32_t>(1, std::min<uint32_t>(16, np / (n_threads * 8)));
+        std::atomic<uint32_t> cursor{0};
+        b->pool.run(n_threads, [&](unsigned w) {
+            for (;;) {
+                uint32_t p0 = cursor.fetch_add(grain, std::memory_order_relaxed);
+                if (p0 >= np || results[w] < 0)
+                    break;
+                int r = dispatch_range(b, devices, n_devices, pkg_cb, user, p0, std::min(np, p0 + grain), stats[w], errs[w]);
+                results[w] = r < 0 ? r : results[w] + r;
+            }
+            digest_publish();
+        });
+    }
+    int decoded = 0;
+    for (uint32_t i = 0; i < n_threads; ++i) {
+        if (results[i] < 0)
+            return fail(results[i], "%s", errs[i].c_str());
+        decoded += results[i];
+    }
+    for (uint32_t d = 0; d < n_devices; ++d) {
+        r433_r_device *rd = devices[d];
+        if (!rd)
+            continue;
+        for (uint32_t i = 0; i < n_threads; ++i) {
+            DevStats const &ds = stats[i][d];
+            rd->decode_events += ds.events;
+            rd->decode_ok += ds.ok;
+            rd->decode_messages += ds.messages;
+            for (int k = 0; k < 5; ++k)
+                rd->decode_fails[k] += ds.fails[k];
+        }
+    }
+    return decoded;
+}
+
+int r433_batch_dispatch(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices, r433_package_fn pkg_cb,
+        void *user)
+{
+    return r433_batch_dispatch_mt(b, devices, n_devices, pkg_cb, user, 1);
+}
+
+// A decode_fn with the reference plugin signature that folds every bitbuffer it is handed into an
+// order-independent checksum (see r433_hip.h).  decode_ctx must point to a r433_digest_ctx.
+int r433_plugin_digest_decode(r433_r_device *decoder, r433_bitbuffer *bits)
+{
+    r433_digest_ctx *ctx = (r433_digest_ctx *)decoder->decode_ctx;
+    if (!ctx)
+        return R433_DECODE_ABORT_EARLY;
+    uint64_t x = 1469598103934665603ull;
+    auto mix = [&x](void const *p, size_t n) {
+        uint8_t const *q = (uint8_t const *)p;
+        for (size_t i = 0; i < n; ++i)
+            x = (x ^ q[i]) * 1099511628211ull;
+    };
+    uint32_t pkg = g_current.package;
+    uint16_t dev = (uint16_t)g_current.device, ord = (uint16_t)g_current.ordinal;
+    mix(&pkg, 4);
+    mix(&dev, 2);
+    mix(&ord, 2);
+    mix(&bits->num_rows, 2);
+    mix(&bits->free_row, 2);
+    for (unsigned r = 0; r < bits->num_rows && r < R433_BITBUF_ROWS; ++r) {
+        mix(&bits->bits_per_row[r], 2);
+        mix(&bits->syncs_before_row[r], 2);
+        mix(bits->bb[r], ((unsigned)bits->bits_per_row[r] + 7) / 8);
+    }
+    if (g_digest.ctx != ctx) {
+        digest_publish();
+        g_digest.ctx = ctx;
+    }
+    g_digest.sum += x; // published by the dispatcher when this thread is done with the batch
+    g_digest.events += 1;
+    return R433_DECODE_ABORT_LENGTH;
+}
+
+} // extern "C"

@@ -1,0 +1,242 @@
+// host_common.hpp -- what the host-side translation units of librtl433hip.so share: error reporting, device /
+// pinned buffers, the dispatch thread pool and the batch object.  Not part of the public C ABI (include/r433_hip.h).
+#ifndef R433_HOST_COMMON_HPP_
+#define R433_HOST_COMMON_HPP_
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "r433_hip.h"
+#include "r433_internal.hpp"
+
+
+// thread-local message behind r433_last_error(); returns `code` so that `return fail(...)` reads well
+int fail(int code, char const *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define HIP_TRY(expr)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess)                                                                                          \
+            return fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? R433_ENODEV : R433_EHIP, "%s: %s",   \
+                    #expr, hipGetErrorString(e_));                                                                     \
+    } while (0)
+
+namespace r433 {
+
+// pulse_detect_set_levels and its dB macros on the host (host_api.cpp)
+void levels_from_db(DetCfg &c, int use_mag, float fixed_db, float min_db, float ratio_db);
+// calc_rssi_snr, reference src/r_flow.c:35-64 (dispatch.cpp)
+void fill_levels(r433_flow_cfg const &cfg, r433_pulse_data &p);
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0; // elements
+    int ensure(size_t n)
+    {
+        if (n <= cap)
+            return 0;
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 4 + 16;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e != hipSuccess)
+            return fail(R433_ENOMEM, "hipMalloc(%zu bytes): %s", want * sizeof(T), hipGetErrorString(e));
+        cap = want;
+        return 0;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+template <typename T> struct PinBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n)
+    {
+        if (n <= cap)
+            return 0;
+        if (p)
+            (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 4 + 16;
+        hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess)
+            return fail(R433_ENOMEM, "hipHostMalloc(%zu bytes): %s", want * sizeof(T), hipGetErrorString(e));
+        cap = want;
+        return 0;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+
+// Persistent host workers for the decoder dispatch (spawning 32 threads per batch costs more than
+// dispatching a small batch).
+class Pool {
+  public:
+    ~Pool() { stop(); }
+    void run(unsigned n, std::function<void(unsigned)> const &job)
+    {
+        if (n <= 1) {
+            job(0);
+            return;
+        }
+        grow(n - 1);
+        {
+            std::lock_guard<std::mutex> g(m_);
+            job_ = &job;
+            want_ = n - 1;
+            pending_ = n - 1;
+            ++epoch_;
+        }
+        cv_.notify_all();
+        job(0);
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [&] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+  private:
+    void grow(unsigned n)
+    {
+        while (threads_.size() < n) {
+            unsigned id = (unsigned)threads_.size();
+            threads_.emplace_back([this, id] { loop(id); });
+        }
+    }
+    void loop(unsigned id)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            std::function<void(unsigned)> const *job = nullptr;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return quit_ || (epoch_ != seen && id < want_); });
+                if (quit_)
+                    return;
+                seen = epoch_;
+                job = job_;
+            }
+            (*job)(id + 1);
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (--pending_ == 0)
+                    done_.notify_all();
+            }
+        }
+    }
+    void stop()
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : threads_)
+            t.join();
+        threads_.clear();
+    }
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> threads_;
+    std::function<void(unsigned)> const *job_ = nullptr;
+    unsigned want_ = 0, pending_ = 0;
+    uint64_t epoch_ = 0;
+    bool quit_ = false;
+};
+
+} // namespace r433
+
+using namespace r433; // internal header of four host translation units; the batch type itself is the C ABI's (global)
+
+struct r433_batch {
+    r433_flow_cfg cfg;
+    DetCfg det;
+    int a16 = 0, b16 = 0;
+    long long a32 = 0, b32 = 0;
+    std::vector<r433_dev_timing> timing; // registration order
+    std::vector<DevRow> rows;            // sorted for the fan-out
+    std::vector<uint32_t> prio_levels;   // distinct priorities ascending
+
+    DevBuf<DevRow> d_rows;
+    DevBuf<uint8_t> d_arena;
+    DevBuf<int2> d_ring;
+    DevBuf<StreamState> d_state;
+    DevBuf<uint32_t> d_frame_sums, d_stream_bytes, d_pkg_base, d_scal;
+    DevBuf<int> d_frame_min_high;
+    std::vector<int> h_frame_min_high;
+    // split captures (r433_batch_set_split)
+    uint32_t split_samples = R433_SPLIT_AUTO;
+    DevBuf<uint32_t> d_tile_max, d_order;
+    DevBuf<SegDesc> d_segs;
+    PinBuf<uint32_t> h_tile_max;
+    PinBuf<StreamState> h_state;
+    uint32_t last_segments = 0, last_redone = 0;
+    DevBuf<uint32_t> d_dir_stream, d_dir_off, d_rec_bytes, d_rec_off, d_sizes, d_pkg_bytes, d_pkg_off;
+    DevBuf<uint8_t> d_pkg_blob, d_events, d_stage, d_converted;
+    DevBuf<r433_analysis> d_analysis;
+    std::vector<uint32_t> conv_bytes;
+    PinBuf<uint32_t> h_scal, h_frame_sums;
+    PinBuf<uint8_t> h_pkg_blob, h_events, h_arena_stage;
+    PinBuf<uint32_t> h_pkg_off, h_rec_off; // per package: byte offset of its first event / of its record
+
+    uint32_t arena_stride = 0;
+    uint32_t frames_cap = 0;
+    uint32_t n_streams = 0;
+    uint32_t n_pkgs = 0, n_events = 0;
+    size_t pkg_bytes = 0, evt_bytes = 0;
+    bool events_counted = false;
+
+    void *tap_env = nullptr, *tap_am = nullptr, *tap_fm = nullptr;
+    uint64_t tap_stride = 0;
+
+    hipEvent_t sync_ev = nullptr; // blocking (sleeping) wait: host threads of other pipeline stages need the cores
+    bool profiling = false;
+    hipEvent_t ev[8] = {};
+    bool ev_made = false;
+    r433_batch_timing last_timing = {};
+
+    // dispatch scratch
+    r433_bitbuffer *bits = nullptr;
+    r433_pulse_data *pulses = nullptr;
+    Pool pool;
+};
+
+inline hipError_t stream_wait(r433_batch *b, hipStream_t st)
+{
+    if (!b->sync_ev) {
+        hipError_t e = hipEventCreateWithFlags(&b->sync_ev, hipEventBlockingSync | hipEventDisableTiming);
+        if (e != hipSuccess)
+            return e;
+    }
+    hipError_t e = hipEventRecord(b->sync_ev, st);
+    return e != hipSuccess ? e : hipEventSynchronize(b->sync_ev);
+}
+
+#endif // R433_HOST_COMMON_HPP_

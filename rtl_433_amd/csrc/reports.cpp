@@ -1,0 +1,319 @@
+// reports.cpp -- host-side text and report formats around the path: the pulse analyzer's report (`-A`) over the
+// device-computed analysis, and the `.ook` pulse-data reader / writer.
+#include "host_common.hpp"
+
+using namespace r433;
+
+extern "C" {
+
+int r433_batch_analyze(r433_batch *b, r433_analysis *out, uint32_t max_packages, void *stream)
+{
+    if (!b || (!out && max_packages))
+        return fail(R433_EINVAL, "null argument");
+    uint32_t const n = std::min(b->n_pkgs, max_packages);
+    if (n == 0)
+        return 0;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = b->d_analysis.ensure(n)))
+        return rc;
+    // the arena and the package directory of the last run are still on the device
+    launch_analyze(b->d_arena.p, b->arena_stride, b->d_dir_stream.p, b->d_dir_off.p, n, b->d_analysis.p, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, b->d_analysis.p, (size_t)n * sizeof(r433_analysis), hipMemcpyDeviceToHost, st));
+    HIP_TRY(stream_wait(b, st));
+    return (int)n;
+}
+
+namespace {
+
+// histogram_find_bin_index, reference src/pulse_analyzer.c:157-165
+int find_bin(r433_histogram const &h, int width)
+{
+    for (uint32_t n = 0; n < h.bins_count && n < R433_HIST_BINS; ++n)
+        if (h.bins[n].min <= width && width <= h.bins[n].max)
+            return (int)n;
+    return -1;
+}
+
+// hexstr_t, reference src/pulse_analyzer.c:180-209
+struct HexStr {
+    uint8_t p[1024];
+    unsigned idx = 0;
+    void byte(uint8_t v)
+    {
+        if (idx < sizeof(p))
+            p[idx++] = v;
+    }
+    void word(uint16_t v)
+    {
+        if (idx + 1 < sizeof(p)) {
+            p[idx++] = (uint8_t)(v >> 8);
+            p[idx++] = (uint8_t)(v & 0xff);
+        }
+    }
+};
+
+} // namespace
+
+int r433_analysis_text(r433_batch *b, uint32_t pkg, r433_analysis const *a, char *buf, size_t cap)
+{
+    if (!b || !a || (!buf && cap))
+        return fail(R433_EINVAL, "null argument");
+    if (pkg >= b->n_pkgs)
+        return fail(R433_EINVAL, "package %u of %u", pkg, b->n_pkgs);
+    size_t len = 0;
+#define PUT(...)                                                                                                     \
+    do {                                                                                                             \
+        int const n_ = snprintf(len < cap ? buf + len : nullptr, len < cap ? cap - len : 0, __VA_ARGS__);           \
+        if (n_ > 0)                                                                                                  \
+            len += (size_t)n_;                                                                                       \
+    } while (0)
+    if (a->num_pulses == 0) { // src/pulse_analyzer.c:281-284
+        PUT("No pulses detected.\n");
+        return (int)len;
+    }
+    uint8_t const *rec = b->h_pkg_blob.p + b->h_rec_off.p[pkg];
+    r433_pkg_rec ph;
+    memcpy(&ph, rec, sizeof(ph));
+    int32_t const *pairs = (int32_t const *)(rec + sizeof(ph));
+    uint32_t const num = std::min<uint32_t>(ph.num_pulses, R433_MAX_PULSES);
+    uint32_t const rate = ph.sample_rate;
+    double const to_ms = 1e3 / rate, to_us = 1e6 / rate;
+    r433_pulse_data lv; // only the level fields are used
+    lv.ook_low_estimate = ph.ook_low;
+    lv.ook_high_estimate = ph.ook_high;
+    lv.fsk_f1_est = ph.fsk_f1;
+    lv.fsk_f2_est = ph.fsk_f2;
+    fill_levels(b->cfg, lv);
+
+    auto print_hist = [&](char const *title, r433_histogram const &h) { // histogram_print, :168-178
+        PUT("%s\n", title);
+        for (uint32_t n = 0; n < h.bins_count && n < R433_HIST_BINS; ++n)
+            PUT(" [%2u] count: %4u,  width: %4.0f us [%.0f;%.0f]\t(%4i S)\n", n, h.bins[n].count, h.bins[n].mean * 1e6 / rate,
+                    h.bins[n].min * 1e6 / rate, h.bins[n].max * 1e6 / rate, h.bins[n].mean);
+    };
+    PUT("Analyzing pulses...\n"); // :326-346
+    PUT("Total count: %4u,  width: %4.2f ms\t\t(%5i S)\n", a->num_pulses, a->total_period * to_ms, a->total_period);
+    print_hist("Pulse width distribution:", a->pulses);
+    print_hist("Gap width distribution:", a->gaps);
+    print_hist("Pulse+gap period distribution:", a->periods_pg);
+    print_hist("Gap+pulse period distribution:", a->periods_gp);
+    print_hist("Timing distribution:", a->timings);
+    PUT("Level estimates [high, low]: %6i, %6i\n", ph.ook_high, ph.ook_low);
+    PUT("RSSI: %.1f dB SNR: %.1f dB Noise: %.1f dB\n", (double)lv.rssi_db, (double)lv.snr_db, (double)lv.noise_db);
+    PUT("Frequency offsets [F1, F2]:  %6i, %6i\t(%+.1f kHz, %+.1f kHz)\n", ph.fsk_f1, ph.fsk_f2,
+            ((float)ph.fsk_f1 / INT16_MAX) * (rate / 2.0 / 1000.0), ((float)ph.fsk_f2 / INT16_MAX) * (rate / 2.0 / 1000.0));
+    static char const *const kGuess[] = {"", "Single pulse detected. Probably Frequency Shift Keying or just noise...",
+            "Un-modulated signal. Maybe a preamble...", "Pulse Position Modulation with fixed pulse width",
+            "Pulse Width Modulation with fixed gap", "Pulse Width Modulation with fixed period", "Manchester coding",
+            "Pulse Width Modulation with multiple packets", "Non Return to Zero coding (Pulse Code)",
+            "Pulse Width Modulation with sync/delimiter", "No clue..."};
+    PUT("Guessing modulation: %s\n", kGuess[a->guess <= R433_GUESS_NO_CLUE ? a->guess : 0]);
+
+    // RfRaw line, :432-513 (the guess sorted only copies of the pulse / gap histograms; their bin counts did not change,
+    // except that an FSK zero-bin left the pulse histogram, which this part does not look at)
+    r433_histogram const &T = a->timings;
+    if (T.bins_count <= 8) {
+        // gap bins by ascending mean, as the reference has sorted them by now
+        r433_hist_bin gs[R433_HIST_BINS];
+        uint32_t const ng = std::min<uint32_t>(a->gaps.bins_count, R433_HIST_BINS);
+        for (uint32_t k = 0; k < ng; ++k)
+            gs[k] = a->gaps.bins[k];
+        for (uint32_t n = 0; n + 1 < ng; ++n)
+            for (uint32_t m = n + 1; m < ng; ++m)
+                if (gs[m].mean < gs[n].mean)
+                    std::swap(gs[m], gs[n]);
+        auto push_bins = [&](HexStr &h) {
+            for (uint32_t k = 0; k < T.bins_count; ++k) {
+                double const w = std::max(0.0, T.bins[k].mean * to_us);
+                h.word((uint16_t)(w < 65535 ? w : 65535));
+            }
+        };
+        if (ng <= 2) {
+            HexStr h;
+            h.byte(0xaa);
+            h.byte(0xb1);
+            h.byte((uint8_t)T.bins_count);
+            push_bins(h);
+            for (uint32_t i = 0; i < num; ++i)
+                h.byte((uint8_t)(0x80 | (find_bin(T, pairs[2 * i]) << 4) | find_bin(T, pairs[2 * i + 1])));
+            h.byte(0x55);
+            PUT("view at https://triq.org/pdv/#");
+            for (unsigned k = 0; k < h.idx; ++k)
+                PUT("%02X", h.p[k]);
+            PUT("\n");
+        }
+        else {
+            int const limit = gs[std::min<uint32_t>(3, ng - 1)].min;
+            std::vector<HexStr> strs(32);
+            unsigned cnt = 0;
+            uint32_t i = 0;
+            while (i < num && cnt < 32) {
+                HexStr &h = strs[cnt];
+                h.idx = 0;
+                h.byte(0xaa);
+                h.byte(0xb0);
+                h.byte(0);
+                h.byte((uint8_t)T.bins_count);
+                h.byte(1);
+                push_bins(h);
+                for (; i < num; ++i) {
+                    h.byte((uint8_t)(0x80 | (find_bin(T, pairs[2 * i]) << 4) | find_bin(T, pairs[2 * i + 1])));
+                    if (pairs[2 * i + 1] >= limit) {
+                        ++i;
+                        break;
+                    }
+                }
+                h.byte(0x55);
+                h.p[2] = (uint8_t)(h.idx - 4 <= 255 ? h.idx - 4 : 0);
+                if (cnt > 0 && strs[cnt - 1].idx == h.idx && !memcmp(&strs[cnt - 1].p[5], &h.p[5], h.idx - 5)) {
+                    h.idx = 0;
+                    strs[cnt - 1].p[4] += 1;
+                }
+                else {
+                    cnt++;
+                }
+            }
+            PUT("view at https://triq.org/pdv/#");
+            for (unsigned j = 0; j < cnt; ++j) {
+                if (j > 0)
+                    PUT("+");
+                for (unsigned k = 0; k < strs[j].idx; ++k)
+                    PUT("%02X", strs[j].p[k]);
+            }
+            PUT("\n");
+            if (cnt >= 32)
+                PUT("Too many pulse groups (%u pulses missed in rfraw)\n", num - i);
+        }
+    }
+    r433_dev_timing const &d = a->device;
+    if (d.modulation) { // :516-556
+        PUT("Attempting demodulation... short_width: %.0f, long_width: %.0f, reset_limit: %.0f, sync_width: %.0f\n", (double)d.short_width,
+                (double)d.long_width, (double)d.reset_limit, (double)d.sync_width);
+        switch (d.modulation) {
+        case 16: // FSK_PULSE_PCM
+            PUT("Use a flex decoder with -X 'n=name,m=FSK_PCM,s=%.0f,l=%.0f,r=%.0f'\n", (double)d.short_width, (double)d.long_width,
+                    (double)d.reset_limit);
+            break;
+        case 5: // OOK_PULSE_PPM
+            PUT("Use a flex decoder with -X 'n=name,m=OOK_PPM,s=%.0f,l=%.0f,g=%.0f,r=%.0f'\n", (double)d.short_width, (double)d.long_width,
+                    (double)d.gap_limit, (double)d.reset_limit);
+            break;
+        case 6:  // OOK_PULSE_PWM
+        case 17: // FSK_PULSE_PWM
+            PUT("Use a flex decoder with -X 'n=name,m=%s,s=%.0f,l=%.0f,r=%.0f,g=%.0f,t=%.0f,y=%.0f'\n", d.modulation == 6 ? "OOK_PWM" : "FSK_PWM",
+                    (double)d.short_width, (double)d.long_width, (double)d.reset_limit, (double)d.gap_limit, (double)d.tolerance,
+                    (double)d.sync_width);
+            break;
+        case 3: // OOK_PULSE_MANCHESTER_ZEROBIT
+            PUT("Use a flex decoder with -X 'n=name,m=OOK_MC_ZEROBIT,s=%.0f,l=%.0f,r=%.0f'\n", (double)d.short_width, (double)d.long_width,
+                    (double)d.reset_limit);
+            break;
+        default:
+            PUT("Unsupported\n");
+        }
+    }
+#undef PUT
+    return (int)len;
+}
+
+// pulse_data_load, reference src/pulse_data.c:122-176, over a text in memory: one call of the reference reads one
+// package; the file loop calls it until a package comes back empty (src/rtl_433.c:1757-1761).
+int r433_pulse_text_load(char const *text, size_t len, uint32_t sample_rate, r433_pulse_data *out, uint32_t max_packages)
+{
+    if ((!text && len) || (!out && max_packages))
+        return fail(R433_EINVAL, "null argument");
+    size_t at = 0;
+    uint32_t n_out = 0;
+    double const to_sample = sample_rate / 1e6;
+    // fgets(s, 1024, file): at most 1023 characters, up to and including the newline
+    auto next_line = [&](char *s) -> bool {
+        if (at >= len)
+            return false;
+        size_t k = 0;
+        while (k < 1023 && at < len) {
+            char const c = text[at++];
+            s[k++] = c;
+            if (c == '\n')
+                break;
+        }
+        s[k] = '\0';
+        return true;
+    };
+    for (;;) {
+        r433_pulse_data *data = n_out < max_packages ? &out[n_out] : nullptr;
+        if (!data)
+            break;
+        memset(data, 0, sizeof(*data)); // pulse_data_clear
+        data->sample_rate = sample_rate;
+        char s[1024];
+        int i = 0;
+        while (i < R433_MAX_PULSES && next_line(s)) {
+            if (!strncmp(s, ";freq1", 6))
+                data->freq1_hz = (float)strtol(s + 6, nullptr, 10);
+            if (!strncmp(s, ";freq2", 6))
+                data->freq2_hz = (float)strtol(s + 6, nullptr, 10);
+            if (*s == ';') {
+                if (i)
+                    break; // end or next header found
+                continue;  // still reading a header
+            }
+            char const *p = s;
+            char *endptr;
+            long const mark = strtol(p, &endptr, 10);
+            p = endptr + 1;
+            long const space = strtol(p, &endptr, 10);
+            if (mark < 0 || space < 0)
+                continue; // the reference warns and skips the line
+            data->pulse[i] = (int)(to_sample * mark);
+            data->gap[i++] = (int)(to_sample * space);
+        }
+        data->num_pulses = (unsigned)i;
+        if (i == 0)
+            break; // the file loop stops at the first empty package
+        n_out += 1;
+    }
+    return (int)n_out;
+}
+
+// pulse_data_dump, reference src/pulse_data.c:193-224.  Returns the length of the text (like snprintf: the text
+// is cut if it does not fit cap, the full length is returned either way).
+int r433_pulse_text_dump(r433_pulse_data const *data, char const *received, char *buf, size_t cap)
+{
+    if (!data || (!buf && cap))
+        return fail(R433_EINVAL, "null argument");
+    size_t len = 0;
+#define PUT(...)                                                                                                     \
+    do {                                                                                                             \
+        int const n_ = snprintf(len < cap ? buf + len : nullptr, len < cap ? cap - len : 0, __VA_ARGS__);           \
+        if (n_ > 0)                                                                                                  \
+            len += (size_t)n_;                                                                                       \
+    } while (0)
+    if (received)
+        PUT(";received %s\n", received);
+    if (data->fsk_f2_est) {
+        PUT(";fsk %u pulses\n", data->num_pulses);
+        PUT(";freq1 %.0f\n", (double)data->freq1_hz);
+        PUT(";freq2 %.0f\n", (double)data->freq2_hz);
+    }
+    else {
+        PUT(";ook %u pulses\n", data->num_pulses);
+        PUT(";freq1 %.0f\n", (double)data->freq1_hz);
+    }
+    PUT(";centerfreq %.0f Hz\n", (double)data->centerfreq_hz);
+    PUT(";samplerate %u Hz\n", data->sample_rate);
+    PUT(";sampledepth %u bits\n", data->depth_bits);
+    PUT(";range %.1f dB\n", (double)data->range_db);
+    PUT(";rssi %.1f dB\n", (double)data->rssi_db);
+    PUT(";snr %.1f dB\n", (double)data->snr_db);
+    PUT(";noise %.1f dB\n", (double)data->noise_db);
+    double const to_us = 1e6 / data->sample_rate;
+    for (unsigned i = 0; i < data->num_pulses && i < R433_MAX_PULSES; ++i)
+        PUT("%.0f %.0f\n", data->pulse[i] * to_us, data->gap[i] * to_us);
+    PUT(";end\n");
+#undef PUT
+    return (int)len;
+}
+
+} // extern "C"
