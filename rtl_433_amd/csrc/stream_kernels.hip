@@ -700,6 +700,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
         int a64_l = 0, f64_l = 0;  // am / 64, fm / 64 (C division) for the level and carrier averages
         int in_pk_l = 0;           // the two of them packed as 16-bit halves
         int in_pkn_l = 0;          // the same with the carrier half negated (|f1| form of the average)
+        int ff_pk_l = 0;           // fm / 64 in both halves (the package's and the FSK detector's carrier averages)
         int bmax = 0, bmin = 0;
         // chunk statistics (lane = chunk) and their suffix extrema, for jumping over whole chunks
         int const my_cmax = s_cmax[lane], my_cmin = s_cmin[lane];
@@ -731,30 +732,40 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                 int a = min(det.low, lz_min) - 1, b = max(det.low, lz_max) + 1;
                 a += (a ^ par) & 1; // lowest / highest candidate of that parity
                 b -= (b ^ par) & 1;
-                int const v0 = ld16(s_am, w0 + lane), v1 = ld16(s_am, w0 + 64 + lane); // w0 + 127 < upto <= n_t
+                if (uni(b - a) <= 256) { // the two close in by at most 2 per sample: further apart they cannot meet in 128
+                    int const v0 = ld16(s_am, w0 + lane), v1 = ld16(s_am, w0 + 64 + lane); // w0 + 127 < upto <= n_t
 #pragma unroll 8
-                for (int u = 0; u < 64; ++u) {
-                    int const x = __builtin_amdgcn_readlane(v0, u);
-                    a += x > a ? 1 : -1;
-                    b += x > b ? 1 : -1;
-                }
+                    for (int u = 0; u < 64; ++u) {
+                        int const x = __builtin_amdgcn_readlane(v0, u);
+                        a += x > a ? 1 : -1;
+                        b += x > b ? 1 : -1;
+                    }
 #pragma unroll 8
-                for (int u = 0; u < 64; ++u) {
-                    int const x = __builtin_amdgcn_readlane(v1, u);
-                    a += x > a ? 1 : -1;
-                    b += x > b ? 1 : -1;
-                }
-                if (a == b) {
-                    lo_est = a;
-                    done = true;
+                    for (int u = 0; u < 64; ++u) {
+                        int const x = __builtin_amdgcn_readlane(v1, u);
+                        a += x > a ? 1 : -1;
+                        b += x > b ? 1 : -1;
+                    }
+                    if (a == b) {
+                        lo_est = a;
+                        done = true;
+                    }
                 }
             }
             if (!done) {
-                for (int j0 = lz_from; j0 < upto; j0 += 64) {
+                lo_est = uni(lo_est);
+                for (int j0 = uni(lz_from); j0 < upto; j0 += 64) {
                     int const v = j0 + lane < upto ? ld16(s_am, j0 + lane) : 0;
-                    int const cntj = min(64, upto - j0);
-                    for (int u = 0; u < cntj; ++u)
-                        lo_est += __builtin_amdgcn_readlane(v, u) > lo_est ? 1 : -1;
+                    int const cntj = uni(min(64, upto - j0));
+                    if (cntj == 64) { // whole blocks: constant lane numbers, no loop control (a noisy floor walks every sample)
+#pragma unroll
+                        for (int u = 0; u < 64; ++u)
+                            lo_est += __builtin_amdgcn_readlane(v, u) > lo_est ? 1 : -1;
+                    }
+                    else {
+                        for (int u = 0; u < cntj; ++u)
+                            lo_est += __builtin_amdgcn_readlane(v, u) > lo_est ? 1 : -1;
+                    }
                 }
             }
             det.low = lo_est;
@@ -854,6 +865,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                 f64_l = div64(fm_l);
                 in_pk_l = (a64_l & 0xffff) | (f64_l << 16);
                 in_pkn_l = (a64_l & 0xffff) | (-f64_l << 16);
+                ff_pk_l = (f64_l & 0xffff) | (f64_l << 16);
                 bmax = uni(max(s_cmax[base >> 5], s_cmax[(base >> 5) + 1]));
                 bmin = uni(min(s_cmin[base >> 5], s_cmin[(base >> 5) + 1]));
                 loaded = base;
@@ -1017,6 +1029,74 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                             }
                             h = hv[0];
                             f1 = hv[1];
+                        }
+                        else if (feed && cfg.fpdm != 0) {
+                            // First pulse of a package with the min/max FSK detector listening (pulse_detect_fsk.c:145-221):
+                            // between two of its events (a frequency toggle, or a sample exactly at the mid level) the
+                            // detector only lets its upper bound sink by 10 per sample towards the signal (or its lower
+                            // bound rise) -- vmax'_r = max(vmax_0 - 10 r, max_{t<=r}(v_t - 10 (r - t))), a running maximum,
+                            // so every lane can tell at once whether the detector would still be in the same state at its
+                            // sample.  The stretch up to the first lane that says no is taken in one go (bounds in closed
+                            // form, the three averages in a short loop); the event sample itself goes through the exact step.
+                            j = uni(j);
+                            int const kk = uni(k);
+                            while (j < kk) {
+                                int const fstate = uni(det.f_state);
+                                int const M0 = uni(det.f_vmax), m0 = uni(det.f_vmin);
+                                int run = 0;
+                                if (uni(det.f_skip) == 0 && fstate != 0 && abs(M0) <= 32000 && abs(m0) <= 32000 && h >= 0 && cfg.min_high >= 0) {
+                                    int const r = lane - (j - base); // my place in the stretch
+                                    bool const mine = r >= 0 && base + lane < kk;
+                                    int const v = fm_l;
+                                    int key = !mine ? INT32_MIN : fstate == 1 ? v + 10 * r : -(v - 10 * r);
+#pragma unroll
+                                    for (int o = 1; o < 64; o <<= 1) { // inclusive running maximum over the lanes
+                                        int const t = __shfl_up(key, (unsigned)o, 64);
+                                        if (lane >= o)
+                                            key = max(key, t);
+                                    }
+                                    int const Mr = fstate == 1 ? max(M0, key) - 10 * r : max(v, M0); // bounds as the sample sees them
+                                    int const mr = fstate == 1 ? min(v, m0) : min(m0, -key) + 10 * r;
+                                    int const mid = (int)(int16_t)((Mr + mr) / 2);
+                                    bool const stay = (fstate == 1 ? v > mid : v < mid) && abs(v) <= 32000;
+                                    unsigned long long const bad = __ballot(mine && !stay);
+                                    int const stop = bad ? base + (__ffsll(bad) - 1) : kk;
+                                    run = uni(stop - j);
+                                    if (run > 0) {
+                                        int const last = j - base + run - 1;
+                                        if (fstate == 1)
+                                            det.f_vmax = __builtin_amdgcn_readlane(Mr, last) - 10;
+                                        else
+                                            det.f_vmin = __builtin_amdgcn_readlane(mr, last) + 10;
+                                        det.f_run += (uint32_t)run;
+                                        // the level average alone, the two carrier averages (package and FSK detector:
+                                        // same input, (sic) f2 while high, f1 while low) as a packed pair
+                                        int fx = fstate == 1 ? det.f_f2 : det.f_f1;
+                                        v2s fv = {(short)f1, (short)fx};
+                                        v2s const m63 = {63, 63};
+                                        for (int u = 0; u < run; ++u) {
+                                            h = max(h - (h >> 6) + __builtin_amdgcn_readlane(a64_l, j - base + u), cfg.min_high);
+                                            v2s const in = as_v2s(__builtin_amdgcn_readlane(ff_pk_l, j - base + u));
+                                            v2s const q = (fv + ((fv >> 15) & m63)) >> 6; // v / 64, truncating toward zero
+                                            fv = fv - q + in;
+                                        }
+                                        f1 = fv[0];
+                                        fx = fv[1];
+                                        if (fstate == 1)
+                                            det.f_f2 = fx;
+                                        else
+                                            det.f_f1 = fx;
+                                        j += run;
+                                    }
+                                }
+                                if (run == 0) { // the detector's skip samples, its first decision, an event, values at the edge of int16
+                                    h += __builtin_amdgcn_readlane(a64_l, j - base) - div64(h);
+                                    h = max(h, cfg.min_high);
+                                    f1 += __builtin_amdgcn_readlane(f64_l, j - base) - div64(f1);
+                                    fsk_feed(det, cfg, __builtin_amdgcn_readlane(fm_l, j - base));
+                                    j += 1;
+                                }
+                            }
                         }
                         else {
                             for (; j < k; ++j) {
