@@ -13,6 +13,7 @@ ap.add_argument("--samples", type=int, default=65536)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--nodevs", action="store_true")
 ap.add_argument("--split", type=int, default=0)
+ap.add_argument("--fsk-cu8", action="store_true", help="250 kS/s cu8 FSK bursts at 433.92 MHz: the classic FSK detector")
 ap.add_argument("--analyze", action="store_true", help="also time the pulse analyzer (-A) over the packages of the run")
 ap.add_argument("--cs16", action="store_true", help="config 3 style: 1024 kS/s cs16 FSK Manchester bursts, minmax detector")
 a = ap.parse_args()
@@ -20,6 +21,10 @@ if a.cs16:
     host = np.stack([synth.fsk_stream_cs16(s, a.samples) for s in range(min(a.streams, 64))])
     host = np.tile(host, ((a.streams + len(host) - 1) // len(host), 1))[: a.streams]
     cfg = flow_cfg(4, 1024000, fpdm=1, center_frequency=868000000)
+elif a.fsk_cu8:
+    host = np.stack([synth.fsk_stream_cu8(s, a.samples, n_bursts=4) for s in range(min(a.streams, 64))])
+    host = np.tile(host, ((a.streams + len(host) - 1) // len(host), 1))[: a.streams]
+    cfg = flow_cfg(2, 250000, fpdm=0)
 else:
     host = synth.ook_batch(a.streams, a.samples, 250000, seed0=0)
     cfg = flow_cfg(2, 250000)
