@@ -162,6 +162,18 @@ __device__ __forceinline__ v2s pk_min(v2s a, v2s b)
     return (a & m) | (b & ~m);
 }
 
+// inclusive running maximum over the lanes of the wavefront
+__device__ __forceinline__ int wave_run_max(int key, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int const t = __shfl_up(key, (unsigned)o, 64);
+        if (lane >= o)
+            key = max(key, t);
+    }
+    return key;
+}
+
 // C division by 64 / 1024 (truncating toward zero) without a divider
 __device__ __forceinline__ int div64(int v)
 {
@@ -1048,13 +1060,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                                     int const r = lane - (j - base); // my place in the stretch
                                     bool const mine = r >= 0 && base + lane < kk;
                                     int const v = fm_l;
-                                    int key = !mine ? INT32_MIN : fstate == 1 ? v + 10 * r : -(v - 10 * r);
-#pragma unroll
-                                    for (int o = 1; o < 64; o <<= 1) { // inclusive running maximum over the lanes
-                                        int const t = __shfl_up(key, (unsigned)o, 64);
-                                        if (lane >= o)
-                                            key = max(key, t);
-                                    }
+                                    int const key = wave_run_max(!mine ? INT32_MIN : fstate == 1 ? v + 10 * r : -(v - 10 * r), lane);
                                     int const Mr = fstate == 1 ? max(M0, key) - 10 * r : max(v, M0); // bounds as the sample sees them
                                     int const mr = fstate == 1 ? min(v, m0) : min(m0, -key) + 10 * r;
                                     int const mid = (int)(int16_t)((Mr + mr) / 2);
@@ -1098,13 +1104,77 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                                 }
                             }
                         }
+                        else if (feed) {
+                            // ... and with the classic FSK detector listening (pulse_detect_fsk.c:34-141): while it sits on
+                            // one of its two frequency estimates, that estimate follows the signal (v/16 or v/64 steps,
+                            // never leaving the hull of where it started and what it has seen since -- truncating division
+                            // is monotone), and the detector toggles when the sample is closer to the other estimate.  Against
+                            // the running hull of the samples before it every lane knows whether a toggle is possible at its
+                            // sample; up to the first lane that cannot rule it out only the averages advance.
+                            constexpr int kNone = -0x40000000;
+                            j = uni(j);
+                            int const kk = uni(k);
+                            while (j < kk) {
+                                int const fstate = uni(det.f_state);
+                                int run = 0;
+                                if (fstate != 0 && h >= 0 && cfg.min_high >= 0) {
+                                    int const F0 = uni(fstate == 1 ? det.f_f1 : det.f_f2); // the estimate the detector sits on
+                                    int const other = uni(fstate == 1 ? det.f_f2 : det.f_f1);
+                                    int const r = lane - (j - base);
+                                    bool const mine = r >= 0 && base + lane < kk;
+                                    int const v = fm_l;
+                                    int up = __shfl_up(wave_run_max(mine ? v : kNone, lane), 1u, 64);   // max of the samples before mine
+                                    int dn = __shfl_up(wave_run_max(mine ? -v : kNone, lane), 1u, 64);  // -min
+                                    if (r <= 0 || lane == 0)
+                                        up = dn = kNone;
+                                    int const U = max(F0, up), L = min(F0, -max(dn, -0x3fffffff));
+                                    bool const possible = max(abs(v - L), abs(v - U)) > abs(v - other);
+                                    unsigned long long const bad = __ballot(mine && possible);
+                                    run = uni((bad ? base + (__ffsll(bad) - 1) : kk) - j);
+                                    if (run > 0) {
+                                        det.f_run += (uint32_t)run;
+                                        int F = F0;
+                                        int const idx0 = uni(j - base);
+                                        // one copy of the loop per state, no branch inside: a taken branch costs a lone
+                                        // wavefront more than the few instructions it would skip
+                                        auto advance = [&](auto up_tag) {
+                                            constexpr bool UP = decltype(up_tag)::value;
+                                            for (int u = 0; u < run; ++u) {
+                                                int const x = __builtin_amdgcn_readlane(fm_l, idx0 + u);
+                                                int const x64 = __builtin_amdgcn_readlane(f64_l, idx0 + u);
+                                                int const x16 = (x + ((x >> 31) & 15)) >> 4; // x / 16, C division
+                                                h = max(h - (h >> 6) + __builtin_amdgcn_readlane(a64_l, idx0 + u), cfg.min_high);
+                                                f1 += x64 - div64(f1);
+                                                bool const fast = UP ? x > F : x < F; // towards the outside: 1/16 steps
+                                                int const sh = fast ? 4 : 6, bias = fast ? 15 : 63;
+                                                F += (fast ? x16 : x64) - ((F + ((F >> 31) & bias)) >> sh); // v/16 - F/16 or v/64 - F/64, C division
+                                            }
+                                        };
+                                        if (fstate == 1)
+                                            advance(std::true_type{});
+                                        else
+                                            advance(std::false_type{});
+                                        if (fstate == 1)
+                                            det.f_f1 = F;
+                                        else
+                                            det.f_f2 = F;
+                                        j += run;
+                                    }
+                                }
+                                if (run == 0) { // start-up of the detector, a possible toggle
+                                    h += __builtin_amdgcn_readlane(a64_l, j - base) - div64(h);
+                                    h = max(h, cfg.min_high);
+                                    f1 += __builtin_amdgcn_readlane(f64_l, j - base) - div64(f1);
+                                    fsk_feed(det, cfg, __builtin_amdgcn_readlane(fm_l, j - base));
+                                    j += 1;
+                                }
+                            }
+                        }
                         else {
                             for (; j < k; ++j) {
                                 h += __builtin_amdgcn_readlane(a64_l, j - base) - div64(h);
                                 h = max(h, cfg.min_high);
                                 f1 += __builtin_amdgcn_readlane(f64_l, j - base) - div64(f1);
-                                if (feed)
-                                    fsk_feed(det, cfg, __builtin_amdgcn_readlane(fm_l, j - base));
                             }
                         }
                         if (k >= e)

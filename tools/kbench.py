@@ -22,7 +22,7 @@ if a.cs16:
     host = np.tile(host, ((a.streams + len(host) - 1) // len(host), 1))[: a.streams]
     cfg = flow_cfg(4, 1024000, fpdm=1, center_frequency=868000000)
 elif a.fsk_cu8:
-    host = np.stack([synth.fsk_stream_cu8(s, a.samples, n_bursts=4) for s in range(min(a.streams, 64))])
+    host = np.stack([synth.fsk_stream_cu8(s, a.samples, n_bursts=4, nbits=512, gap=3000) for s in range(min(a.streams, 64))])
     host = np.tile(host, ((a.streams + len(host) - 1) // len(host), 1))[: a.streams]
     cfg = flow_cfg(2, 250000, fpdm=0)
 else:
