@@ -780,26 +780,16 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                     }
                 }
             }
-            det.low = lo_est;
+            det.low = lo_est = uni(lo_est);
             det.high = max(cfg.ratio * lo_est, cfg.min_high);
             lz_n = 0;
             lz_min = 0x7fffffff;
             lz_max = -0x7fffffff;
         };
-        while (i < n_t) {
-            long long const t_it = now();
-            int const st_it = det.state;
-            if (timing && lane == 0)
-                s_tk[7] += 1;
-            if (dc == 0) { // a new frame == a new push_sdr_flow call
-                flen = (int)min(my_n - (t0 + (uint32_t)i), F);
-                if (p.frame_min_high) // pulse_detect_set_levels before this frame's detection, r_flow.c:180-186
-                    cfg.min_high = uni(p.frame_min_high[(uint64_t)cap * p.frames_cap + min(frame, p.frames_cap - 1)]);
-                det_call_entry(det, cfg, flen, 0);
-            }
-            // Every lane holds the same values here, but they have been through per-lane-looking code
-            // (LDS, the general step); pin what the fast paths loop on to SGPRs so that those loops run
-            // on the scalar unit with scalar branches.
+        // Every lane holds the same detector state, but the general step and call entry are per-lane-looking code;
+        // after them, pin what the fast paths loop on to SGPRs so that those loops run on the scalar unit with
+        // scalar branches (the fast paths themselves keep these values scalar).
+        auto pin_state = [&]() {
             i = uni(i);
             dc = uni(dc);
             flen = uni(flen);
@@ -814,6 +804,20 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
             det.cur_pulse = uni(det.cur_pulse);
             det.ook_f1 = uni(det.ook_f1);
             det.fsk_num = (uint32_t)uni((int)det.fsk_num);
+        };
+        pin_state();
+        while (i < n_t) {
+            long long const t_it = now();
+            int const st_it = det.state;
+            if (timing && lane == 0)
+                s_tk[7] += 1;
+            if (dc == 0) { // a new frame == a new push_sdr_flow call
+                flen = (int)min(my_n - (t0 + (uint32_t)i), F);
+                if (p.frame_min_high) // pulse_detect_set_levels before this frame's detection, r_flow.c:180-186
+                    cfg.min_high = uni(p.frame_min_high[(uint64_t)cap * p.frames_cap + min(frame, p.frames_cap - 1)]);
+                det_call_entry(det, cfg, flen, 0);
+                pin_state();
+            }
             // ---- whole chunks at a time: while idle or inside a gap, nothing can happen before the first
             // chunk whose maximum reaches the (conservative) threshold, the end-of-package count, or the
             // end of the frame ----
@@ -847,9 +851,10 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                         thr = (int)(int16_t)cfg.fixed_high;
                     int const hys = (int)(int16_t)(thr / 8);
                     unsigned long long const m = __ballot(lane >= ci && my_cmax > thr + hys);
-                    long long const lim = min(max(10ll * det.max_pulse, 10ll * cfg.per_ms), 100ll * cfg.per_ms);
-                    long long const togo = det.eop_spurious ? 0 : max(0ll, lim - (long long)det.run);
-                    int const je = togo < (long long)(lim_i - i) ? i + (int)togo : lim_i;
+                    // min(max(10 max_pulse, 10 per_ms), 100 per_ms) without leaving 32 bits (100 per_ms < 2^29)
+                    int const lim = 10 * min(max(det.max_pulse, cfg.per_ms), 10 * cfg.per_ms);
+                    int const togo = det.eop_spurious ? 0 : max(0, lim - det.run);
+                    int const je = togo < lim_i - i ? i + togo : lim_i;
                     jump_to = min(min(m ? (__ffsll(m) - 1) * kChunk : n_t, je), lim_i);
                     if (jump_to > i)
                         det.run += jump_to - i;
@@ -902,7 +907,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                             lo_est += div1024(dl);
                             lo_est += dl > 0 ? 1 : -1;
                         }
-                        det.low = lo_est;
+                        det.low = lo_est = uni(lo_est);
                         det.high = max(cfg.ratio * lo_est, cfg.min_high);
                     }
                     else {
@@ -931,7 +936,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                                 lo_est += dl > 0 ? 1 : -1;
                             }
                             if (k > i0) {
-                                det.low = lo_est;
+                                det.low = lo_est = uni(lo_est);
                                 det.high = max(cfg.ratio * lo_est, cfg.min_high);
                             }
                         }
@@ -947,9 +952,9 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                     unsigned long long const m = __ballot(in_seg && am_l > thr + hys);
                     int const ka = m ? base + (__ffsll(m) - 1) : e;
                     // first sample whose gap count ends the package (pulse_detect.c:446-450)
-                    long long const lim = min(max(10ll * det.max_pulse, 10ll * cfg.per_ms), 100ll * cfg.per_ms);
-                    long long const togo = det.eop_spurious ? 0 : max(0ll, lim - (long long)det.run);
-                    int const ke = togo < (long long)(e - i0) ? i0 + (int)togo : e;
+                    int const lim = 10 * min(max(det.max_pulse, cfg.per_ms), 10 * cfg.per_ms);
+                    int const togo = det.eop_spurious ? 0 : max(0, lim - det.run);
+                    int const ke = togo < e - i0 ? i0 + togo : e;
                     k = min(ka, ke);
                     det.run += k - i0;
                     if (ka <= ke && ka < e && !det.eop_spurious && det.ook_num + 1 < R433_PD_MAX_PULSES) {
@@ -1197,8 +1202,8 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                         j = k + 1;
                         cand &= cand - 1; // next candidate
                     }
-                    det.high = h;
-                    det.ook_f1 = f1;
+                    det.high = uni(h);
+                    det.ook_f1 = uni(f1);
                     det.run += k - i0;
                     if (fall && !feed && det.run + 1 >= 10) {
                         // the pulse ends at k (pulse_detect.c:340-357, the regular case): its width is known, the
@@ -1275,6 +1280,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                     ++local_dc;
                 } while (j < e && det.ook_num == 0 && (det.state == ST_GAP_START || det.state == ST_PULSE));
                 consumed += j - k;
+                pin_state();
             }
             i += consumed;
             dc += consumed;
