@@ -179,13 +179,19 @@ int r433_convert_cs8_cu8(void const *d_in, void *d_out, uint64_t n, void *stream
 int r433_convert_cf32_cs16(void const *d_in, void *d_out, uint64_t n, void *stream);
 /* The pulse-data side door (`-r file.ook`, src/rtl_433.c:1755-1794): packages detected elsewhere go straight to the
  * decoder fan-out.  pulses: n_packages structs in the reference's pulse_data_t layout (host memory); a package goes
- * to the FSK decoders if its fsk_f2_est is non-zero, as the reference decides.  Results are read and dispatched exactly
+ * to the FSK decoders if its fsk_f2_est is non-zero, as the reference decides.  Every package must be at the batch's
+ * sample rate (the decoders' timings are resolved for it at r433_batch_create; sample_rate 0 = the batch's).  Results are read and dispatched exactly
  * as after r433_batch_run (package k carries stream = k).  Returns the number of packages, negative on error. */
 int r433_batch_run_pulses(r433_batch *b, r433_pulse_data const *pulses, uint32_t n_packages, void *stream);
 /* pulse_data_load (src/pulse_data.c:122-176) over a whole `.ook` text in memory: every package up to the first empty
- * one, like the file loop reads them.  (rfraw lines, src/rfraw.c, are not understood.)  Returns the number of packages
+ * one, like the file loop reads them, RfRaw lines (AA B0 / AA B1 ..., src/rfraw.c) included -- those carry
+ * microseconds and set the package's sample_rate to 1000000 as the reference does.  Returns the number of packages
  * written to out (at most max_packages). */
 int r433_pulse_text_load(char const *text, size_t len, uint32_t sample_rate, r433_pulse_data *out, uint32_t max_packages);
+/* The VCD pulse writer (`-w file.vcd`): pulse_data_print_vcd_header (src/pulse_data.c:77-100; `date` is the text of the
+ * $date line) and pulse_data_print_vcd (:102-120; ch_id '\'' for an OOK package, '"' for an FSK one).  snprintf convention. */
+int r433_pulse_vcd_header(uint32_t sample_rate, char const *date, char *buf, size_t cap);
+int r433_pulse_vcd(r433_pulse_data const *data, int ch_id, char *buf, size_t cap);
 /* pulse_data_dump (src/pulse_data.c:193-224): one package as `.ook` text; `received` is the time string of the
  * ";received" line (NULL: no such line).  snprintf convention: returns the full length, writes at most cap bytes. */
 int r433_pulse_text_dump(r433_pulse_data const *data, char const *received, char *buf, size_t cap);

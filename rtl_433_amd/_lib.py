@@ -90,6 +90,7 @@ EXPORTS = [
     "r433_plugin_digest_decode", "r433_envelope_detect", "r433_magnitude_est_cu8",
     "r433_magnitude_est_cs16", "r433_convert_cs8_cu8", "r433_convert_cf32_cs16", "r433_dump_convert",
     "r433_batch_run_pulses", "r433_pulse_text_load", "r433_pulse_text_dump", "r433_batch_analyze", "r433_analysis_text",
+    "r433_pulse_vcd_header", "r433_pulse_vcd",
 ]
 
 
@@ -159,6 +160,10 @@ def bind(L):
     L.r433_batch_analyze.argtypes = [vp, vp, C.c_uint32, vp]
     L.r433_analysis_text.restype = C.c_int
     L.r433_analysis_text.argtypes = [vp, C.c_uint32, vp, C.c_char_p, C.c_size_t]
+    L.r433_pulse_vcd_header.restype = C.c_int
+    L.r433_pulse_vcd_header.argtypes = [C.c_uint32, C.c_char_p, C.c_char_p, C.c_size_t]
+    L.r433_pulse_vcd.restype = C.c_int
+    L.r433_pulse_vcd.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
     L.r433_dump_convert.restype = C.c_int
     L.r433_dump_convert.argtypes = [C.c_int, C.c_uint32, vp, vp, C.c_uint64, vp]
     for f in (L.r433_envelope_detect, L.r433_magnitude_est_cu8, L.r433_magnitude_est_cs16):

@@ -676,6 +676,8 @@ int r433_batch_run_pulses(r433_batch *b, r433_pulse_data const *pulses, uint32_t
     for (uint32_t k = 0; k < n_packages; ++k) {
         if (pulses[k].num_pulses > R433_PD_MAX_PULSES)
             return fail(R433_EINVAL, "package %u has %u pulses (at most %u)", k, pulses[k].num_pulses, (unsigned)R433_PD_MAX_PULSES);
+        if (pulses[k].sample_rate && pulses[k].sample_rate != b->cfg.samp_rate)
+            return fail(R433_EINVAL, "package %u is at %u samples/s, the batch at %u", k, pulses[k].sample_rate, b->cfg.samp_rate);
         max_pulses = std::max(max_pulses, pulses[k].num_pulses);
     }
     uint32_t const stride = ((uint32_t)sizeof(r433_pkg_rec) + 8u * max_pulses + 15u) & ~15u;

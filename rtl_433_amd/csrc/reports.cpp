@@ -218,6 +218,138 @@ int r433_analysis_text(r433_batch *b, uint32_t pkg, r433_analysis const *a, char
     return (int)len;
 }
 
+namespace {
+
+// ---- RfRaw lines inside pulse files, reference src/rfraw.c ----
+int hex_nibble(char const **p) // :16-36
+{
+    if (!p || !*p || !**p)
+        return -1;
+    while (**p == ' ' || **p == '\t' || **p == '-' || **p == ':')
+        ++*p;
+    int const c = **p;
+    if (c >= '0' && c <= '9') {
+        ++*p;
+        return c - '0';
+    }
+    if (c >= 'A' && c <= 'F') {
+        ++*p;
+        return c - 'A' + 10;
+    }
+    if (c >= 'a' && c <= 'f') {
+        ++*p;
+        return c - 'a' + 10;
+    }
+    return -1;
+}
+
+int hex_byte(char const **p) // :38-45
+{
+    int const h = hex_nibble(p);
+    int const l = hex_nibble(p);
+    return h >= 0 && l >= 0 ? (h << 4) | l : -1;
+}
+
+int hex_word(char const **p) // :47-54
+{
+    int const h = hex_byte(p);
+    int const l = hex_byte(p);
+    return h >= 0 && l >= 0 ? (h << 8) | l : -1;
+}
+
+int hex_peek_byte(char const *p) // :56-63
+{
+    return hex_byte(&p);
+}
+
+bool rfraw_check(char const *p) // :65-72: 0xaa 0xb0 or 0xaa 0xb1
+{
+    return hex_nibble(&p) == 0xa && hex_nibble(&p) == 0xa && hex_nibble(&p) == 0xb && (hex_nibble(&p) | 1) == 0x1;
+}
+
+bool parse_rfraw(r433_pulse_data *data, char const **p) // :94-178
+{
+    if (!p || !*p || !**p)
+        return false;
+    if (hex_byte(p) != 0xaa)
+        return false;
+    int const fmt = hex_byte(p);
+    if (fmt != 0xb0 && fmt != 0xb1)
+        return false;
+    if (fmt == 0xb0)
+        hex_byte(p); // len, ignored
+    int const bins_len = hex_byte(p);
+    if (bins_len > 8)
+        return false;
+    int repeats = 1;
+    if (fmt == 0xb0)
+        repeats = hex_byte(p);
+    int bins[8] = {0};
+    for (int i = 0; i < bins_len; ++i)
+        bins[i] = hex_word(p);
+    bool oldfmt = true; // old or new format?
+    for (char const *t = *p; *t;) {
+        int const b = hex_byte(&t);
+        if (b < 0 || b == 0x55)
+            break;
+        if (b & 0x88) {
+            oldfmt = false;
+            break;
+        }
+    }
+    unsigned const prev_pulses = data->num_pulses;
+    bool pulse_needed = true, aligned = true;
+    while (**p) {
+        if (aligned && hex_peek_byte(*p) == 0x55) {
+            hex_byte(p);
+            break;
+        }
+        int const w = hex_nibble(p);
+        aligned = !aligned;
+        if (w < 0)
+            return false;
+        if (w >= 8 || (oldfmt && !aligned)) { // pulse
+            if (!pulse_needed) {
+                data->gap[data->num_pulses] = 0;
+                data->num_pulses++;
+            }
+            data->pulse[data->num_pulses] = bins[w & 7];
+            pulse_needed = false;
+        }
+        else { // gap
+            if (pulse_needed)
+                data->pulse[data->num_pulses] = 0;
+            data->gap[data->num_pulses] = bins[w];
+            data->num_pulses++;
+            pulse_needed = true;
+        }
+        if (data->num_pulses >= R433_MAX_PULSES)
+            break;
+    }
+    unsigned const pkt_pulses = data->num_pulses - prev_pulses; // expand the repeats while there is room
+    for (int i = 1; i < repeats && data->num_pulses + pkt_pulses <= R433_MAX_PULSES; ++i) {
+        memcpy(&data->pulse[data->num_pulses], &data->pulse[prev_pulses], pkt_pulses * sizeof(*data->pulse));
+        memcpy(&data->gap[data->num_pulses], &data->gap[prev_pulses], pkt_pulses * sizeof(*data->pulse));
+        data->num_pulses += pkt_pulses;
+    }
+    data->sample_rate = 1000000; // the widths are microseconds
+    return true;
+}
+
+void rfraw_parse(r433_pulse_data *data, char const *p) // :180-200, appends to the package
+{
+    if (!p || !*p)
+        return;
+    while (*p) {
+        while (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n' || *p == '+' || *p == '-')
+            ++p;
+        if (!parse_rfraw(data, &p))
+            break;
+    }
+}
+
+} // namespace
+
 // pulse_data_load, reference src/pulse_data.c:122-176, over a text in memory: one call of the reference reads one
 // package; the file loop calls it until a package comes back empty (src/rtl_433.c:1757-1761).
 int r433_pulse_text_load(char const *text, size_t len, uint32_t sample_rate, r433_pulse_data *out, uint32_t max_packages)
@@ -259,6 +391,11 @@ int r433_pulse_text_load(char const *text, size_t len, uint32_t sample_rate, r43
                     break; // end or next header found
                 continue;  // still reading a header
             }
+            if (rfraw_check(s)) { // src/pulse_data.c:155-159
+                rfraw_parse(data, s);
+                i = (int)data->num_pulses;
+                continue;
+            }
             char const *p = s;
             char *endptr;
             long const mark = strtol(p, &endptr, 10);
@@ -275,6 +412,62 @@ int r433_pulse_text_load(char const *text, size_t len, uint32_t sample_rate, r43
         n_out += 1;
     }
     return (int)n_out;
+}
+
+// pulse_data_print_vcd_header, reference src/pulse_data.c:77-100 (nice_freq: src/r_util.c:290-307)
+int r433_pulse_vcd_header(uint32_t sample_rate, char const *date, char *buf, size_t cap)
+{
+    if (!buf && cap)
+        return fail(R433_EINVAL, "null argument");
+    char freq[30];
+    double const f = sample_rate;
+    if (f >= 1E9)
+        snprintf(freq, sizeof(freq), "%.3fGHz", f / 1E9);
+    else if (f >= 1E6)
+        snprintf(freq, sizeof(freq), "%.3fMHz", f / 1E6);
+    else if (f >= 1E3)
+        snprintf(freq, sizeof(freq), "%.3fkHz", f / 1E3);
+    else
+        snprintf(freq, sizeof(freq), "%f", f);
+    int const n = snprintf(buf, cap,
+            "$date %s $end\n$version rtl_433 0.1.0 $end\n$comment Acquisition at %s Hz $end\n$timescale %s $end\n"
+            "$scope module rtl_433 $end\n$var wire 1 / FRAME $end\n$var wire 1 ' AM $end\n$var wire 1 \" FM $end\n"
+            "$upscope $end\n$enddefinitions $end\n#0 0/ 0' 0\"\n",
+            date ? date : "", freq, sample_rate <= 500000 ? "1 us" : "100 ns");
+    return n;
+}
+
+// pulse_data_print_vcd, reference src/pulse_data.c:102-120; ch_id is '\'' for an OOK package, '"' for an FSK one
+int r433_pulse_vcd(r433_pulse_data const *data, int ch_id, char *buf, size_t cap)
+{
+    if (!data || (!buf && cap))
+        return fail(R433_EINVAL, "null argument");
+    size_t len = 0;
+#define PUT(...)                                                                                                     \
+    do {                                                                                                             \
+        int const n_ = snprintf(len < cap ? buf + len : nullptr, len < cap ? cap - len : 0, __VA_ARGS__);           \
+        if (n_ > 0)                                                                                                  \
+            len += (size_t)n_;                                                                                       \
+    } while (0)
+    float scale; // (sic) integer division, then float
+    if (data->sample_rate <= 500000)
+        scale = (float)(1000000 / data->sample_rate);
+    else
+        scale = (float)(10000000 / data->sample_rate);
+    uint64_t pos = data->offset;
+    for (unsigned n = 0; n < data->num_pulses && n < R433_MAX_PULSES; ++n) {
+        if (n == 0)
+            PUT("#%.f 1/ 1%c\n", pos * scale, ch_id);
+        else
+            PUT("#%.f 1%c\n", pos * scale, ch_id);
+        pos += (uint64_t)data->pulse[n];
+        PUT("#%.f 0%c\n", pos * scale, ch_id);
+        pos += (uint64_t)data->gap[n];
+    }
+    if (data->num_pulses > 0)
+        PUT("#%.f 0/\n", pos * scale);
+#undef PUT
+    return (int)len;
 }
 
 // pulse_data_dump, reference src/pulse_data.c:193-224.  Returns the length of the text (like snprintf: the text

@@ -166,3 +166,71 @@ def test_reference_cli_decode_of_ook_file_gpu():
     assert len(evs) == 1 and evs[0]["num_rows"] == ref["num_rows"]
     for (bits, _s, data), w in zip(evs[0]["rows"], ref["rows"]):
         assert bits == w["len"] and data[: (bits + 7) // 8].hex()[: (bits + 3) // 4] == w["data"]
+
+
+def _rows_match(evs, ref_events):
+    assert len(evs) == len(ref_events)
+    for ev, ref in zip(evs, ref_events):
+        assert ev["num_rows"] == ref["num_rows"]
+        for (bits, _s, data), w in zip(ev["rows"], ref["rows"]):
+            assert bits == w["len"] and data[: (bits + 7) // 8].hex()[: (bits + 3) // 4] == w["data"]
+
+
+def _flex_row(spec):
+    kv = dict(item.split("=") for item in spec.split(","))
+    mod = {"OOK_PWM": 6, "OOK_PCM": 4}[kv["m"]]
+    row = np.zeros(1, dtype=po.DEV_DTYPE)
+    row[0] = (mod, float(kv.get("s", 0)), float(kv.get("l", 0)), float(kv.get("r", 0)), float(kv.get("g", 0)),
+              float(kv.get("y", 0)), float(kv.get("t", 0)), 0)
+    return row
+
+
+@pytest.mark.parametrize("name", sorted(OOK_FLEX["rfraw"]))
+def test_rfraw_lines_decode_like_reference_cli_emulator(name):
+    """RfRaw lines (src/rfraw.c) inside a pulse file: what the reference CLI decodes from them at 1 MS/s."""
+    g = OOK_FLEX["rfraw"][name]
+    L = _text_lib()
+    pulses = load_pulse_text(g["text"].encode(), 1000000, library=L)
+    assert all(p.sample_rate == 1000000 for p in pulses)
+    eng = _emu_engine(flow_cfg(2, 1000000), _flex_row(g["flex"]))
+    assert eng.run_pulses(pulses) == len(pulses)
+    evs = po.parse_events(eng.events()[0])
+    eng.close()
+    _rows_match(evs, g["events"])
+
+
+def test_pulses_at_another_rate_are_refused_emulator():
+    L = _text_lib()
+    eng = _emu_engine(flow_cfg(2, 250000), load_device_table()[0])
+    pulses = load_pulse_text(OOK_FLEX["rfraw"]["kat"]["text"].encode(), 250000, library=L)  # rfraw: 1 MS/s whatever the caller says
+    assert L.r433_batch_run_pulses(eng.h, C.cast(pulses, C.c_void_p), len(pulses), None) < 0
+    assert "samples/s" in _lib.last_error(L)
+    eng.close()
+
+
+def test_vcd_writer_matches_reference_file_emulator():
+    """`-w kat.vcd` of the reference CLI == r433_pulse_vcd_header + r433_pulse_vcd of the package the path detects
+    (the $date line carries the time of the run)."""
+    from tests.emu.host import emu_lib
+    L = emu_lib()
+    want = open(os.path.join(GOLD, "kat.vcd"), "rb").read().decode().splitlines()
+    iq, ss, rate, freq = make_case("kat")
+    buf = np.zeros(iq.nbytes + 80, dtype=np.uint8)
+    off = (-buf.ctypes.data) % 16
+    buf[off:off + iq.nbytes] = iq.view(np.uint8)
+    eng = BatchEngine(flow_cfg(ss, rate, center_frequency=freq), np.zeros(0, dtype=po.DEV_DTYPE), profiling=False, library=L)
+    assert eng.run_ptr(buf.ctypes.data + off, (iq.nbytes + 15) // 16 * 16, 1, np.array([iq.nbytes], dtype=np.uint32)) == 1
+    out = []
+
+    def on_pkg(user, stream, typ, pd):
+        b = C.create_string_buffer(1 << 16)
+        n = L.r433_pulse_vcd(pd, ord("'") if typ == 1 else ord('"'), b, len(b))
+        out.append(b.raw[:n].decode())
+    cb = PKG_FN(on_pkg)
+    eng.dispatch((C.POINTER(_lib.RDevice) * 0)(), pkg_cb=cb)
+    eng.close()
+    hb = C.create_string_buffer(4096)
+    n = L.r433_pulse_vcd_header(rate, b"D", hb, len(hb))
+    got = (hb.raw[:n].decode() + "".join(out)).splitlines()
+    assert got[0] == "$date D $end" and want[0].startswith("$date ")
+    assert got[1:] == want[1:]
