@@ -188,6 +188,20 @@ int r433_batch_run_pulses(r433_batch *b, r433_pulse_data const *pulses, uint32_t
  * microseconds and set the package's sample_rate to 1000000 as the reference does.  Returns the number of packages
  * written to out (at most max_packages). */
 int r433_pulse_text_load(char const *text, size_t len, uint32_t sample_rate, r433_pulse_data *out, uint32_t max_packages);
+/* The sample grabber (`-S all|unknown|known`, src/r_flow.c:136-147,246-252,342-362, src/samp_grab.c:100-165) as a
+ * plan: which byte range of which capture the reference would have saved to its g<counter>_<freq>M_<rate>k files, from
+ * the package records of the last r433_batch_run (and, for modes 2 and 3, the decode results of the last dispatch).
+ * The ranges point into the caller's own IQ buffers -- copying them out is a memcpy.  grab_mode: 1 all, 2 unknown
+ * (no decoder reported an event during the frame), 3 known.  Returns the number of grabs (may exceed max_grabs). */
+typedef struct r433_grab {
+    uint32_t stream;      /* capture index */
+    uint32_t counter;     /* the ### of the file name, counted through the batch */
+    uint64_t byte_offset; /* into the capture */
+    uint64_t byte_len;    /* multiple of 128 KiB unless cut by the start of the capture or the 3 MiB ring */
+    uint32_t n_samples;   /* the padded signal length the reference reports */
+    uint32_t clipped;     /* 1: the reference would have read ring memory older than the capture here */
+} r433_grab;
+int r433_batch_grab_plan(r433_batch *b, int grab_mode, r433_grab *out, uint32_t max_grabs);
 /* The VCD pulse writer (`-w file.vcd`): pulse_data_print_vcd_header (src/pulse_data.c:77-100; `date` is the text of the
  * $date line) and pulse_data_print_vcd (:102-120; ch_id '\'' for an OOK package, '"' for an FSK one).  snprintf convention. */
 int r433_pulse_vcd_header(uint32_t sample_rate, char const *date, char *buf, size_t cap);

@@ -65,6 +65,12 @@ class Analysis(C.Structure):
                 ("timings", Histogram), ("device", DevTimingRow)]
 
 
+class Grab(C.Structure):
+    """r433_grab (include/r433_hip.h)."""
+    _fields_ = [("stream", C.c_uint32), ("counter", C.c_uint32), ("byte_offset", C.c_uint64), ("byte_len", C.c_uint64),
+                ("n_samples", C.c_uint32), ("clipped", C.c_uint32)]
+
+
 class DigestCtx(C.Structure):
     _fields_ = [("sum", C.c_uint64), ("events", C.c_uint64)]
 
@@ -90,7 +96,7 @@ EXPORTS = [
     "r433_plugin_digest_decode", "r433_envelope_detect", "r433_magnitude_est_cu8",
     "r433_magnitude_est_cs16", "r433_convert_cs8_cu8", "r433_convert_cf32_cs16", "r433_dump_convert",
     "r433_batch_run_pulses", "r433_pulse_text_load", "r433_pulse_text_dump", "r433_batch_analyze", "r433_analysis_text",
-    "r433_pulse_vcd_header", "r433_pulse_vcd",
+    "r433_pulse_vcd_header", "r433_pulse_vcd", "r433_batch_grab_plan",
 ]
 
 
@@ -164,6 +170,8 @@ def bind(L):
     L.r433_pulse_vcd_header.argtypes = [C.c_uint32, C.c_char_p, C.c_char_p, C.c_size_t]
     L.r433_pulse_vcd.restype = C.c_int
     L.r433_pulse_vcd.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
+    L.r433_batch_grab_plan.restype = C.c_int
+    L.r433_batch_grab_plan.argtypes = [vp, C.c_int, vp, C.c_uint32]
     L.r433_dump_convert.restype = C.c_int
     L.r433_dump_convert.argtypes = [C.c_int, C.c_uint32, vp, vp, C.c_uint64, vp]
     for f in (L.r433_envelope_detect, L.r433_magnitude_est_cu8, L.r433_magnitude_est_cs16):

@@ -242,6 +242,7 @@ int run_plan(RunCtx &r)
     r.cap_n.resize(r.n_streams);
     for (uint32_t c = 0; c < r.n_streams; ++c)
         r.cap_n[c] = (r.stream_bytes ? r.stream_bytes[c] : (uint32_t)r.stride_bytes) / r.ss;
+    b->stream_samples = r.cap_n;
     // automatic: only where one wavefront per capture would leave the chip empty -- few, long captures.
     // Aim at ~4096 segments, at least 32 Ki samples each.
     uint32_t split_samples = b->split_samples;
@@ -596,6 +597,8 @@ int run_slice_and_mirror(RunCtx &r)
     b->pkg_bytes = pkg_bytes;
     b->evt_bytes = evt_bytes;
     b->events_counted = false;
+    b->dispatched = false;
+    b->pkg_decoded.clear();
     b->h_rec_off.p[r.total_pkgs] = (uint32_t)pkg_bytes;
     b->h_pkg_off.p[r.total_pkgs] = (uint32_t)evt_bytes;
     if (!n_devs)
@@ -671,6 +674,7 @@ int r433_batch_run_pulses(r433_batch *b, r433_pulse_data const *pulses, uint32_t
     r.n_streams = n_packages;
     r.frames_cap = 1;
     r.n_order = n_packages;
+    b->stream_samples.clear();
     // one arena slot per package, laid out exactly as the detection kernel leaves a capture with one package
     uint32_t max_pulses = 0;
     for (uint32_t k = 0; k < n_packages; ++k) {

@@ -192,6 +192,8 @@ int dispatch_range(r433_batch *b, r433_r_device *const *devices, uint32_t n_devi
             }
         }
         decoded += p_events;
+        if (pkg < b->pkg_decoded.size())
+            b->pkg_decoded[pkg] = p_events; // for the sample grabber's "known / unknown" modes
         for (uint32_t dev : touched)
             count[dev] = 0;
     }
@@ -215,6 +217,8 @@ int r433_batch_dispatch_mt(r433_batch *b, r433_r_device *const *devices, uint32_
 {
     if (!b)
         return fail(R433_EINVAL, "null batch");
+    b->pkg_decoded.assign(b->n_pkgs, 0);
+    b->dispatched = true;
     if (n_devices != b->timing.size())
         return fail(R433_EINVAL, "dispatch needs the %zu devices the engine was created with", b->timing.size());
     uint32_t const np = b->n_pkgs;

@@ -212,6 +212,9 @@ struct r433_batch {
     uint32_t n_pkgs = 0, n_events = 0;
     size_t pkg_bytes = 0, evt_bytes = 0;
     bool events_counted = false;
+    std::vector<uint32_t> stream_samples; // per capture of the last run (as the detector saw them)
+    std::vector<int> pkg_decoded; // per package: events its decoders reported in the last dispatch
+    bool dispatched = false;
 
     void *tap_env = nullptr, *tap_am = nullptr, *tap_fm = nullptr;
     uint64_t tap_stride = 0;

@@ -218,6 +218,78 @@ int r433_analysis_text(r433_batch *b, uint32_t pkg, r433_analysis const *a, char
     return (int)len;
 }
 
+// The sample grabber's bookkeeping (`-S`, reference src/r_flow.c:136-147, 246-252, 342-362 and samp_grab_write,
+// src/samp_grab.c:100-165) replayed over the package records of the last run: which byte ranges of which capture the
+// reference would have written to its g###_<freq>_<rate> files.  The ring buffer is taken per capture (every capture
+// starts from r_init_cfg state like everything else in a batch); where the reference would read ring memory that was
+// never written (a window reaching before the start of the input) the range is clipped and flagged.
+int r433_batch_grab_plan(r433_batch *b, int grab_mode, r433_grab *out, uint32_t max_grabs)
+{
+    if (!b || (!out && max_grabs))
+        return fail(R433_EINVAL, "null argument");
+    if (grab_mode < 1 || grab_mode > 3)
+        return fail(R433_EINVAL, "grab mode must be 1 (all), 2 (unknown) or 3 (known)");
+    if (grab_mode != 1 && !b->dispatched)
+        return fail(R433_EINVAL, "grab modes 2 and 3 need the decode results: dispatch first");
+    uint32_t const ss = b->cfg.sample_size, F = b->cfg.frame_samples;
+    constexpr uint64_t kRing = 12ull * 262144ull; // SIGNAL_GRABBER_BUFFER, include/rtl_433.h:22
+    constexpr uint64_t kBlock = 128 * 1024;       // src/samp_grab.c:98
+    uint32_t n_out = 0, counter = 1;
+    uint32_t pkg = 0;
+    for (uint32_t c = 0; c < b->n_streams; ++c) {
+        uint64_t const n_total = b->stream_samples.size() > c ? b->stream_samples[c] : 0;
+        uint32_t const data_calls = (uint32_t)((n_total + F - 1) / F);
+        unsigned start_ago = 0, end_ago = 0, event_count = 0;
+        uint64_t pushed = 0; // bytes
+        for (uint32_t call = 0; call <= data_calls; ++call) { // the last one is the flush (len 0)
+            uint32_t const n = call < data_calls ? (uint32_t)std::min<uint64_t>(F, n_total - (uint64_t)call * F) : 0u;
+            pushed += (uint64_t)n * ss;
+            if (start_ago)
+                start_ago += n;
+            if (end_ago)
+                end_ago += n;
+            for (; pkg < b->n_pkgs; ++pkg) { // packages are in (capture, detection order)
+                r433_pkg_rec ph;
+                memcpy(&ph, b->h_pkg_blob.p + b->h_rec_off.p[pkg], sizeof(ph));
+                bool const flushed = ph.ret_pos == R433_RET_FLUSH;
+                if (ph.stream != c || (flushed ? call < data_calls : ph.frame != call))
+                    break;
+                if (!start_ago)
+                    start_ago = ph.start_ago;
+                end_ago = ph.end_ago;
+                if (pkg < b->pkg_decoded.size())
+                    event_count += (unsigned)b->pkg_decoded[pkg];
+            }
+            if (start_ago && end_ago > n) { // the frame is older than a whole buffer: it is over
+                if (grab_mode == 1 || (grab_mode == 2 && event_count == 0) || (grab_mode == 3 && event_count > 0)) {
+                    unsigned const pad = n / 8;
+                    unsigned const start_padded = start_ago + pad, end_padded = end_ago - pad;
+                    unsigned const len_padded = start_padded - end_padded;
+                    uint64_t bsize = (uint64_t)ss * len_padded;
+                    bsize += kBlock - bsize % kBlock;
+                    bsize = std::min<uint64_t>(bsize, std::min<uint64_t>(pushed, kRing));
+                    uint64_t const end_byte = pushed - std::min<uint64_t>(pushed, (uint64_t)ss * end_padded);
+                    uint64_t const want_start = end_byte >= bsize ? end_byte - bsize : 0;
+                    if (n_out < max_grabs) {
+                        r433_grab &g = out[n_out];
+                        g.stream = c;
+                        g.counter = counter;
+                        g.byte_offset = want_start;
+                        g.byte_len = end_byte - want_start;
+                        g.n_samples = len_padded;
+                        g.clipped = end_byte < bsize ? 1u : 0u;
+                    }
+                    n_out += 1;
+                    counter += 1;
+                }
+                start_ago = 0;
+                event_count = 0;
+            }
+        }
+    }
+    return (int)n_out;
+}
+
 namespace {
 
 // ---- RfRaw lines inside pulse files, reference src/rfraw.c ----

@@ -113,3 +113,12 @@ def dump_capture(name):
         return synth.ook_batch(1, 32768, 250000, seed0=5)[0][: 2 * 32765].copy(), 2, "g_433.92M_250k.cu8"
     iq = np.asarray(synth.fsk_stream_cs16(3, 40003))
     return iq[: 2 * 40003].copy(), 4, "g_868M_1024k.cs16"
+
+
+def grab_capture(name):
+    """Inputs of the sample-grabber vectors (tests/golden/gen_grab_golden.py): long quiet stretches around bursts so that
+    every window the reference writes lies inside the file."""
+    quiet = lambda n: np.tile(np.array([128, 127], dtype=np.uint8), n)
+    if name == "one_frame":  # five close bursts: one tracked frame
+        return np.concatenate([quiet(200000), make_case("ook_long")[0]])
+    return np.concatenate([quiet(300000), synth.ook_stream(1)[0], quiet(400000), synth.ook_stream(2)[0], quiet(300000)])

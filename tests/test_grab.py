@@ -1,0 +1,78 @@
+"""Sample grabber plan (`-S`, reference src/r_flow.c:342-362, src/samp_grab.c:100-165) against the files the real
+reference CLI saves (tests/golden/grabs.json, made by tests/golden/gen_grab_golden.py)."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from rtl_433_amd import _lib
+from rtl_433_amd.engine import BatchEngine, flow_cfg
+from tests.cases import GOLD, grab_capture
+
+GRABS = json.load(open(os.path.join(GOLD, "grabs.json")))
+
+
+def _plan(eng, mode, L):
+    arr = (_lib.Grab * 16)()
+    n = L.r433_batch_grab_plan(eng.h, mode, C.cast(arr, C.c_void_p), 16)
+    assert n >= 0, _lib.last_error(L)
+    return [arr[k] for k in range(n)]
+
+
+def _check(make_engine, L):
+    names = sorted(GRABS)
+    caps = [grab_capture(n) for n in names]
+    eng, n_pkgs = make_engine(caps)
+    grabs = _plan(eng, 1, L)
+    want = [(ci, g) for ci, n in enumerate(names) for g in GRABS[n]]
+    assert len(grabs) == len(want)
+    for k, (g, (ci, w)) in enumerate(zip(grabs, want)):
+        assert g.stream == ci and g.counter == k + 1 and not g.clipped
+        assert (g.byte_offset, g.byte_len) == (w["offset_in_input"], w["bytes"]), (k, g.byte_offset, g.byte_len, w)
+        data = caps[ci].tobytes()[g.byte_offset:g.byte_offset + g.byte_len]
+        assert hashlib.sha256(data).hexdigest() == w["sha256"]
+    # known / unknown need the decode results
+    assert L.r433_batch_grab_plan(eng.h, 3, None, 0) < 0
+    eng.dispatch((C.POINTER(_lib.RDevice) * 0)())  # no decoders: nothing is ever "known"
+    assert len(_plan(eng, 3, L)) == 0 and len(_plan(eng, 2, L)) == len(want)
+    assert L.r433_batch_grab_plan(eng.h, 4, None, 0) < 0
+    eng.close()
+
+
+def _emu_engine(caps):
+    from tests.emu.host import emu_lib
+    lens = np.array([c.nbytes for c in caps], dtype=np.uint32)
+    stride = int((lens.max() + 15) // 16 * 16)
+    buf = np.zeros(len(caps) * stride + 64, dtype=np.uint8)
+    off = (-buf.ctypes.data) % 16
+    for i, c in enumerate(caps):
+        buf[off + i * stride: off + i * stride + c.nbytes] = c.view(np.uint8)
+    eng = BatchEngine(flow_cfg(2, 250000), np.zeros(0, dtype=po.DEV_DTYPE), profiling=False, library=emu_lib())
+    eng._keep = buf
+    eng.set_split(0)
+    return eng, eng.run_ptr(buf.ctypes.data + off, stride, len(caps), lens)
+
+
+def test_grab_plan_matches_reference_files_emulator():
+    from tests.emu.host import emu_lib
+    _check(_emu_engine, emu_lib())
+
+
+@pytest.mark.gpu
+def test_grab_plan_matches_reference_files_gpu():
+    import torch
+
+    def make(caps):
+        lens = np.array([c.nbytes for c in caps], dtype=np.uint32)
+        stride = int((lens.max() + 15) // 16 * 16)
+        host = np.zeros((len(caps), stride), dtype=np.uint8)
+        for i, c in enumerate(caps):
+            host[i, :c.nbytes] = c.view(np.uint8)
+        eng = BatchEngine(flow_cfg(2, 250000), np.zeros(0, dtype=po.DEV_DTYPE), profiling=False)
+        eng._keep = torch.from_numpy(host).cuda()
+        return eng, eng.run(eng._keep, lens)
+    _check(make, _lib.lib())
