@@ -107,3 +107,21 @@ def _gpu_engine(iq, ss, rate, freq):
 @pytest.mark.gpu
 def test_gpu_matches_oracle_and_reference():
     _check_engine(_gpu_engine, sorted(n for n in GOLDEN if GOLDEN[n]["packages"]))
+
+
+def test_analyze_after_pulse_side_door_emulator():
+    """Packages that came in through r433_batch_run_pulses are analyzed like detected ones."""
+    from tests.emu.host import emu_lib
+    from rtl_433_amd.engine import load_pulse_text
+    L = emu_lib()
+    iq, ss, rate, freq = make_case("kat")
+    eng, n = _emu_engine(iq, ss, rate, freq)
+    a_det = eng.analyze()[0]
+    eng.close()
+    eng = BatchEngine(flow_cfg(ss, rate, center_frequency=freq), None, profiling=False, library=L)
+    text = open(os.path.join(GOLD, "kat.ook"), "rb").read()
+    assert eng.run_pulses(load_pulse_text(text, rate, library=L)) == 1
+    a_file = eng.analyze()[0]
+    eng.close()
+    # the file holds microseconds rounded to integers: 4 us per sample here, so the sample counts survive
+    assert bytes(a_file) == bytes(a_det)
