@@ -174,6 +174,10 @@ def main():
         det, tot, host = [], [], []
         futs, nxt, n_pkgs = deque(), 0, 0
         while nxt < min(n, n_eng - 1):
+            if nxt and state.get("stagger"):
+                # prologue of the software pipeline: legs that start together stay in phase (detection kernel against
+                # detection kernel, slicers against slicers) for several steps; half a leg apart they interleave at once
+                time.sleep(state["stagger"])
             futs.append(gpu_threads.submit(gpu_leg, nxt))
             nxt += 1
         for k in range(n):
@@ -196,6 +200,7 @@ def main():
     solo = [gpu_leg(0)[1] for _ in range(7)]
     solo_det_ms = float(np.mean([t["detect_ms"] for t in solo]))  # average launch duration, as rocprofv3 --stats reports it
     solo_tot_ms = float(np.mean([t["total_ms"] for t in solo]))
+    state["stagger"] = solo_tot_ms / 1e3 / (n_eng - 1)
     run_steps(args.warmup)
     if dist:
         dist.barrier()
