@@ -43,6 +43,11 @@ def make_capture(rng, ss, rate):
         if kind == 1:
             return synth.noise_cu8(int(rng.integers(1 << 30)), n_max, float(rng.choice([0.0, 0.5, 1, 3, 8, 20, 40])))
         if kind == 2:
+            if rng.integers(0, 2):  # FSK of every shape: narrow / wide shift, short / long bits, weak and noisy
+                return synth.fsk_stream_cu8(int(rng.integers(1 << 30)), n_max, rate=rate, n_bursts=int(rng.integers(1, 4)),
+                                            dev_hz=float(rng.choice([4e3, 12e3, 30e3, 70e3])), bit_us=float(rng.choice([24, 60, 100, 400])),
+                                            coding=str(rng.choice(["pcm", "mc"])), nbits=int(rng.integers(8, 300)),
+                                            amp=float(rng.choice([8, 20, 60, 120])), sigma=float(rng.choice([0, 1, 3, 8])))
             return synth.fsk_stream_cu8(int(rng.integers(1 << 30)), n_max, rate=rate, n_bursts=int(rng.integers(1, 4)))
         if kind == 3:  # FSK with very many transitions (> 1200 FSK pulses: ring overflow)
             n = n_max
