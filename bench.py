@@ -252,6 +252,8 @@ def main():
                              "gpu_leg_overlapped": round(float(np.mean(tot_ms)), 3),
                              "host_dispatch": round(float(np.mean(disp_s)) * 1e3, 3), "engines": n_eng,
                              "note": "steps are software-pipelined: up to engines-1 GPU legs (own HIP streams) run under the host leg of an earlier step"},
+            "kernel_only": {"value": round(n_streams * n_samples / (solo_det_ms * 1e-3) / 1e6, 1), "unit": "Msamples/s",
+                            "note": "samples of one launch / isolated k_wave time, per GPU (SURVEY 8d asks for it next to the end-to-end rate)"},
             "packages_per_step": int(n_pkgs), "events_per_step": int(ctx.events),
         }
         if world == 1 and not args.no_cpu_baseline:
