@@ -206,3 +206,15 @@ def dump_pulse_text(pd, received=None, library=None):
     buf = C.create_string_buffer(64 * 1024)
     n = _lib.check(L.r433_pulse_text_dump(C.byref(pd), received, buf, len(buf)), "r433_pulse_text_dump", L)
     return buf.raw[:n]
+
+
+def dump_convert(fmt, sample_size, d_in, n_out, stream=None, library=None):
+    """-w dump format `fmt` ("cs16", "cf32", "am.f32", ... see _lib.DUMP_FORMATS) of a device tensor -> new uint8 device
+    tensor with the converted stream (reference src/r_flow.c:385-489)."""
+    import torch
+    L = library or _lib.lib()
+    width = {"cu8": 1, "cs8": 1, "cs16": 2, "am.s16": 2, "fm.s16": 2}.get(fmt, 4)
+    out = torch.empty(n_out * width + 16, dtype=torch.uint8, device=d_in.device)
+    _lib.check(L.r433_dump_convert(_lib.DUMP_FORMATS[fmt], sample_size, C.c_void_p(d_in.data_ptr()), C.c_void_p(out.data_ptr()),
+                                   n_out, stream), "r433_dump_convert", L)
+    return out[: n_out * width]
