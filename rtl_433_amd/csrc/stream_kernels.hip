@@ -872,9 +872,12 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                     continue;
                 }
             }
-            int const base = i & ~63;
-            int const e = min(min(n_t, base + 64), i + (flen - dc));
-            if (loaded != base) {
+            int const lim = min(n_t, i + (flen - dc)); // end of the tile or of the frame, whichever comes first
+            int base = i & ~63;
+            int e = min(base + 64, lim);
+            auto load_block = [&]() { // the 64 samples at `base`, one per lane, and what the fast paths want of them
+                if (loaded == base)
+                    return;
                 int const il = base + lane;
                 am_l = il < n_t ? ld16(s_am, il) : 0;
                 fm_l = il < n_t ? ld16(s_fm, il) : 0;
@@ -886,7 +889,8 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                 bmax = uni(max(s_cmax[base >> 5], s_cmax[(base >> 5) + 1]));
                 bmin = uni(min(s_cmin[base >> 5], s_cmin[(base >> 5) + 1]));
                 loaded = base;
-            }
+            };
+            load_block();
             // Legs inside this block.  A fast path covers [i0, k) and, where it can, also what happens at k (a
             // regular pulse end, the end of the debounce, the next pulse's start): then the next leg starts
             // right there, without going round the outer loop.  Otherwise the general step takes over at k.
@@ -1247,8 +1251,37 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                     }
                     settled = true;
                 }
-                if (!settled || k >= e)
+                if (k < e) {
+                    if (!settled)
+                        break; // the general step takes over at k
+                    continue;
+                }
+                // The block is used up and nothing is pending.  Inside a package (pulse, debounce, gap) the next block
+                // follows at once -- a gap first skips whole chunks, like the outer loop does -- ; idle stretches and the
+                // ends of the frame and of the tile go round the outer loop.
+                settled = true;
+                if (k >= lim || det.state == ST_IDLE)
                     break;
+                if (det.state == ST_GAP) {
+                    int thr = (int)(int16_t)((det.low + min(det.high, cfg.max_high)) / 2);
+                    if (cfg.fixed_high != 0)
+                        thr = (int)(int16_t)cfg.fixed_high;
+                    int const hys = (int)(int16_t)(thr / 8);
+                    unsigned long long const m = __ballot(lane >= (k >> 5) && my_cmax > thr + hys);
+                    int const lim_eop = 10 * min(max(det.max_pulse, cfg.per_ms), 10 * cfg.per_ms);
+                    int const togo = det.eop_spurious ? 0 : max(0, lim_eop - det.run);
+                    int const je = togo < lim - k ? k + togo : lim;
+                    int const jump_to = min(min(m ? (__ffsll(m) - 1) * kChunk : n_t, je), lim);
+                    if (jump_to > k) {
+                        det.run += jump_to - k;
+                        k = jump_to;
+                    }
+                    if (k >= lim)
+                        break;
+                }
+                base = k & ~63;
+                e = min(base + 64, lim);
+                load_block();
             }
             if (settled) { // everything up to k is done: no general step this round
                 int const done = k - i;
