@@ -1126,8 +1126,10 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                             while (j < kk) {
                                 int const fstate = uni(det.f_state);
                                 int run = 0;
-                                if (fstate != 0 && h >= 0 && cfg.min_high >= 0) {
-                                    int const F0 = uni(fstate == 1 ? det.f_f1 : det.f_f2); // the estimate the detector sits on
+                                // (before its first decision the detector follows the signal with its first estimate in v/16
+                                // steps from the 10th sample on and decides when a sample is more than 3000 away, :44-68)
+                                if ((fstate != 0 || uni((int)det.f_run) >= 9) && h >= 0 && cfg.min_high >= 0) {
+                                    int const F0 = uni(fstate == 2 ? det.f_f2 : det.f_f1); // the estimate the detector sits on
                                     int const other = uni(fstate == 1 ? det.f_f2 : det.f_f1);
                                     int const r = lane - (j - base);
                                     bool const mine = r >= 0 && base + lane < kk;
@@ -1137,7 +1139,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                                     if (r <= 0 || lane == 0)
                                         up = dn = kNone;
                                     int const U = max(F0, up), L = min(F0, -max(dn, -0x3fffffff));
-                                    bool const possible = max(abs(v - L), abs(v - U)) > abs(v - other);
+                                    bool const possible = max(abs(v - L), abs(v - U)) > (fstate == 0 ? 3000 : abs(v - other));
                                     unsigned long long const bad = __ballot(mine && possible);
                                     run = uni((bad ? base + (__ffsll(bad) - 1) : kk) - j);
                                     if (run > 0) {
@@ -1146,27 +1148,29 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                                         int const idx0 = uni(j - base);
                                         // one copy of the loop per state, no branch inside: a taken branch costs a lone
                                         // wavefront more than the few instructions it would skip
-                                        auto advance = [&](auto up_tag) {
-                                            constexpr bool UP = decltype(up_tag)::value;
+                                        auto advance = [&](auto mode_tag) {
+                                            constexpr int MODE = decltype(mode_tag)::value; // the detector's state
                                             for (int u = 0; u < run; ++u) {
                                                 int const x = __builtin_amdgcn_readlane(fm_l, idx0 + u);
                                                 int const x64 = __builtin_amdgcn_readlane(f64_l, idx0 + u);
                                                 int const x16 = (x + ((x >> 31) & 15)) >> 4; // x / 16, C division
                                                 h = max(h - (h >> 6) + __builtin_amdgcn_readlane(a64_l, idx0 + u), cfg.min_high);
                                                 f1 += x64 - div64(f1);
-                                                bool const fast = UP ? x > F : x < F; // towards the outside: 1/16 steps
+                                                bool const fast = MODE == 0 || (MODE == 1 ? x > F : x < F); // towards the outside: 1/16 steps
                                                 int const sh = fast ? 4 : 6, bias = fast ? 15 : 63;
                                                 F += (fast ? x16 : x64) - ((F + ((F >> 31) & bias)) >> sh); // v/16 - F/16 or v/64 - F/64, C division
                                             }
                                         };
-                                        if (fstate == 1)
-                                            advance(std::true_type{});
+                                        if (fstate == 0)
+                                            advance(std::integral_constant<int, 0>{});
+                                        else if (fstate == 1)
+                                            advance(std::integral_constant<int, 1>{});
                                         else
-                                            advance(std::false_type{});
-                                        if (fstate == 1)
-                                            det.f_f1 = F;
-                                        else
+                                            advance(std::integral_constant<int, 2>{});
+                                        if (fstate == 2)
                                             det.f_f2 = F;
+                                        else
+                                            det.f_f1 = F;
                                         j += run;
                                     }
                                 }
