@@ -1030,7 +1030,20 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                                     j += nb * 8;
                                     continue;
                                 }
-                                int const cnt = uni(min(8, kk - j));
+                                if (run > 0) { // the tail of such a run: same plain form, lane numbers computed
+                                    v2s const sv = {1, (short)(neg ? -1 : 1)};
+                                    int const in_sel = neg ? in_pkn_l : in_pk_l;
+                                    v2s x = hv * sv;
+                                    for (int u = 0; u < run; ++u) {
+                                        v2s const in = as_v2s(__builtin_amdgcn_readlane(in_sel, j - base + u));
+                                        x = x + (in - (x >> 6));
+                                    }
+                                    hv = x * sv;
+                                    j += run;
+                                    continue;
+                                }
+                                // the samples the plain form must not take (and only those), at most 8 at a time
+                                int const cnt = uni(min(min(8, kk - j), f1s == -32768 ? 8 : (int)__builtin_ctzll(~bad | (1ull << 63))));
                                 if (cnt == 8) {
     #pragma unroll
                                     for (int u = 0; u < 8; ++u) {
