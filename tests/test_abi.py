@@ -67,3 +67,21 @@ def test_missing_library_is_a_hard_error(monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.lib()
+
+
+def test_public_headers_are_plain_c_and_mirrors_match(tmp_path):
+    """include/*.h compile as C99 on their own, and the ctypes mirrors of the result structs have the compiler's sizes."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "r433_hip.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(r433_analysis), sizeof(r433_histogram), sizeof(r433_grab),\n'
+                   '  sizeof(r433_pulse_data), sizeof(r433_flow_cfg), offsetof(r433_analysis, device), offsetof(r433_grab, byte_len), sizeof(r433_dev_timing)); return 0; }\n')
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, stdout=subprocess.PIPE).stdout.split()]
+    want = [C.sizeof(_lib.Analysis), C.sizeof(_lib.Histogram), C.sizeof(_lib.Grab), C.sizeof(_lib.PulseData), C.sizeof(_lib.FlowCfg),
+            _lib.Analysis.device.offset, _lib.Grab.byte_len.offset, C.sizeof(_lib.DevTimingRow)]
+    assert got == want
