@@ -202,6 +202,11 @@ typedef struct r433_grab {
     uint32_t clipped;     /* 1: the reference would have read ring memory older than the capture here */
 } r433_grab;
 int r433_batch_grab_plan(r433_batch *b, int grab_mode, r433_grab *out, uint32_t max_grabs);
+/* The SigMF container the grabber writes with `-S sigmf:...` (src/samp_grab.c:166-232, src/sigmf.c, microtar): the
+ * bytes before the data of a grab (meta member + header of the data member) and the bytes after it (record padding +
+ * two null records).  Both return the number of bytes needed and write them if cap suffices. */
+int r433_sigmf_prefix(uint32_t sample_size, uint32_t sample_rate, uint32_t frequency, uint64_t data_len, uint8_t *buf, size_t cap);
+int r433_sigmf_trailer(uint64_t data_len, uint8_t *buf, size_t cap);
 /* The VCD pulse writer (`-w file.vcd`): pulse_data_print_vcd_header (src/pulse_data.c:77-100; `date` is the text of the
  * $date line) and pulse_data_print_vcd (:102-120; ch_id '\'' for an OOK package, '"' for an FSK one).  snprintf convention. */
 int r433_pulse_vcd_header(uint32_t sample_rate, char const *date, char *buf, size_t cap);

@@ -97,6 +97,7 @@ EXPORTS = [
     "r433_magnitude_est_cs16", "r433_convert_cs8_cu8", "r433_convert_cf32_cs16", "r433_dump_convert",
     "r433_batch_run_pulses", "r433_pulse_text_load", "r433_pulse_text_dump", "r433_batch_analyze", "r433_analysis_text",
     "r433_pulse_vcd_header", "r433_pulse_vcd", "r433_batch_grab_plan",
+    "r433_sigmf_prefix", "r433_sigmf_trailer",
 ]
 
 
@@ -172,6 +173,10 @@ def bind(L):
     L.r433_pulse_vcd.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
     L.r433_batch_grab_plan.restype = C.c_int
     L.r433_batch_grab_plan.argtypes = [vp, C.c_int, vp, C.c_uint32]
+    L.r433_sigmf_prefix.restype = C.c_int
+    L.r433_sigmf_prefix.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, vp, C.c_size_t]
+    L.r433_sigmf_trailer.restype = C.c_int
+    L.r433_sigmf_trailer.argtypes = [C.c_uint64, vp, C.c_size_t]
     L.r433_dump_convert.restype = C.c_int
     L.r433_dump_convert.argtypes = [C.c_int, C.c_uint32, vp, vp, C.c_uint64, vp]
     for f in (L.r433_envelope_detect, L.r433_magnitude_est_cu8, L.r433_magnitude_est_cs16):

@@ -292,6 +292,72 @@ int r433_batch_grab_plan(r433_batch *b, int grab_mode, r433_grab *out, uint32_t 
 
 namespace {
 
+// one 512-byte tar member header as microtar writes it (reference src/microtar.c:140-170, 388-398): mode 0664, owner,
+// group, mtime and device numbers zero, type '0', "ustar" "00", checksum over the header with its own field as spaces
+void tar_header(uint8_t *h, char const *name, uint64_t size)
+{
+    memset(h, 0, 512);
+    snprintf((char *)h, 100, "%s", name);
+    snprintf((char *)h + 100, 8, "%07o", 0664);
+    snprintf((char *)h + 108, 8, "%07o", 0);
+    snprintf((char *)h + 116, 8, "%07o", 0);
+    snprintf((char *)h + 124, 12, "%011o", (unsigned)size);
+    snprintf((char *)h + 136, 12, "%011o", 0u);
+    h[156] = '0';
+    memcpy(h + 257, "ustar", 6);
+    memcpy(h + 263, "00", 2);
+    snprintf((char *)h + 329, 8, "%07o", 0);
+    snprintf((char *)h + 337, 8, "%07o", 0);
+    unsigned sum = 256;
+    for (int k = 0; k < 148; ++k)
+        sum += h[k];
+    for (int k = 156; k < 512; ++k)
+        sum += h[k];
+    snprintf((char *)h + 148, 8, "%07o", sum);
+    h[155] = ' ';
+}
+
+} // namespace
+
+// The SigMF container of a grabbed signal (`-S sigmf:...`, reference src/samp_grab.c:166-232, src/sigmf.c:290-325,
+// 441-494): everything that precedes the data -- the archive's meta member and the header of the data member.
+int r433_sigmf_prefix(uint32_t sample_size, uint32_t sample_rate, uint32_t frequency, uint64_t data_len, uint8_t *buf, size_t cap)
+{
+    if (!buf && cap)
+        return fail(R433_EINVAL, "null argument");
+    if (sample_size != 2 && sample_size != 4)
+        return fail(R433_EINVAL, "sample_size must be 2 (cu8) or 4 (cs16)");
+    char json[1024] = {0};
+    snprintf(json, sizeof(json),
+            "{    \"global\" : {        \"core:datatype\" : \"%s\",        \"core:sample_rate\" : %u,        \"core:recorder\" : \"%s\","
+            "        \"core:version\" : \"1.0.0\"    },    \"captures\" : [        {            \"core:sample_start\" : %u,"
+            "            \"core:frequency\" : %u        }    ],    \"annotations\" : []}",
+            sample_size == 2 ? "cu8" : "ci16_le", sample_rate, "rtl_433", 0u, frequency);
+    size_t const json_len = strlen(json);
+    size_t const meta_padded = (json_len + 511) / 512 * 512;
+    size_t const total = 512 + meta_padded + 512;
+    if (cap >= total) {
+        memset(buf, 0, total);
+        tar_header(buf, "foobar.sigmf-meta", json_len);
+        memcpy(buf + 512, json, json_len);
+        tar_header(buf + 512 + meta_padded, "foobar.sigmf-data", data_len);
+    }
+    return (int)total;
+}
+
+// ... and what follows it: padding to the next 512-byte record and the two null records that end the archive.
+int r433_sigmf_trailer(uint64_t data_len, uint8_t *buf, size_t cap)
+{
+    if (!buf && cap)
+        return fail(R433_EINVAL, "null argument");
+    size_t const total = (size_t)((512 - data_len % 512) % 512) + 1024;
+    if (cap >= total)
+        memset(buf, 0, total);
+    return (int)total;
+}
+
+namespace {
+
 // ---- RfRaw lines inside pulse files, reference src/rfraw.c ----
 int hex_nibble(char const **p) // :16-36
 {

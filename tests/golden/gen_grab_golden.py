@@ -35,6 +35,14 @@ def main():
                 gold[name].append({"file": os.path.basename(f), "bytes": len(data), "sha256": hashlib.sha256(data).hexdigest(),
                                    "offset_in_input": raw.find(data)})
             said = [ln for ln in r.stderr.decode(errors="replace").splitlines() if "Saving signal" in ln]
+            # the same grabs in the SigMF container (`-S sigmf:all`, src/samp_grab.c:166-232, src/sigmf.c): deterministic bytes
+            for f in files:
+                os.remove(f)
+            subprocess.run([po.REF_CLI, "-r", "in_433.92M_250k.cu8", "-S", "sigmf:all"], cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            for k, f in enumerate(sorted(glob.glob(os.path.join(td, "g[0-9]*.sigmf")))):
+                data = open(f, "rb").read()
+                gold[name][k]["sigmf_bytes"] = len(data)
+                gold[name][k]["sigmf_sha256"] = hashlib.sha256(data).hexdigest()
         print(name, gold[name], said)
     with open(os.path.join(ROOT, "tests", "golden", "grabs.json"), "w") as f:
         json.dump(gold, f, indent=1)

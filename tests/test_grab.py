@@ -76,3 +76,21 @@ def test_grab_plan_matches_reference_files_gpu():
         eng._keep = torch.from_numpy(host).cuda()
         return eng, eng.run(eng._keep, lens)
     _check(make, _lib.lib())
+
+
+def test_sigmf_container_matches_reference_files():
+    """`-S sigmf:all`: prefix + grabbed bytes + trailer == the .sigmf file the reference CLI writes (host-only code)."""
+    L = _lib.lib()
+    for name in sorted(GRABS):
+        raw = grab_capture(name).tobytes()
+        for g in GRABS[name]:
+            buf = C.create_string_buffer(4096)
+            n = L.r433_sigmf_prefix(2, 250000, 433920000, g["bytes"], buf, len(buf))
+            assert n == 1536
+            pre = buf.raw[:n]
+            n2 = L.r433_sigmf_trailer(g["bytes"], buf, len(buf))
+            whole = pre + raw[g["offset_in_input"]:g["offset_in_input"] + g["bytes"]] + buf.raw[:n2]
+            assert len(whole) == g["sigmf_bytes"]
+            assert hashlib.sha256(whole).hexdigest() == g["sigmf_sha256"]
+    assert L.r433_sigmf_prefix(3, 250000, 1, 1, None, 0) < 0
+    assert L.r433_sigmf_trailer(100, None, 0) == 412 + 1024
