@@ -207,6 +207,19 @@ int r433_batch_grab_plan(r433_batch *b, int grab_mode, r433_grab *out, uint32_t 
  * two null records).  Both return the number of bytes needed and write them if cap suffices. */
 int r433_sigmf_prefix(uint32_t sample_size, uint32_t sample_rate, uint32_t frequency, uint64_t data_len, uint8_t *buf, size_t cap);
 int r433_sigmf_trailer(uint64_t data_len, uint8_t *buf, size_t cap);
+/* ... and the reader side (`-r file.sigmf`, sigmf_reader_open, src/sigmf.c:336-434) over an archive in memory: the
+ * first stream's meta data and where its samples sit in the buffer.  (The reference then reads the samples as cu8
+ * whatever the datatype says, src/rtl_433.c:1719.) */
+typedef struct r433_sigmf_info {
+    char datatype[32];    /* core:datatype */
+    uint32_t sample_rate; /* core:sample_rate */
+    uint32_t frequency;   /* captures[0] core:frequency */
+    uint32_t sample_start;
+    uint32_t reserved;
+    uint64_t data_offset; /* of the .sigmf-data member's bytes in the archive */
+    uint64_t data_len;
+} r433_sigmf_info;
+int r433_sigmf_probe(uint8_t const *buf, size_t len, r433_sigmf_info *info);
 /* The VCD pulse writer (`-w file.vcd`): pulse_data_print_vcd_header (src/pulse_data.c:77-100; `date` is the text of the
  * $date line) and pulse_data_print_vcd (:102-120; ch_id '\'' for an OOK package, '"' for an FSK one).  snprintf convention. */
 int r433_pulse_vcd_header(uint32_t sample_rate, char const *date, char *buf, size_t cap);

@@ -71,6 +71,11 @@ class Grab(C.Structure):
                 ("n_samples", C.c_uint32), ("clipped", C.c_uint32)]
 
 
+class SigmfInfo(C.Structure):
+    _fields_ = [("datatype", C.c_char * 32), ("sample_rate", C.c_uint32), ("frequency", C.c_uint32), ("sample_start", C.c_uint32),
+                ("reserved", C.c_uint32), ("data_offset", C.c_uint64), ("data_len", C.c_uint64)]
+
+
 class DigestCtx(C.Structure):
     _fields_ = [("sum", C.c_uint64), ("events", C.c_uint64)]
 
@@ -97,7 +102,7 @@ EXPORTS = [
     "r433_magnitude_est_cs16", "r433_convert_cs8_cu8", "r433_convert_cf32_cs16", "r433_dump_convert",
     "r433_batch_run_pulses", "r433_pulse_text_load", "r433_pulse_text_dump", "r433_batch_analyze", "r433_analysis_text",
     "r433_pulse_vcd_header", "r433_pulse_vcd", "r433_batch_grab_plan",
-    "r433_sigmf_prefix", "r433_sigmf_trailer",
+    "r433_sigmf_prefix", "r433_sigmf_trailer", "r433_sigmf_probe",
 ]
 
 
@@ -177,6 +182,8 @@ def bind(L):
     L.r433_sigmf_prefix.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, vp, C.c_size_t]
     L.r433_sigmf_trailer.restype = C.c_int
     L.r433_sigmf_trailer.argtypes = [C.c_uint64, vp, C.c_size_t]
+    L.r433_sigmf_probe.restype = C.c_int
+    L.r433_sigmf_probe.argtypes = [vp, C.c_size_t, vp]
     L.r433_dump_convert.restype = C.c_int
     L.r433_dump_convert.argtypes = [C.c_int, C.c_uint32, vp, vp, C.c_uint64, vp]
     for f in (L.r433_envelope_detect, L.r433_magnitude_est_cu8, L.r433_magnitude_est_cs16):

@@ -356,6 +356,80 @@ int r433_sigmf_trailer(uint64_t data_len, uint8_t *buf, size_t cap)
     return (int)total;
 }
 
+// sigmf_reader_open, reference src/sigmf.c:336-434, over an archive in memory: the first stream's meta data (the keys
+// json_parse reads, :127-286) and where its samples sit.  Like the reference, whatever `core:datatype` says, the file
+// loop then treats the samples as cu8 (src/rtl_433.c:1719).
+int r433_sigmf_probe(uint8_t const *buf, size_t len, r433_sigmf_info *info)
+{
+    if (!buf || !info)
+        return fail(R433_EINVAL, "null argument");
+    memset(info, 0, sizeof(*info));
+    auto octal = [](uint8_t const *p, size_t n) {
+        uint64_t v = 0;
+        for (size_t k = 0; k < n && p[k] >= '0' && p[k] <= '7'; ++k)
+            v = v * 8 + (uint64_t)(p[k] - '0');
+        return v;
+    };
+    auto has_ext = [](char const *name, char const *ext) {
+        size_t const a = strlen(name), b = strlen(ext);
+        return a >= b && !strcmp(name + a - b, ext);
+    };
+    char stream[101] = {0};
+    size_t pos = 0;
+    bool found_data = false;
+    while (pos + 512 <= len && buf[pos] != 0) { // a null record ends the archive
+        uint8_t const *h = buf + pos;
+        char name[101] = {0};
+        memcpy(name, h, 100);
+        uint64_t const size = octal(h + 124, 11);
+        size_t const data_at = pos + 512;
+        if (data_at + size > len)
+            return fail(R433_EINVAL, "SigMF archive is cut short");
+        bool const regular = h[156] == '0' || h[156] == 0;
+        if (regular && has_ext(name, ".sigmf-meta") && !stream[0]) {
+            snprintf(stream, sizeof(stream), "%s", name);
+            std::string const json((char const *)buf + data_at, (size_t)size);
+            auto value_after = [&](char const *key) -> char const * {
+                size_t const k = json.find(std::string("\"") + key + "\"");
+                if (k == std::string::npos)
+                    return nullptr;
+                size_t c = json.find(':', k + strlen(key) + 2);
+                if (c == std::string::npos)
+                    return nullptr;
+                c += 1;
+                while (c < json.size() && (json[c] == ' ' || json[c] == '\t' || json[c] == '\n' || json[c] == '\r'))
+                    c += 1;
+                return json.c_str() + c;
+            };
+            if (char const *v = value_after("core:datatype")) {
+                if (*v == '"') {
+                    size_t n = 0;
+                    for (++v; v[n] && v[n] != '"' && n + 1 < sizeof(info->datatype); ++n)
+                        info->datatype[n] = v[n];
+                }
+            }
+            if (char const *v = value_after("core:sample_rate"))
+                info->sample_rate = (uint32_t)strtod(v, nullptr);
+            if (char const *v = value_after("core:frequency"))
+                info->frequency = (uint32_t)strtod(v, nullptr);
+            if (char const *v = value_after("core:sample_start"))
+                info->sample_start = (uint32_t)strtod(v, nullptr);
+        }
+        else if (regular && stream[0] && !found_data && has_ext(name, ".sigmf-data")
+                && !strncmp(name, stream, strlen(stream) - 4)) { // "<stream>.sigmf-" + "data"
+            info->data_offset = data_at;
+            info->data_len = size;
+            found_data = true;
+        }
+        pos = data_at + (size_t)((size + 511) / 512 * 512);
+    }
+    if (!stream[0])
+        return fail(R433_EINVAL, "SigMF input with no streams");
+    if (!found_data)
+        return fail(R433_EINVAL, "SigMF input with no stream data");
+    return 0;
+}
+
 namespace {
 
 // ---- RfRaw lines inside pulse files, reference src/rfraw.c ----

@@ -94,3 +94,20 @@ def test_sigmf_container_matches_reference_files():
             assert hashlib.sha256(whole).hexdigest() == g["sigmf_sha256"]
     assert L.r433_sigmf_prefix(3, 250000, 1, 1, None, 0) < 0
     assert L.r433_sigmf_trailer(100, None, 0) == 412 + 1024
+
+
+def test_sigmf_probe_reads_the_container_back():
+    L = _lib.lib()
+    buf = C.create_string_buffer(4096)
+    data = bytes(range(256)) * 5 + b"xyz"  # 1283 bytes: needs record padding
+    n = L.r433_sigmf_prefix(4, 1024000, 868000000, len(data), buf, len(buf))
+    pre = buf.raw[:n]
+    n2 = L.r433_sigmf_trailer(len(data), buf, len(buf))
+    arc = pre + data + buf.raw[:n2]
+    assert len(arc) % 512 == 0
+    info = _lib.SigmfInfo()
+    assert L.r433_sigmf_probe(arc, len(arc), C.byref(info)) == 0, _lib.last_error(L)
+    assert (info.datatype, info.sample_rate, info.frequency, info.sample_start) == (b"ci16_le", 1024000, 868000000, 0)
+    assert arc[info.data_offset:info.data_offset + info.data_len] == data
+    assert L.r433_sigmf_probe(arc[:1000], 1000, C.byref(info)) < 0       # cut short
+    assert L.r433_sigmf_probe(bytes(2048), 2048, C.byref(info)) < 0      # no stream
