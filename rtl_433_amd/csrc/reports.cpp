@@ -231,6 +231,8 @@ int r433_batch_grab_plan(r433_batch *b, int grab_mode, r433_grab *out, uint32_t 
         return fail(R433_EINVAL, "grab mode must be 1 (all), 2 (unknown) or 3 (known)");
     if (grab_mode != 1 && !b->dispatched)
         return fail(R433_EINVAL, "grab modes 2 and 3 need the decode results: dispatch first");
+    if (b->stream_samples.size() != b->n_streams)
+        return fail(R433_EINVAL, "the grabber follows a detection run (r433_batch_run), not a pulse-data run");
     uint32_t const ss = b->cfg.sample_size, F = b->cfg.frame_samples;
     constexpr uint64_t kRing = 12ull * 262144ull; // SIGNAL_GRABBER_BUFFER, include/rtl_433.h:22
     constexpr uint64_t kBlock = 128 * 1024;       // src/samp_grab.c:98

@@ -111,3 +111,15 @@ def test_sigmf_probe_reads_the_container_back():
     assert arc[info.data_offset:info.data_offset + info.data_len] == data
     assert L.r433_sigmf_probe(arc[:1000], 1000, C.byref(info)) < 0       # cut short
     assert L.r433_sigmf_probe(bytes(2048), 2048, C.byref(info)) < 0      # no stream
+
+
+def test_grab_plan_needs_a_detection_run_emulator():
+    from tests.emu.host import emu_lib
+    from rtl_433_amd.engine import load_pulse_text
+    L = emu_lib()
+    eng = BatchEngine(flow_cfg(2, 250000), np.zeros(0, dtype=po.DEV_DTYPE), profiling=False, library=L)
+    text = open(os.path.join(GOLD, "kat.ook"), "rb").read()
+    assert eng.run_pulses(load_pulse_text(text, 250000, library=L)) == 1
+    assert L.r433_batch_grab_plan(eng.h, 1, None, 0) < 0
+    assert "detection run" in _lib.last_error(L)
+    eng.close()
