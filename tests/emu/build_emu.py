@@ -27,7 +27,7 @@ def available():
 
 def sources():
     from rtl_433_amd.build import SOURCES
-    return [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "hip_emu_rt.cpp")]
+    return [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "hip_emu_rt.cpp"), os.path.join(HERE, "selftest_kernels.hip")]
 
 
 def _stale():
@@ -35,7 +35,7 @@ def _stale():
         return True
     t = os.path.getmtime(OUT)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INC, f) for f in os.listdir(INC)]
-    deps += [os.path.join(HERE, "hip_emu_rt.cpp"), os.path.join(HERE, "include", "hip", "hip_runtime.h")]
+    deps += [os.path.join(HERE, "hip_emu_rt.cpp"), os.path.join(HERE, "selftest_kernels.hip"), os.path.join(HERE, "include", "hip", "hip_runtime.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

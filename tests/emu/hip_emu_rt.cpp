@@ -104,6 +104,16 @@ uint8_t *rendezvous(void const *val, unsigned bytes, unsigned tag, uint8_t const
     return B.slots[par].data();
 }
 
+bool all_at_barrier()
+{
+    Block &B = g_blk;
+    unsigned const par = (B.cur->seq - 1u) & 1u; // the round this fiber has just come back from
+    for (unsigned i = 0; i < B.n; ++i)
+        if (!B.fibers[i].done && !(B.live[par][i] && B.tags[par][i] == 1))
+            return false;
+    return true;
+}
+
 static uint8_t *get_stack(unsigned i)
 {
     while (g_stacks.size() <= i) {

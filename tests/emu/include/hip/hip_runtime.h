@@ -70,6 +70,7 @@ unsigned nblocks();
 constexpr unsigned kSlot = 16;
 uint8_t *rendezvous(void const *val, unsigned bytes, unsigned tag, uint8_t const **live);
 void launch(dim3 grid, dim3 block, std::function<void()> const &body);
+bool all_at_barrier(); // did every live fiber of the workgroup deposit the barrier tag in the round just finished?
 
 template <typename T> struct Exch {
     uint8_t *base;
@@ -97,7 +98,15 @@ template <typename T> inline Exch<T> exchange(T v, unsigned tag)
 #define gridDim (emu::Idx{emu::nblocks(), 1u, 1u})
 #define warpSize 64
 
-static inline void __syncthreads() { (void)emu::exchange<int>(0, 1); }
+// A workgroup barrier holds every fiber until all live fibers of the workgroup are at a barrier in the same round:
+// wavefronts that run different code (a producer and a consumer wavefront, say) reach it after different numbers of
+// cross-lane primitives.
+static inline void __syncthreads()
+{
+    do {
+        (void)emu::exchange<int>(0, 1);
+    } while (!emu::all_at_barrier());
+}
 
 template <typename T> static inline T emu_shfl_abs(T v, unsigned tag, int rel_kind, int arg)
 {
