@@ -157,6 +157,12 @@ class BatchEngine:
         n = _lib.check(self.L.r433_analysis_text(self.h, pkg, C.byref(analysis), buf, len(buf)), "r433_analysis_text", self.L)
         return buf.raw[:n].decode()
 
+    def grab_plan(self, mode=1, max_grabs=4096):
+        """Sample grabber (-S all / unknown / known = 1 / 2 / 3): byte ranges of the captures the reference would save."""
+        arr = (_lib.Grab * max_grabs)()
+        n = _lib.check(self.L.r433_batch_grab_plan(self.h, mode, C.cast(arr, C.c_void_p), max_grabs), "r433_batch_grab_plan", self.L)
+        return [arr[k] for k in range(min(n, max_grabs))]
+
     def dispatch(self, rdevices, pkg_cb=None, user=None, n_threads=1):
         """rdevices: ctypes array of POINTER(RDevice) in registration order."""
         cb = C.cast(pkg_cb, C.c_void_p) if pkg_cb is not None else None
