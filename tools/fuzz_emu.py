@@ -202,4 +202,6 @@ if __name__ == "__main__":
         if r:
             bad.append(seed)
             print(f"seed {seed}: {r}", flush=True)
+        if (seed - first + 1) % 50 == 0:
+            print(f"... {seed - first + 1} cases, {len(bad)} failures so far, {time.time() - t0:.0f} s", flush=True)
     print(f"{n_cases} cases, {len(bad)} failures {bad} in {time.time() - t0:.0f} s")
