@@ -1,0 +1,664 @@
+/** @file
+    r_flow_hip.c -- the translation unit a maintainer adds to rtl_433 in place of src/r_flow.c: the same three entry
+    points (include/r_flow.h:19-23)
+
+        int  push_sdr_flow(struct r_cfg *cfg, unsigned char *iq_buf, uint32_t len);
+        int  flush_sdr_flow(struct r_cfg *cfg);
+        void reset_sdr_flow(struct r_cfg *cfg);
+
+    served by librtl433hip.so (include/r433_hip.h).  Everything else of rtl_433 stays what it is: the CLI and its
+    `-r` file loop (src/rtl_433.c:1703-1859), r_api.c with register_protocol / data_acquired_handler, the ~330
+    decoders behind r_device.decode_fn, the output modules.  It is compiled against the reference's own headers and
+    is C99 like the rest of that tree.
+
+    What changes is WHEN the work happens.  The reference walks a file frame by frame on one core.  Here a frame
+    that is pushed is only appended to the current capture in pinned host memory; a flush (the end of a `-r` file)
+    closes the capture; and a *drain* hands every capture collected so far to the GPU in one pass
+    (r433_batch_run_host: one wavefront per capture, then the slicer fan-out) and replays the resulting bitbuffers
+    into the registered decoders in the reference's order (r433_batch_dispatch_hooks), with the pieces of
+    struct dm_state / r_cfg that the output path reads (src/r_api.c:306-333,632-840: in_filename, sample_file_pos,
+    pulse_data / fsk_pulse_data levels and start_ago, ...) set to what they were in the reference at that moment.
+    So `rtl_433 -r a.cu8 -r b.cu8 ... -F json` prints the same lines in the same order.
+
+    A drain happens
+      - at every flush                      when batching is off (RTL433_HIP_BATCH=1, or no end hook compiled in);
+      - when RTL433_HIP_BATCH captures (default 4096) or 1 GiB of samples are waiting;
+      - at hip_sdr_flow_drain(cfg), which the host calls once after its file loop and before close_dumpers()
+        (one added line in src/rtl_433.c:1860; builds of the unmodified rtl_433.c get the same effect from
+        -Dclose_dumpers=hip_sdr_flow_close_dumpers on that one file, see dropin/Makefile).
+    Deferred work means push_sdr_flow returns 0 and the flush (or the drain) returns the events; "-E quit" style
+    options that look at the per-frame event count therefore act at file granularity.
+
+    Not served by this flow (reported once, then ignored): the sample grabber (-S), the raw rtl_tcp output's
+    per-frame pacing is kept, S16_AM / S16_FM pseudo-IQ input files, and sample dumpers other than the input's own
+    format (-w/-W .ook and .vcd are served).
+ */
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdint.h>
+#include <stdbool.h>
+#include <string.h>
+#include <math.h>
+
+#include "r_flow.h"
+#include "rtl_433.h"
+#include "r_private.h"
+#include "r_device.h"
+#include "r_api.h"
+#include "pulse_analyzer.h"
+#include "pulse_data.h"
+#include "decoder_util.h"
+#include "data.h"
+#include "raw_output.h"
+#include "r_util.h"
+#include "logger.h"
+#include "fatal.h"
+
+#include "r433_hip.h"
+
+/* the three structs that cross the boundary are the reference's own (include/r433_abi.h mirrors them) */
+_Static_assert(sizeof(r433_r_device) == sizeof(r_device), "r_device layout");
+_Static_assert(sizeof(r433_pulse_data) == sizeof(pulse_data_t), "pulse_data_t layout");
+_Static_assert(sizeof(r433_bitbuffer) == sizeof(bitbuffer_t), "bitbuffer_t layout");
+
+int hip_sdr_flow_drain(struct r_cfg *cfg);
+void hip_sdr_flow_close_dumpers(struct r_cfg *cfg);
+
+/* one `-r` file (or one stretch of live input between two flushes) */
+typedef struct hip_capture {
+    char const *in_filename;
+    file_info_t load_info;
+    uint32_t samp_rate;
+    uint32_t center_frequency;
+    int sample_size;
+    int fpdm;
+    size_t offset; /* into the staging buffer */
+    uint32_t bytes;
+    uint32_t frame_bytes; /* length of every push but the last */
+    uint32_t last_bytes;  /* length of the last push */
+    uint32_t n_frames;
+    uint32_t frames_cap;
+    float *frame_pos;          /* dm_state.sample_file_pos at each push */
+    struct timeval *frame_now; /* dm_state.now at each push */
+    uint64_t input_pos;        /* dm_state.input_pos at the first push */
+    int irregular;
+} hip_capture;
+
+static struct {
+    r433_batch *eng;
+    r433_flow_cfg eng_cfg;
+    size_t eng_devs;
+    void *eng_first_dev;
+    uint8_t *stage; /* pinned */
+    size_t stage_cap, stage_len;
+    hip_capture *caps;
+    size_t n_caps, caps_cap;
+    int open; /* the last capture is still being pushed to */
+    int warned_grab, warned_dump;
+    /* replay context */
+    r_cfg_t *cfg;
+    hip_capture *group;
+    uint32_t const *frame_sums;
+    uint32_t sums_cap;
+    uint32_t cur_stream;
+    uint32_t cur_frames_done;
+} H = {.cur_stream = UINT32_MAX};
+
+static size_t batch_limit(void)
+{
+    char const *e = getenv("RTL433_HIP_BATCH");
+    if (e && *e) {
+        long v = atol(e);
+        return v < 1 ? 1 : (size_t)v;
+    }
+#ifdef R433_HIP_HAVE_DRAIN
+    return 4096;
+#else
+    return 1;
+#endif
+}
+
+static void hip_fatal(char const *what)
+{
+    print_logf(LOG_FATAL, "HIP", "%s: %s", what, r433_last_error());
+    exit(1);
+}
+
+static void stage_reserve(size_t need)
+{
+    if (need <= H.stage_cap)
+        return;
+    size_t cap = H.stage_cap ? H.stage_cap : (size_t)8 << 20;
+    while (cap < need)
+        cap *= 2;
+    uint8_t *p = r433_host_alloc(cap);
+    if (!p)
+        hip_fatal("pinned staging buffer");
+    if (H.stage_len)
+        memcpy(p, H.stage, H.stage_len);
+    r433_host_free(H.stage);
+    H.stage     = p;
+    H.stage_cap = cap;
+}
+
+static hip_capture *capture_open(r_cfg_t *cfg)
+{
+    struct dm_state *demod = cfg->demod;
+    if (H.n_caps == H.caps_cap) {
+        H.caps_cap = H.caps_cap ? H.caps_cap * 2 : 64;
+        H.caps     = realloc(H.caps, H.caps_cap * sizeof(*H.caps));
+        if (!H.caps)
+            FATAL_REALLOC("hip captures");
+    }
+    hip_capture *c = &H.caps[H.n_caps++];
+    memset(c, 0, sizeof(*c));
+    c->in_filename      = cfg->in_filename;
+    c->load_info        = demod->load_info;
+    c->samp_rate        = demod->samp_rate;
+    c->center_frequency = demod->center_frequency;
+    c->sample_size      = demod->sample_size;
+    c->fpdm             = demod->fsk_pulse_detect_mode;
+    c->input_pos        = demod->input_pos;
+    H.stage_len         = (H.stage_len + 15) & ~(size_t)15;
+    c->offset           = H.stage_len;
+    H.open              = 1;
+    return c;
+}
+
+static void capture_free(hip_capture *c)
+{
+    free(c->frame_pos);
+    free(c->frame_now);
+}
+
+/* ---- replay: what the reference's frame loop does around its decoders (src/r_flow.c:166-189, 240-340) ---- */
+
+/* squelch / auto level bookkeeping of the frames [cur_frames_done, upto) of the current capture */
+static void account_frames(hip_capture *c, uint32_t stream, uint32_t upto)
+{
+    r_cfg_t *cfg           = H.cfg;
+    struct dm_state *demod = cfg->demod;
+    if (upto > c->n_frames)
+        upto = c->n_frames;
+    for (uint32_t f = H.cur_frames_done; f < upto; ++f) {
+        uint32_t n_bytes   = f + 1 < c->n_frames ? c->frame_bytes : c->last_bytes;
+        uint32_t n_samples = n_bytes / c->sample_size;
+        uint32_t sum       = H.frame_sums && f < H.sums_cap ? H.frame_sums[(size_t)stream * H.sums_cap + f] : 0;
+        float avg_db       = r433_level_db(sum, n_samples, c->sample_size == 4 || demod->use_mag_est);
+        if (demod->min_level_auto == 0.0f) {
+            demod->min_level_auto = demod->min_level;
+        }
+        if (demod->noise_level == 0.0f) {
+            demod->noise_level = demod->min_level_auto - 3.0f;
+        }
+        int noise_only = avg_db < demod->noise_level + 3.0f;
+        demod->total_frames_count += 1;
+        if (noise_only) {
+            demod->total_frames_squelch += 1;
+            demod->noise_level = (demod->noise_level * 7 + avg_db) / 8;
+            if (demod->auto_level > 0 && demod->noise_level < demod->min_level - 3.0f
+                    && fabsf(demod->min_level_auto - demod->noise_level - 3.0f) > 1.0f) {
+                demod->min_level_auto = demod->noise_level + 3.0f;
+                print_logf(LOG_WARNING, "Auto Level", "Estimated noise level is %.1f dB, adjusting minimum detection level to %.1f dB",
+                        demod->noise_level, demod->min_level_auto);
+            }
+        }
+        else {
+            demod->noise_level = (demod->noise_level * 31 + avg_db) / 32;
+        }
+    }
+    if (upto > H.cur_frames_done)
+        H.cur_frames_done = upto;
+}
+
+static void switch_to(uint32_t stream)
+{
+    r_cfg_t *cfg           = H.cfg;
+    struct dm_state *demod = cfg->demod;
+    hip_capture *c         = &H.group[stream];
+    H.cur_stream           = stream;
+    H.cur_frames_done      = 0;
+    /* what reset_sdr_flow leaves behind (src/r_flow.c:79-97) and the file loop sets (src/rtl_433.c:1706-1711) */
+    demod->min_level_auto        = 0.0f;
+    demod->noise_level           = 0.0f;
+    cfg->in_filename             = (char *)c->in_filename;
+    demod->load_info             = c->load_info;
+    cfg->samp_rate               = c->samp_rate;
+    cfg->center_frequency        = c->center_frequency;
+    demod->samp_rate             = c->samp_rate;
+    demod->center_frequency      = c->center_frequency;
+    demod->sample_size           = c->sample_size;
+    demod->fsk_pulse_detect_mode = c->fpdm;
+}
+
+/* make `stream` the capture the replay is in; captures on the way (no packages) still count their frames */
+static void enter_capture(uint32_t stream)
+{
+    if (H.cur_stream == stream)
+        return;
+    uint32_t s = 0;
+    if (H.cur_stream != UINT32_MAX) {
+        account_frames(&H.group[H.cur_stream], H.cur_stream, UINT32_MAX);
+        s = H.cur_stream + 1;
+    }
+    for (; s < stream; ++s) {
+        switch_to(s);
+        account_frames(&H.group[s], s, UINT32_MAX);
+    }
+    switch_to(stream);
+}
+
+static void on_package_begin(void *user, r433_pkg_rec const *rec, r433_pulse_data const *pulses)
+{
+    (void)user;
+    r_cfg_t *cfg           = H.cfg;
+    struct dm_state *demod = cfg->demod;
+    char time_str[LOCAL_TIME_BUFLEN];
+
+    enter_capture(rec->stream);
+    hip_capture *c = &H.group[rec->stream];
+    /* the push_sdr_flow call the reference returned this package in (the flush call comes after the last frame) */
+    uint32_t f = rec->frame < c->n_frames ? rec->frame : c->n_frames - 1;
+    account_frames(c, rec->stream, f + 1);
+    demod->sample_file_pos = c->frame_pos[f];
+    demod->now             = c->frame_now[f];
+
+    if (rec->type == R433_PKG_OOK) {
+        memcpy(&demod->pulse_data, pulses, sizeof(pulse_data_t));
+        demod->pulse_data.offset += c->input_pos;
+        /* the FSK candidate next to it: cleared at the package start, no estimates stored (src/pulse_detect.c:313-324) */
+        pulse_data_clear(&demod->fsk_pulse_data);
+        demod->fsk_pulse_data.sample_rate = pulses->sample_rate;
+        demod->fsk_pulse_data.start_ago   = pulses->start_ago;
+        if (demod->analyze_pulses) {
+            fprintf(stderr, "Detected OOK package\t%s\n", time_pos_str(cfg, demod->pulse_data.start_ago, time_str));
+        }
+    }
+    else {
+        memcpy(&demod->fsk_pulse_data, pulses, sizeof(pulse_data_t));
+        demod->fsk_pulse_data.offset += c->input_pos;
+        /* the OOK side is still in its first pulse; the handlers only look at its start_ago (src/r_api.c:820) */
+        pulse_data_clear(&demod->pulse_data);
+        demod->pulse_data.sample_rate = pulses->sample_rate;
+        demod->pulse_data.offset      = demod->fsk_pulse_data.offset;
+        demod->pulse_data.start_ago   = pulses->start_ago;
+        demod->pulse_data.end_ago     = pulses->end_ago;
+        if (demod->analyze_pulses) {
+            fprintf(stderr, "Detected FSK package\t%s\n", time_pos_str(cfg, demod->fsk_pulse_data.start_ago, time_str));
+        }
+    }
+}
+
+static char const *slicer_name(unsigned modulation)
+{
+    switch (modulation) {
+    case OOK_PULSE_PCM:
+    case FSK_PULSE_PCM: return "pulse_slicer_pcm";
+    case OOK_PULSE_PPM: return "pulse_slicer_ppm";
+    case OOK_PULSE_PWM:
+    case FSK_PULSE_PWM: return "pulse_slicer_pwm";
+    case OOK_PULSE_MANCHESTER_ZEROBIT:
+    case FSK_PULSE_MANCHESTER_ZEROBIT: return "pulse_slicer_manchester_zerobit";
+    case OOK_PULSE_PIWM_RAW: return "pulse_slicer_piwm_raw";
+    case OOK_PULSE_PIWM_DC: return "pulse_slicer_piwm_dc";
+    case OOK_PULSE_DMC: return "pulse_slicer_dmc";
+    case OOK_PULSE_PWM_OSV1: return "pulse_slicer_osv1";
+    case OOK_PULSE_NRZS: return "pulse_slicer_nrzs";
+    case OOK_PULSE_RZI: return "pulse_slicer_rzi";
+    default: return "pulse_slicer";
+    }
+}
+
+/* account_event's debug printout (src/pulse_slicer.c:49-59) */
+static void on_event_done(void *user, r433_r_device *dev, int ret, r433_bitbuffer const *bb)
+{
+    (void)user;
+    r_device *device        = (r_device *)dev;
+    bitbuffer_t const *bits = (bitbuffer_t const *)bb;
+    unsigned max_bits       = 0;
+    for (int row = 0; row < bits->num_rows; ++row) {
+        if (bits->bits_per_row[row] > max_bits) {
+            max_bits = bits->bits_per_row[row];
+        }
+    }
+    if (!device->decode_fn || (device->verbose && ret > 0) || (device->verbose > 1 && max_bits > 16) || (device->verbose > 2)) {
+        decoder_log_bitbuffer(device, ret > 0 ? 1 : 2, slicer_name(device->modulation), bits, device->name);
+    }
+}
+
+static void on_package_end(void *user, r433_pkg_rec const *rec, int p_events)
+{
+    (void)user;
+    r_cfg_t *cfg           = H.cfg;
+    struct dm_state *demod = cfg->demod;
+    int const is_ook       = rec->type == R433_PKG_OOK;
+    pulse_data_t *pd       = is_ook ? &demod->pulse_data : &demod->fsk_pulse_data;
+
+    if (is_ook) {
+        demod->total_frames_ook += 1;
+        demod->frames_ook += 1;
+    }
+    else {
+        demod->total_frames_fsk += 1;
+        demod->frames_fsk += 1;
+    }
+    demod->total_frames_events += p_events > 0;
+    demod->frames_events += p_events > 0;
+
+    for (void **iter = demod->dumper.elems; iter && *iter; ++iter) {
+        file_info_t const *dumper = *iter;
+        if (dumper->format == VCD_LOGIC) {
+            pulse_data_print_vcd(dumper->file, pd, is_ook ? '\'' : '"');
+        }
+        if (dumper->format == PULSE_OOK) {
+            pulse_data_dump(dumper->file, pd);
+        }
+    }
+    if (demod->verbosity >= LOG_TRACE) {
+        pulse_data_print(pd);
+    }
+    if (demod->raw_mode == 1 || (demod->raw_mode == 2 && p_events == 0) || (demod->raw_mode == 3 && p_events > 0)) {
+        data_t *data = pulse_data_print_data(pd);
+        event_occurred_handler(cfg, data);
+    }
+    if (demod->analyze_pulses && (demod->grab_mode <= 1 || (demod->grab_mode == 2 && p_events == 0) || (demod->grab_mode == 3 && p_events > 0))) {
+        r_device device = {.log_fn = log_device_handler, .output_ctx = cfg};
+        pulse_analyzer(pd, is_ook ? PULSE_DATA_OOK : PULSE_DATA_FSK, &device);
+    }
+}
+
+/* ---- the GPU pass over a group of captures that share one flow configuration ---- */
+
+static uint32_t capture_frame_samples(hip_capture const *c)
+{
+    /* a capture that came in one push has no frame boundary inside: any frame at least that long will do */
+    uint32_t dflt = DEFAULT_BUF_LENGTH / c->sample_size;
+    if (c->n_frames <= 1)
+        return c->bytes / c->sample_size <= dflt ? dflt : ((c->bytes / c->sample_size + 63u) & ~63u);
+    return c->frame_bytes / c->sample_size;
+}
+
+static void engine_config(r_cfg_t *cfg, hip_capture const *c, r433_flow_cfg *fc)
+{
+    struct dm_state *demod = cfg->demod;
+    r433_flow_cfg_default(fc, c->sample_size, c->samp_rate);
+    fc->frame_samples    = capture_frame_samples(c);
+    fc->fpdm             = c->fpdm;
+    fc->use_mag_est      = demod->use_mag_est;
+    fc->enable_fm        = demod->enable_FM_demod;
+    fc->fm_low_pass      = demod->fm_low_pass;
+    fc->level_limit_db   = demod->level_limit;
+    fc->min_level_db     = demod->min_level;
+    fc->min_snr_db       = demod->min_snr;
+    fc->auto_level       = demod->auto_level;
+    fc->center_frequency = c->center_frequency;
+}
+
+static void engine_ensure(r_cfg_t *cfg, r433_flow_cfg const *fc)
+{
+    struct dm_state *demod = cfg->demod;
+    void *first            = demod->r_devs.len ? demod->r_devs.elems[0] : NULL;
+    if (H.eng && memcmp(fc, &H.eng_cfg, sizeof(*fc)) == 0 && H.eng_devs == demod->r_devs.len && H.eng_first_dev == first)
+        return;
+    r433_batch_destroy(H.eng);
+    size_t n              = demod->r_devs.len;
+    r433_dev_timing *rows = calloc(n ? n : 1, sizeof(*rows));
+    if (!rows)
+        FATAL_CALLOC("hip device rows");
+    for (size_t i = 0; i < n; ++i) {
+        r_device const *d  = demod->r_devs.elems[i];
+        rows[i].modulation  = d->modulation;
+        rows[i].short_width = d->short_width;
+        rows[i].long_width  = d->long_width;
+        rows[i].reset_limit = d->reset_limit;
+        rows[i].gap_limit   = d->gap_limit;
+        rows[i].sync_width  = d->sync_width;
+        rows[i].tolerance   = d->tolerance;
+        rows[i].priority    = d->priority;
+    }
+    H.eng = r433_batch_create(fc, rows, (uint32_t)n);
+    free(rows);
+    if (!H.eng)
+        hip_fatal("r433_batch_create");
+    H.eng_cfg       = *fc;
+    H.eng_devs      = n;
+    H.eng_first_dev = first;
+}
+
+static int run_group(r_cfg_t *cfg, hip_capture *group, size_t n)
+{
+    struct dm_state *demod = cfg->demod;
+    r433_flow_cfg fc;
+    engine_config(cfg, &group[0], &fc);
+    engine_ensure(cfg, &fc);
+
+    void const **ptrs = malloc(n * sizeof(*ptrs));
+    uint32_t *bytes   = malloc(n * sizeof(*bytes));
+    if (!ptrs || !bytes)
+        FATAL_MALLOC("hip capture list");
+    for (size_t i = 0; i < n; ++i) {
+        ptrs[i]  = H.stage + group[i].offset;
+        bytes[i] = group[i].bytes;
+    }
+    int n_pkgs = r433_batch_run_host(H.eng, ptrs, bytes, (uint32_t)n);
+    free(ptrs);
+    free(bytes);
+    if (n_pkgs < 0)
+        hip_fatal("r433_batch_run_host");
+
+    H.cfg        = cfg;
+    H.group      = group;
+    H.cur_stream = UINT32_MAX;
+    r433_batch_frame_sums(H.eng, &H.frame_sums, &H.sums_cap);
+    r433_dispatch_hooks hooks = {NULL, on_package_begin, on_event_done, on_package_end};
+    int events = r433_batch_dispatch_hooks(H.eng, (r433_r_device *const *)demod->r_devs.elems, (uint32_t)demod->r_devs.len, &hooks);
+    if (events == R433_EDECODER) {
+        /* src/pulse_slicer.c:44-47 */
+        print_logf(LOG_ERROR, "pulse_slicer", "%s: notify maintainer", r433_last_error());
+        exit(1);
+    }
+    if (events < 0)
+        hip_fatal("r433_batch_dispatch_hooks");
+    /* captures without packages (and the frames after the last package) still count their frames */
+    enter_capture((uint32_t)n - 1);
+    account_frames(&group[n - 1], (uint32_t)n - 1, UINT32_MAX);
+    H.cur_stream = UINT32_MAX;
+    return events;
+}
+
+static int same_group(r_cfg_t *cfg, hip_capture const *a, hip_capture const *b)
+{
+    (void)cfg;
+    return a->sample_size == b->sample_size && a->samp_rate == b->samp_rate && a->fpdm == b->fpdm
+            && a->center_frequency == b->center_frequency && capture_frame_samples(a) == capture_frame_samples(b);
+}
+
+int hip_sdr_flow_drain(struct r_cfg *cfg)
+{
+    struct dm_state *demod = cfg->demod;
+    if (!demod || H.n_caps == 0)
+        return 0;
+    /* what the host set for the file it is working on right now: restored after the replay */
+    char *keep_filename        = cfg->in_filename;
+    file_info_t keep_load_info = demod->load_info;
+    uint32_t keep_rate = cfg->samp_rate, keep_freq = cfg->center_frequency;
+    uint32_t keep_drate = demod->samp_rate, keep_dfreq = demod->center_frequency;
+    int keep_ss = demod->sample_size, keep_fpdm = demod->fsk_pulse_detect_mode;
+    float keep_pos = demod->sample_file_pos, keep_noise = demod->noise_level, keep_auto = demod->min_level_auto;
+    struct timeval keep_now = demod->now;
+
+    int events   = 0;
+    size_t n_run = H.n_caps - (H.open ? 1 : 0); /* a capture still being pushed to stays queued */
+    for (size_t i = 0; i < n_run;) {
+        hip_capture *c = &H.caps[i];
+        if (c->irregular || c->bytes == 0 || c->n_frames == 0 || (c->n_frames > 1 && c->frame_bytes / c->sample_size % 64 != 0)) {
+            if (c->bytes && c->n_frames)
+                print_logf(LOG_ERROR, "HIP", "\"%s\": frames of unequal or odd length are not served by the HIP flow, capture skipped",
+                        c->in_filename ? c->in_filename : "?");
+            ++i;
+            continue;
+        }
+        size_t j = i + 1;
+        while (j < n_run && !H.caps[j].irregular && H.caps[j].bytes && same_group(cfg, c, &H.caps[j]))
+            ++j;
+        events += run_group(cfg, c, j - i);
+        i = j;
+    }
+
+    /* keep a capture that is still open at the front of the queue */
+    for (size_t i = 0; i < n_run; ++i)
+        capture_free(&H.caps[i]);
+    if (H.open) {
+        hip_capture last = H.caps[H.n_caps - 1];
+        memmove(H.stage, H.stage + last.offset, last.bytes);
+        last.offset = 0;
+        H.caps[0]   = last;
+        H.n_caps    = 1;
+        H.stage_len = last.bytes;
+    }
+    else {
+        H.n_caps    = 0;
+        H.stage_len = 0;
+    }
+
+    cfg->in_filename             = keep_filename;
+    demod->load_info             = keep_load_info;
+    cfg->samp_rate               = keep_rate;
+    cfg->center_frequency        = keep_freq;
+    demod->samp_rate             = keep_drate;
+    demod->center_frequency      = keep_dfreq;
+    demod->sample_size           = keep_ss;
+    demod->fsk_pulse_detect_mode = keep_fpdm;
+    demod->sample_file_pos       = keep_pos;
+    demod->noise_level           = keep_noise;
+    demod->min_level_auto        = keep_auto;
+    demod->now                   = keep_now;
+    return events;
+}
+
+/* For builds of the unmodified src/rtl_433.c: compiled with -Dclose_dumpers=hip_sdr_flow_close_dumpers the file loop's
+   last act (src/rtl_433.c:1861) first drains what is still queued. */
+void hip_sdr_flow_close_dumpers(struct r_cfg *cfg)
+{
+    hip_sdr_flow_drain(cfg);
+    close_dumpers(cfg);
+}
+
+/* ---- the seam ---- */
+
+int flush_sdr_flow(r_cfg_t *cfg)
+{
+    return push_sdr_flow(cfg, NULL, 0);
+}
+
+void reset_sdr_flow(r_cfg_t *cfg)
+{
+    struct dm_state *demod = cfg->demod;
+
+    get_time_now(&demod->now);
+
+    demod->frame_start_ago   = 0;
+    demod->frame_end_ago     = 0;
+    demod->frame_event_count = 0;
+    demod->frame_quality     = 0;
+
+    demod->min_level_auto = 0.0f;
+    demod->noise_level    = 0.0f;
+
+    /* filter, discriminator and detector state live on the device, per capture: a new capture starts clean */
+    H.open = 0;
+}
+
+int push_sdr_flow(r_cfg_t *cfg, unsigned char *iq_buf, uint32_t len)
+{
+    struct dm_state *demod = cfg->demod;
+
+    if (!demod) {
+        return 0; // might happen when the demod closed and we get a last data frame
+    }
+
+    if (!len) {
+        /* flush: the capture is complete */
+        H.open = 0;
+        if (H.n_caps >= batch_limit() || H.stage_len >= ((size_t)1 << 30))
+            return hip_sdr_flow_drain(cfg);
+        return 0;
+    }
+
+    unsigned long n_samples = len / demod->sample_size;
+    if (n_samples * demod->sample_size != len) {
+        print_log(LOG_WARNING, __func__, "Sample buffer length not aligned to sample size!");
+    }
+
+    // Feed data to all raw outputs (e.g. rtl_tcp)
+    for (void **iter = demod->raw_handler ? demod->raw_handler->elems : NULL; iter && *iter; ++iter) {
+        raw_output_t *output = *iter;
+        raw_output_frame(output, iq_buf, len);
+    }
+
+    get_time_now(&demod->now);
+
+    if (demod->samp_grab && !H.warned_grab) {
+        H.warned_grab = 1;
+        print_log(LOG_WARNING, "HIP", "the sample grabber (-S) is not served by the HIP flow");
+    }
+    if (demod->load_info.format == S16_AM || demod->load_info.format == S16_FM) {
+        print_log(LOG_ERROR, "HIP", "AM / FM sample files are not served by the HIP flow");
+        return -1;
+    }
+
+    hip_capture *c = H.open && H.n_caps ? &H.caps[H.n_caps - 1] : capture_open(cfg);
+    if (c->n_frames && (c->sample_size != demod->sample_size || c->samp_rate != demod->samp_rate)) {
+        H.open = 0; /* the stream changed without a flush */
+        c      = capture_open(cfg);
+    }
+    if ((uint64_t)c->bytes + len > 0xfffffff0ull) {
+        print_log(LOG_ERROR, "HIP", "captures are limited to 4 GiB");
+        return -1;
+    }
+    if (c->n_frames == c->frames_cap) {
+        c->frames_cap = c->frames_cap ? c->frames_cap * 2 : 8;
+        c->frame_pos  = realloc(c->frame_pos, c->frames_cap * sizeof(*c->frame_pos));
+        c->frame_now  = realloc(c->frame_now, c->frames_cap * sizeof(*c->frame_now));
+        if (!c->frame_pos || !c->frame_now)
+            FATAL_REALLOC("hip frame table");
+    }
+    if (c->n_frames == 0)
+        c->frame_bytes = len;
+    else if (c->last_bytes != c->frame_bytes)
+        c->irregular = 1; /* a short frame that was not the last */
+    c->last_bytes             = len;
+    c->frame_pos[c->n_frames] = demod->sample_file_pos;
+    c->frame_now[c->n_frames] = demod->now;
+    c->n_frames += 1;
+
+    stage_reserve(c->offset + c->bytes + len + 16);
+    memcpy(H.stage + c->offset + c->bytes, iq_buf, len);
+    c->bytes += len;
+    H.stage_len = c->offset + c->bytes;
+
+    /* sample dumpers: the input's own format is a plain copy (src/r_flow.c:396,403); the package dumpers
+       (.ook, .vcd) are written during the replay */
+    int d_events = 0;
+    for (void **iter = demod->dumper.elems; iter && *iter; ++iter) {
+        file_info_t const *dumper = *iter;
+        if (!dumper->file || dumper->format == VCD_LOGIC || dumper->format == PULSE_OOK) {
+            continue;
+        }
+        if ((dumper->format == CU8_IQ && demod->sample_size == 2) || (dumper->format == CS16_IQ && demod->sample_size == 4)) {
+            if (fwrite(iq_buf, 1, len, dumper->file) != len) {
+                print_log(LOG_ERROR, __func__, "Short write, samples lost, exiting!");
+                d_events = -1;
+            }
+        }
+        else if (!H.warned_dump) {
+            H.warned_dump = 1;
+            print_logf(LOG_WARNING, "HIP", "sample dumper \"%s\" is not served by the HIP flow", dumper->spec);
+        }
+    }
+
+    demod->input_pos += n_samples;
+
+    return d_events;
+}

@@ -80,6 +80,16 @@ void r433_batch_destroy(r433_batch *b);
 int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint32_t const *stream_bytes,
         uint32_t n_streams, void *stream);
 
+/* The same pass for a C host that keeps its captures in host memory (the `-r` file loop, reference
+ * src/rtl_433.c:1703-1859, reads every file into one host buffer): capture s is the capture_bytes[s] bytes at
+ * h_captures[s].  The library stages them into device memory of its own (grow-only; one copy when the captures are
+ * contiguous and equally long, one per capture otherwise) on an internal stream and runs r433_batch_run there.
+ * Memory from r433_host_alloc is pinned, which makes the copy asynchronous and roughly twice as fast; any host
+ * memory works.  Returns the number of packages. */
+void *r433_host_alloc(size_t bytes);
+void r433_host_free(void *p);
+int r433_batch_run_host(r433_batch *b, void const *const *h_captures, uint32_t const *capture_bytes, uint32_t n_captures);
+
 /* Host views of the last run (valid until the next run/destroy). */
 int r433_batch_packages(r433_batch *b, uint8_t const **blob, size_t *len, uint32_t *count);
 int r433_batch_events(r433_batch *b, uint8_t const **blob, size_t *len, uint32_t *count);
@@ -140,6 +150,23 @@ int r433_batch_dispatch(r433_batch *b, r433_r_device *const *devices, uint32_t n
  * cross-package output order is the caller's business). */
 int r433_batch_dispatch_mt(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices, r433_package_fn pkg_cb,
         void *user, uint32_t n_threads);
+
+/* The same replay with every hook point the reference's frame loop has around its decoders (src/r_flow.c:240-340):
+ * package_begin before the decoders of a package (pulse_data_t inflated and levelled as above, plus the package record
+ * with the frame index and data_counter the reference returned it at), event_done after each decode_fn call and before
+ * bitbuffer_clear (account_event's statistics are already updated; this is where its debug printout sits,
+ * src/pulse_slicer.c:49-59), package_end with the package's event count (p_events).  Any hook may be NULL.
+ * Single-threaded, on the calling thread, in reference order. */
+typedef struct r433_dispatch_hooks {
+    void *user;
+    void (*package_begin)(void *user, r433_pkg_rec const *rec, r433_pulse_data const *pulses);
+    void (*event_done)(void *user, r433_r_device *device, int ret, r433_bitbuffer const *bits);
+    void (*package_end)(void *user, r433_pkg_rec const *rec, int p_events);
+} r433_dispatch_hooks;
+int r433_batch_dispatch_hooks(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices,
+        r433_dispatch_hooks const *hooks);
+/* per package of the last dispatch: the events its decoders reported (p_events) */
+int r433_batch_decoded(r433_batch *b, int const **per_package, uint32_t *count);
 
 /* What the dispatcher is handing to decode_fn right now, for plugins that want to tag their output
  * (the reference's `output_tag FILE` needs the capture; time stamps need start_ago).  Thread-local. */

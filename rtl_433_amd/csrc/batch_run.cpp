@@ -652,6 +652,61 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
     return run_slice_and_mirror(r);
 }
 
+void *r433_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        fail(e == hipErrorNoDevice ? R433_ENODEV : R433_ENOMEM, "hipHostMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+
+void r433_host_free(void *p)
+{
+    if (p)
+        (void)hipHostFree(p);
+}
+
+int r433_batch_run_host(r433_batch *b, void const *const *h_captures, uint32_t const *capture_bytes, uint32_t n_captures)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    if (n_captures == 0)
+        return r433_batch_run(b, nullptr, 0, nullptr, 0, nullptr);
+    if (!h_captures || !capture_bytes)
+        return fail(R433_EINVAL, "null capture list");
+    uint64_t max_bytes = 0;
+    bool packed = true; // contiguous and equally long: one copy
+    for (uint32_t i = 0; i < n_captures; ++i) {
+        if (capture_bytes[i] && !h_captures[i])
+            return fail(R433_EINVAL, "capture %u is null", i);
+        max_bytes = std::max<uint64_t>(max_bytes, capture_bytes[i]);
+        if (capture_bytes[i] != capture_bytes[0] || (capture_bytes[0] & 15u)
+                || (uint8_t const *)h_captures[i] != (uint8_t const *)h_captures[0] + (size_t)i * capture_bytes[0])
+            packed = false;
+    }
+    uint64_t const stride = std::max<uint64_t>(16, (max_bytes + 15) & ~15ull);
+    if (stride > 0xfffffff0ull)
+        return fail(R433_EINVAL, "captures are limited to 4 GiB each");
+    if (int rc = b->d_input.ensure((size_t)n_captures * stride + 16))
+        return rc;
+    if (!b->own_stream)
+        HIP_TRY(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
+    hipStream_t const st = b->own_stream;
+    if (packed) {
+        HIP_TRY(hipMemcpyAsync(b->d_input.p, h_captures[0], (size_t)n_captures * stride, hipMemcpyHostToDevice, st));
+    }
+    else {
+        for (uint32_t i = 0; i < n_captures; ++i)
+            if (capture_bytes[i])
+                HIP_TRY(hipMemcpyAsync(b->d_input.p + (size_t)i * stride, h_captures[i], capture_bytes[i], hipMemcpyHostToDevice, st));
+    }
+    b->host_bytes.assign(capture_bytes, capture_bytes + n_captures);
+    return r433_batch_run(b, b->d_input.p, stride, b->host_bytes.data(), n_captures, st);
+}
+
 int r433_batch_run_pulses(r433_batch *b, r433_pulse_data const *pulses, uint32_t n_packages, void *stream)
 {
     if (!b)

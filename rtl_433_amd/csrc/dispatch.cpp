@@ -71,10 +71,11 @@ thread_local r433_dispatch_info g_current;
 
 // Replays packages [p0, p1).  Returns decoded event count or a negative error code.
 int dispatch_range(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices, r433_package_fn pkg_cb, void *user,
-        uint32_t p0, uint32_t p1, std::vector<DevStats> &stats, std::string &err)
+        uint32_t p0, uint32_t p1, std::vector<DevStats> &stats, std::string &err, r433_dispatch_hooks const *hooks = nullptr)
 {
     r433_bitbuffer *bits = (r433_bitbuffer *)calloc(1, sizeof(r433_bitbuffer));
-    r433_pulse_data *pd = pkg_cb ? (r433_pulse_data *)calloc(1, sizeof(r433_pulse_data)) : nullptr;
+    bool const want_pd = pkg_cb || (hooks && hooks->package_begin);
+    r433_pulse_data *pd = want_pd ? (r433_pulse_data *)calloc(1, sizeof(r433_pulse_data)) : nullptr;
     uint8_t const *ev = b->h_events.p;
     uint8_t const *pk = b->h_pkg_blob.p;
     std::vector<uint32_t> first(n_devices, 0), count(n_devices, 0), touched, refs;
@@ -84,7 +85,7 @@ int dispatch_range(r433_batch *b, r433_r_device *const *devices, uint32_t n_devi
     for (uint32_t pkg = p0; pkg < p1 && rc == 0; ++pkg) {
         r433_pkg_rec ph;
         memcpy(&ph, pk + b->h_rec_off.p[pkg], sizeof(ph));
-        if (pkg_cb) {
+        if (want_pd) {
             memset(pd, 0, sizeof(*pd));
             pd->offset = ph.offset;
             pd->sample_rate = ph.sample_rate;
@@ -101,7 +102,10 @@ int dispatch_range(r433_batch *b, r433_r_device *const *devices, uint32_t n_devi
             pd->fsk_f1_est = ph.fsk_f1;
             pd->fsk_f2_est = ph.fsk_f2;
             fill_levels(b->cfg, *pd);
-            pkg_cb(user, ph.stream, ph.type, pd);
+            if (pkg_cb)
+                pkg_cb(user, ph.stream, ph.type, pd);
+            if (hooks && hooks->package_begin)
+                hooks->package_begin(hooks->user, &ph, pd);
         }
 
         // index this package's events by device (they arrive sorted by device, then ordinal)
@@ -182,6 +186,18 @@ int dispatch_range(r433_batch *b, r433_r_device *const *devices, uint32_t n_devi
                     }
                     if (ret > 0)
                         p_events += ret;
+                    if (hooks) { // single-threaded: the r_device's counters move right here, as in account_event
+                        if (rd) {
+                            rd->decode_events += ds.events;
+                            rd->decode_ok += ds.ok;
+                            rd->decode_messages += ds.messages;
+                            for (int f = 0; f < 5; ++f)
+                                rd->decode_fails[f] += ds.fails[f];
+                        }
+                        ds = DevStats();
+                        if (hooks->event_done)
+                            hooks->event_done(hooks->user, rd, ret, bits);
+                    }
                     // bitbuffer_clear: only what can be dirty (the decoder may have grown the buffer)
                     used_rows = std::max<uint32_t>(used_rows, std::max<uint32_t>(bits->num_rows, bits->free_row));
                     if (used_rows > R433_BITBUF_ROWS)
@@ -192,6 +208,8 @@ int dispatch_range(r433_batch *b, r433_r_device *const *devices, uint32_t n_devi
             }
         }
         decoded += p_events;
+        if (hooks && hooks->package_end && rc == 0)
+            hooks->package_end(hooks->user, &ph, p_events);
         if (pkg < b->pkg_decoded.size())
             b->pkg_decoded[pkg] = p_events; // for the sample grabber's "known / unknown" modes
         for (uint32_t dev : touched)
@@ -269,6 +287,38 @@ int r433_batch_dispatch_mt(r433_batch *b, r433_r_device *const *devices, uint32_
         }
     }
     return decoded;
+}
+
+int r433_batch_dispatch_hooks(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices,
+        r433_dispatch_hooks const *hooks)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    b->pkg_decoded.assign(b->n_pkgs, 0);
+    b->dispatched = true;
+    if (n_devices != b->timing.size())
+        return fail(R433_EINVAL, "dispatch needs the %zu devices the engine was created with", b->timing.size());
+    std::vector<DevStats> stats(n_devices);
+    std::string err;
+    static r433_dispatch_hooks const none = {nullptr, nullptr, nullptr, nullptr};
+    int const decoded = dispatch_range(b, devices, n_devices, nullptr, nullptr, 0, b->n_pkgs, stats, err, hooks ? hooks : &none);
+    digest_publish();
+    if (decoded < 0)
+        return fail(decoded, "%s", err.c_str());
+    return decoded;
+}
+
+int r433_batch_decoded(r433_batch *b, int const **per_package, uint32_t *count)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    if (!b->dispatched)
+        return fail(R433_EINVAL, "no dispatch since the last run");
+    if (per_package)
+        *per_package = b->pkg_decoded.data();
+    if (count)
+        *count = (uint32_t)b->pkg_decoded.size();
+    return 0;
 }
 
 int r433_batch_dispatch(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices, r433_package_fn pkg_cb,

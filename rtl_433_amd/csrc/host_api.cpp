@@ -150,6 +150,10 @@ r433_batch *r433_batch_create(r433_flow_cfg const *cfg, r433_dev_timing const *d
         fail(R433_EINVAL, "bad flow configuration");
         return nullptr;
     }
+    if (n_devs && !devs) {
+        fail(R433_EINVAL, "null device table");
+        return nullptr;
+    }
     if (n_devs > 2048) {
         fail(R433_EINVAL, "at most 2048 devices per batch engine");
         return nullptr;
@@ -250,6 +254,11 @@ void r433_batch_destroy(r433_batch *b)
     b->d_events.release();
     b->d_stage.release();
     b->d_converted.release();
+    b->d_analysis.release();
+    b->h_arena_stage.release();
+    b->d_input.release();
+    if (b->own_stream)
+        (void)hipStreamDestroy(b->own_stream);
     b->h_scal.release();
     b->h_frame_sums.release();
     b->h_pkg_blob.release();

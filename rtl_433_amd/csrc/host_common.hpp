@@ -219,6 +219,11 @@ struct r433_batch {
     void *tap_env = nullptr, *tap_am = nullptr, *tap_fm = nullptr;
     uint64_t tap_stride = 0;
 
+    // r433_batch_run_host: captures staged from host memory
+    DevBuf<uint8_t> d_input;
+    hipStream_t own_stream = nullptr;
+    std::vector<uint32_t> host_bytes;
+
     hipEvent_t sync_ev = nullptr; // blocking (sleeping) wait: host threads of other pipeline stages need the cores
     bool profiling = false;
     hipEvent_t ev[8] = {};

@@ -1,0 +1,184 @@
+"""The drop-in itself: rtl_433's own CLI, decoders and JSON printer (compiled unmodified from the reference tree by
+dropin/Makefile) with src/r_flow.c replaced by dropin/r_flow_hip.c, against the stock reference binary
+(oracle/_ref/rtl_433_ref) on the same `-r` file lists.  stdout must be byte-identical: JSON fields, time stamps,
+levels, tags, order.
+
+  * CPU suite: dropin/_build/rtl_433_emu (the kernels on the wave emulator) -- checks r_flow_hip.c and the host API.
+  * -m gpu   : dropin/_build/rtl_433_hip (librtl433hip.so on the MI355X).
+
+Both binaries hold reference code, are built only where /root/reference exists and travel to the GPU box prebuilt.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from rtl_433_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref", "rtl_433_ref")
+EMU = os.path.join(ROOT, "dropin", "_build", "rtl_433_emu")
+HIP = os.path.join(ROOT, "dropin", "_build", "rtl_433_hip")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+FLEX = ["-X", "n=pwm,m=OOK_PWM,s=300,l=600,r=5000,g=2000,t=150",
+        "-X", "n=ppm,m=OOK_PPM,s=300,l=600,r=5000,g=2000,t=150",
+        "-X", "n=mc,m=OOK_MC_ZEROBIT,s=300,l=300,r=5000"]
+KAT_LINE = ('{"time" : "@0.008000s", "protocol" : 169, "model" : "Nice-FlorS", "button" : 1, "serial" : 87791745, '
+            '"code" : 1139, "count" : 6, "mod" : "ASK", "freq" : 433.955, "rssi" : -2.312, "snr" : 39.833, "noise" : -42.144}')
+
+
+def _ensure_built(binary):
+    if os.path.exists(binary) and os.path.exists(REF):
+        return
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip(f"{os.path.relpath(binary, ROOT)} not built and no reference tree to build it from")
+    from oracle import pyoracle as po
+    po.build_ref()
+    if binary == EMU:
+        from tests.emu import build_emu
+        build_emu.build()
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "dropin"), "emu" if binary == EMU else "hip"],
+                          stdout=subprocess.DEVNULL)
+
+
+def run_cli(binary, args, cwd, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([binary] + args, cwd=cwd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+    return p.stdout.decode()
+
+
+def write_ook_files(d, seeds):
+    names = []
+    for s in seeds:
+        iq, _ = synth.ook_stream(s)
+        name = f"s{s:05d}_433.92M_250k.cu8"
+        iq.tofile(os.path.join(d, name))
+        names.append(name)
+    return names
+
+
+def config3_recipe(path):
+    """1024 kS/s cs16, two Manchester FSK bursts, +-40 kHz, 51 samples per half bit."""
+    iq = synth.fsk_stream_cs16(3, 6000 + 2 * (112 * 2 * 51 + 20000), rate=1024000, dev_hz=40e3, halfbit_us=51 / 1.024,
+                               coding="mc", n_bursts=2, nbits=96, amp=0.8, sigma=0.01, lead_in=6000, gap=20000)
+    iq.tofile(path)
+
+
+def file_args(names):
+    out = []
+    for n in names:
+        out += ["-r", n]
+    return out
+
+
+def check_kat(binary, tmp_path):
+    shutil.copy(os.path.join(GOLD, "nice_250k.cu8"), tmp_path / "g001_433.92M_250k.cu8")
+    args = ["-r", "g001_433.92M_250k.cu8", "-R", "169", "-F", "json", "-M", "level", "-M", "protocol"]
+    ref = run_cli(REF, args, tmp_path)
+    got = run_cli(binary, args, tmp_path)
+    assert ref.strip() == KAT_LINE  # the reference's own end-to-end vector
+    assert got == ref
+
+
+def check_batch(binary, tmp_path, seeds, extra_env=None):
+    names = write_ook_files(tmp_path, seeds)
+    # all default decoders + three generic ones (random payloads rarely pass a real decoder's checksum), tagged per file
+    args = file_args(names) + FLEX + ["-F", "json", "-M", "level", "-M", "protocol", "-M", "bits", "-K", "FILE"]
+    ref = run_cli(REF, args, tmp_path)
+    got = run_cli(binary, args, tmp_path, extra_env)
+    assert ref.count("\n") >= len(seeds)  # the generic decoders see every burst
+    assert got == ref
+    return ref
+
+
+def check_config3(binary, tmp_path):
+    config3_recipe(tmp_path / "mc_868M_1024k.cs16")
+    args = ["-r", "mc_868M_1024k.cs16", "-X", "n=mc,m=FSK_MC_ZEROBIT,s=50,l=50,r=120", "-F", "json", "-M", "level"]
+    ref = run_cli(REF, args, tmp_path)
+    got = run_cli(binary, args, tmp_path)
+    assert '"mod" : "FSK"' in ref and ref.count("\n") >= 2
+    assert got == ref
+    # the classic detector (below 800 MHz) and every default decoder on the same samples
+    shutil.copy(tmp_path / "mc_868M_1024k.cs16", tmp_path / "mc_433.92M_1024k.cs16")
+    args = ["-r", "mc_433.92M_1024k.cs16", "-X", "n=mc,m=FSK_MC_ZEROBIT,s=50,l=50,r=120", "-F", "json", "-M", "level"]
+    assert run_cli(binary, args, tmp_path) == run_cli(REF, args, tmp_path)
+
+
+def check_mixed_list(binary, tmp_path):
+    """cu8 and cs16 files, two sample rates, an empty and a short file in one list: groups and order."""
+    names = write_ook_files(tmp_path, [11, 12])
+    config3_recipe(tmp_path / "mc_868M_1024k.cs16")
+    shutil.copy(os.path.join(GOLD, "nice_250k.cu8"), tmp_path / "g001_433.92M_250k.cu8")
+    (tmp_path / "empty_433.92M_250k.cu8").write_bytes(b"")
+    np.full(2 * 300, 128, dtype=np.uint8).tofile(tmp_path / "short_433.92M_250k.cu8")
+    iq, _ = synth.ook_stream(13, rate=1000000)
+    iq.tofile(tmp_path / "s13_433.92M_1000k.cu8")
+    order = [names[0], "mc_868M_1024k.cs16", "empty_433.92M_250k.cu8", "g001_433.92M_250k.cu8", "s13_433.92M_1000k.cu8",
+             "short_433.92M_250k.cu8", names[1]]
+    args = file_args(order) + FLEX + ["-X", "n=fmc,m=FSK_MC_ZEROBIT,s=50,l=50,r=120", "-F", "json", "-M", "level", "-K", "FILE"]
+    ref = run_cli(REF, args, tmp_path)
+    assert '"mod" : "FSK"' in ref and '"mod" : "ASK"' in ref
+    assert run_cli(binary, args, tmp_path) == ref
+    assert run_cli(binary, args, tmp_path, {"RTL433_HIP_BATCH": "1"}) == ref  # one GPU pass per file
+
+
+# ---- CPU suite: the emulator build ----
+
+def test_emu_kat(tmp_path):
+    _ensure_built(EMU)
+    check_kat(EMU, tmp_path)
+
+
+def test_emu_batch(tmp_path):
+    _ensure_built(EMU)
+    check_batch(EMU, tmp_path, range(6))
+
+
+def test_emu_config3(tmp_path):
+    _ensure_built(EMU)
+    check_config3(EMU, tmp_path)
+
+
+def test_emu_mixed_list(tmp_path):
+    _ensure_built(EMU)
+    check_mixed_list(EMU, tmp_path)
+
+
+# ---- GPU: the product library ----
+
+@pytest.mark.gpu
+def test_hip_kat(tmp_path):
+    _ensure_built(HIP)
+    check_kat(HIP, tmp_path)
+
+
+@pytest.mark.gpu
+def test_hip_batch64(tmp_path):
+    _ensure_built(HIP)
+    ref = check_batch(HIP, tmp_path, range(64))
+    assert ref.count("\n") > 64
+
+
+@pytest.mark.gpu
+def test_hip_batch_per_file(tmp_path):
+    _ensure_built(HIP)
+    check_batch(HIP, tmp_path, range(100, 108), {"RTL433_HIP_BATCH": "1"})
+
+
+@pytest.mark.gpu
+def test_hip_config3(tmp_path):
+    _ensure_built(HIP)
+    check_config3(HIP, tmp_path)
+
+
+@pytest.mark.gpu
+def test_hip_mixed_list(tmp_path):
+    _ensure_built(HIP)
+    check_mixed_list(HIP, tmp_path)
