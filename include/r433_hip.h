@@ -126,8 +126,17 @@ typedef struct r433_batch_timing {
 } r433_batch_timing;
 int r433_batch_set_profiling(r433_batch *b, int on);
 /* Debugging aid: raw per-capture kernel state of the last run (n_streams records; returns the record size).
- * With env R433_DEBUG_FLAGS=1024 the detection kernel leaves per-phase clock ticks in it (tools/kbench.py). */
+ * With R433_DEBUG_TIMING (r433_batch_set_debug) the detection kernel leaves per-phase clock ticks in it (tools/kbench.py). */
 int r433_batch_debug_state(r433_batch *b, void *host_buf, size_t bytes);
+/* Development switches, off unless asked for here (no environment variable changes what the library computes).
+ * The first three never change results; SKIP_* leave the results of a run INCOMPLETE (kernel timing experiments). */
+#define R433_DEBUG_SPLIT_BLIND 1u      /* split captures at fixed distances instead of where they look idle (tests) */
+#define R433_DEBUG_TWO_PASS_SLICER 2u  /* count + write slicer passes instead of staging slots */
+#define R433_DEBUG_SPLIT_TRACE 4u      /* stderr trace of dropped cuts */
+#define R433_DEBUG_SKIP_DETECT 256u
+#define R433_DEBUG_SKIP_FILTERS 512u
+#define R433_DEBUG_TIMING 1024u        /* per-phase shader clocks into the debug state (tools/kbench.py) */
+int r433_batch_set_debug(r433_batch *b, uint32_t flags);
 int r433_batch_get_timing(r433_batch *b, r433_batch_timing *t);
 
 /* ------------------------------------------------------------------------------------------------

@@ -281,6 +281,7 @@ class Ref:
         L.refh_digest2.restype = C.c_uint64
         L.refh_digest2.argtypes = [C.c_void_p]
         L.refh_abi_sizes.argtypes = [C.c_void_p]
+        L.refh_add_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         if protocols is None:
             arr, n = None, 0
         else:
@@ -289,6 +290,11 @@ class Ref:
         flex_s = None if not flex else "\n".join(flex).encode()
         jp = None if not json_path else json_path.encode()
         self.h = L.refh_create(arr, n, flex_s, int(call_real), int(record), jp, report_meta, report_protocol)
+
+    def add_rows(self, rows):
+        """Register synthetic decoders (DEV_DTYPE timing rows, any modulation) after the devices registered so far."""
+        rows = np.ascontiguousarray(rows, dtype=DEV_DTYPE)
+        self.L.refh_add_rows(self.h, _ptr(rows), len(rows))
 
     def close(self):
         if self.h:

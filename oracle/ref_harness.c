@@ -214,6 +214,49 @@ static int recording_decode(r_device *decoder, bitbuffer_t *bits)
     return ret;
 }
 
+/* wrap every registered device that is not wrapped yet so its decode_fn records first */
+static void wrap_devices(r_cfg_t *cfg)
+{
+    unsigned idx = 0;
+    for (void **it = cfg->demod->r_devs.elems; it && *it; ++it, ++idx) {
+        r_device *p = *it;
+        if (p->decode_fn == recording_decode)
+            continue;
+        wrapped_dev *w = calloc(1, sizeof(*w));
+        w->dev = *p;
+        w->index = idx;
+        w->real_decode = p->decode_fn;
+        w->dev.decode_fn = recording_decode;
+        free(p);
+        *it = &w->dev;
+    }
+}
+
+/* Synthetic decoders: plain timing rows registered like any protocol (no decode_fn of their own), so that every
+ * slicer -- also the ones no default-enabled protocol uses, OOK_PULSE_PIWM_RAW and OOK_PULSE_NRZS -- can be run
+ * with arbitrary timings through the reference's own fan-out.  Appended after the devices registered so far. */
+void refh_add_rows(void *hv, r433_dev_timing const *rows, int n_rows)
+{
+    harness *h = hv;
+    for (int i = 0; i < n_rows; ++i) {
+        r_device d;
+        memset(&d, 0, sizeof(d));
+        d.name = "probe";
+        d.modulation = rows[i].modulation;
+        d.short_width = rows[i].short_width;
+        d.long_width = rows[i].long_width;
+        d.reset_limit = rows[i].reset_limit;
+        d.gap_limit = rows[i].gap_limit;
+        d.sync_width = rows[i].sync_width;
+        d.tolerance = rows[i].tolerance;
+        d.priority = rows[i].priority;
+        register_protocol(h->cfg, &d, NULL);
+        if (d.modulation >= FSK_DEMOD_MIN_VAL)
+            h->cfg->demod->enable_FM_demod = 1;
+    }
+    wrap_devices(h->cfg);
+}
+
 /* ---- lifecycle ---- */
 
 static void quiet_log(log_level_t level, char const *src, char const *msg, void *userdata)
@@ -263,18 +306,7 @@ void *refh_create(int const *protocols, int n_protocols, char const *flex_specs,
         if (((r_device *)*it)->modulation >= FSK_DEMOD_MIN_VAL)
             cfg->demod->enable_FM_demod = 1;
 
-    /* wrap every registered device so its decode_fn records first */
-    unsigned idx = 0;
-    for (void **it = cfg->demod->r_devs.elems; it && *it; ++it, ++idx) {
-        r_device *p = *it;
-        wrapped_dev *w = calloc(1, sizeof(*w));
-        w->dev = *p;
-        w->index = idx;
-        w->real_decode = p->decode_fn;
-        w->dev.decode_fn = recording_decode;
-        free(p);
-        *it = &w->dev;
-    }
+    wrap_devices(cfg);
     if (json_path && *json_path) {
         list_push(&cfg->output_handler, data_output_json_create(0, strdup(json_path))); /* appends, flushes per line */
     }

@@ -86,6 +86,25 @@ class DispatchInfo(C.Structure):
 
 PACKAGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p)
 
+
+class PkgRec(C.Structure):
+    """r433_pkg_rec (include/r433_records.h): the header of a package record."""
+    _fields_ = [("total_bytes", C.c_uint32), ("stream", C.c_uint32), ("type", C.c_uint32), ("num_pulses", C.c_uint32),
+                ("frame", C.c_uint32), ("ret_pos", C.c_uint32), ("offset", C.c_uint64), ("start_ago", C.c_uint32),
+                ("end_ago", C.c_uint32), ("ook_low", C.c_int32), ("ook_high", C.c_int32), ("fsk_f1", C.c_int32),
+                ("fsk_f2", C.c_int32), ("sample_rate", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+HOOK_BEGIN_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(PkgRec), C.POINTER(PulseData))
+HOOK_EVENT_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(RDevice), C.c_int, C.c_void_p)
+HOOK_END_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(PkgRec), C.c_int)
+
+
+class DispatchHooks(C.Structure):
+    """r433_dispatch_hooks (include/r433_hip.h)."""
+    _fields_ = [("user", C.c_void_p), ("package_begin", HOOK_BEGIN_FN), ("event_done", HOOK_EVENT_FN),
+                ("package_end", HOOK_END_FN)]
+
 _lib = None
 
 # -w dump formats (include/r433_hip.h R433_DUMP_*)
@@ -96,7 +115,7 @@ EXPORTS = [
     "r433_version", "r433_last_error", "r433_device_count", "r433_flow_cfg_default", "r433_level_db",
     "r433_batch_create", "r433_batch_destroy", "r433_batch_run", "r433_batch_packages", "r433_batch_events",
     "r433_batch_frame_sums", "r433_batch_device_events", "r433_batch_set_taps", "r433_batch_set_split",
-    "r433_batch_split_stats", "r433_batch_set_profiling",
+    "r433_batch_split_stats", "r433_batch_set_profiling", "r433_batch_set_debug",
     "r433_batch_get_timing", "r433_batch_debug_state", "r433_batch_dispatch", "r433_batch_dispatch_mt", "r433_dispatch_current",
     "r433_plugin_digest_decode", "r433_envelope_detect", "r433_magnitude_est_cu8",
     "r433_magnitude_est_cs16", "r433_convert_cs8_cu8", "r433_convert_cf32_cs16", "r433_dump_convert",
@@ -146,6 +165,8 @@ def bind(L):
     L.r433_batch_set_taps.argtypes = [vp, vp, vp, vp, C.c_uint64]
     L.r433_batch_set_split.restype = C.c_int
     L.r433_batch_set_split.argtypes = [vp, C.c_uint32]
+    L.r433_batch_set_debug.restype = C.c_int
+    L.r433_batch_set_debug.argtypes = [vp, C.c_uint32]
     L.r433_batch_split_stats.restype = C.c_int
     L.r433_batch_split_stats.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.r433_batch_set_profiling.restype = C.c_int

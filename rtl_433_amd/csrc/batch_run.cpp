@@ -177,7 +177,7 @@ int run_plan_split(RunCtx &r, uint32_t split_samples)
     if (b->det.fixed_high)
         thr = b->det.fixed_high;
     uint64_t const abs_quiet = (uint64_t)std::max(1, (thr - thr / 8) / 2) * 2048u;
-    bool const blind = getenv("R433_SPLIT_BLIND") != nullptr; // tests: cut anywhere, let the verification sort it out
+    bool const blind = (b->debug_flags & R433_DEBUG_SPLIT_BLIND) != 0; // tests: cut anywhere, let the verification sort it out
     uint32_t const seg_len = (split_samples + kTileS - 1) / kTileS * kTileS;
     // a package stays open until its last gap exceeds 10 pulse widths and 10 ms (pulse_detect.c:446-450):
     // ask for 12.5 ms of quiet before a cut (pulses up to 1.25 ms; the stitch catches the rest)
@@ -281,8 +281,7 @@ StreamParams stream_params(RunCtx const &r)
     sp.n_streams = r.n_planned;
     sp.frame_samples = b->cfg.frame_samples;
     sp.flags = 0;
-    if (char const *dbg = getenv("R433_DEBUG_FLAGS")) // phase timing experiments only (results are then incomplete)
-        sp.flags |= (uint32_t)strtoul(dbg, nullptr, 0) & (RUN_DBG_SKIP_DETECT | RUN_DBG_SKIP_FILTERS | RUN_DBG_TIMING);
+    sp.flags |= b->debug_flags & (RUN_DBG_SKIP_DETECT | RUN_DBG_SKIP_FILTERS | RUN_DBG_TIMING); // r433_batch_set_debug
     sp.det = b->det;
     sp.use_mag = (int)b->cfg.use_mag_est;
     sp.enable_fm = (int)b->cfg.enable_fm;
@@ -418,7 +417,7 @@ int run_stitch(RunCtx &r, StreamParams const &sp)
                 // drop this cut: the standing piece continues through the next one.  (Three cuts in a
                 // row that fail are not worth a fourth try: the piece then runs to the capture's end.)
                 bool const give_up = ++dropped[c] >= 3;
-                if (getenv("R433_SPLIT_DEBUG"))
+                if (b->debug_flags & R433_DEBUG_SPLIT_TRACE)
                     fprintf(stderr, "r.split: capture %u cut at %u dropped (end state %d, floor %d vs %d/%d, fail %d/%d)\n", c, nx.seg.start,
                             P.seg_end_state, P.seg_end_low, b->h_state.p[nx.slot[0]].seg_init_low, b->h_state.p[nx.slot[1]].seg_init_low,
                             b->h_state.p[nx.slot[0]].seg_fail, b->h_state.p[nx.slot[1]].seg_fail);
@@ -535,7 +534,7 @@ int run_slice_and_mirror(RunCtx &r)
         uint32_t stage_cap = 4096;
         while (stage_cap >= 512 && (size_t)r.total_pkgs * b->rows.size() * stage_cap > kStageMax)
             stage_cap >>= 1;
-        if (stage_cap >= 512 && !getenv("R433_TWO_PASS_SLICER")) {
+        if (stage_cap >= 512 && !(b->debug_flags & R433_DEBUG_TWO_PASS_SLICER)) {
             if ((rc = b->d_stage.ensure((size_t)r.total_pkgs * b->rows.size() * stage_cap)))
                 return rc;
             lp.stage = b->d_stage.p;
@@ -559,8 +558,11 @@ int run_slice_and_mirror(RunCtx &r)
     HIP_TRY(stream_wait(b, r.st));
     size_t const pkg_bytes = b->h_scal.p[2];
     size_t const evt_bytes = b->h_scal.p[3];
+    // the scans saturate at 0xffffffff (k_scan_u32): offsets are 32-bit by format, a larger batch has to be split
     if (evt_bytes > 0xf0000000ull)
-        return fail(R433_EOVERFLOW, "event stream exceeds 4 GiB; r.split the batch");
+        return fail(R433_EOVERFLOW, "event stream of this batch exceeds 3.75 GiB: run it in smaller batches");
+    if (pkg_bytes > 0xf0000000ull)
+        return fail(R433_EOVERFLOW, "package records of this batch exceed 3.75 GiB: run it in smaller batches");
 
     if ((rc = b->d_pkg_blob.ensure(pkg_bytes + 16)) || (rc = b->h_pkg_blob.ensure(pkg_bytes + 16))
             || (rc = b->d_events.ensure(evt_bytes + 16)) || (rc = b->h_events.ensure(evt_bytes + 16))

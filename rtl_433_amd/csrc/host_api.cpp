@@ -298,6 +298,14 @@ int r433_batch_set_split(r433_batch *b, uint32_t segment_samples)
     return 0;
 }
 
+int r433_batch_set_debug(r433_batch *b, uint32_t flags)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    b->debug_flags = flags;
+    return 0;
+}
+
 int r433_batch_split_stats(r433_batch *b, uint32_t *segments, uint32_t *pieces_rerun)
 {
     if (!b)

@@ -193,6 +193,7 @@ struct r433_batch {
     std::vector<int> h_frame_min_high;
     // split captures (r433_batch_set_split)
     uint32_t split_samples = R433_SPLIT_AUTO;
+    uint32_t debug_flags = 0; // r433_batch_set_debug
     DevBuf<uint32_t> d_tile_max, d_order;
     DevBuf<SegDesc> d_segs;
     PinBuf<uint32_t> h_tile_max;

@@ -512,6 +512,10 @@ bool parse_rfraw(r433_pulse_data *data, char const **p) // :94-178
         }
     }
     unsigned const prev_pulses = data->num_pulses;
+    // The reference stores first and checks after (src/rfraw.c:141-163): a further segment on a line whose package is
+    // already full writes past pulse[] / gap[].  This reader takes untrusted text, so a full package takes nothing more.
+    if (prev_pulses >= R433_MAX_PULSES)
+        return false;
     bool pulse_needed = true, aligned = true;
     while (**p) {
         if (aligned && hex_peek_byte(*p) == 0x55) {
@@ -526,6 +530,8 @@ bool parse_rfraw(r433_pulse_data *data, char const **p) // :94-178
             if (!pulse_needed) {
                 data->gap[data->num_pulses] = 0;
                 data->num_pulses++;
+                if (data->num_pulses >= R433_MAX_PULSES)
+                    break;
             }
             data->pulse[data->num_pulses] = bins[w & 7];
             pulse_needed = false;
@@ -557,7 +563,7 @@ void rfraw_parse(r433_pulse_data *data, char const *p) // :180-200, appends to t
     while (*p) {
         while (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n' || *p == '+' || *p == '-')
             ++p;
-        if (!parse_rfraw(data, &p))
+        if (data->num_pulses >= R433_MAX_PULSES || !parse_rfraw(data, &p))
             break;
     }
 }

@@ -144,11 +144,14 @@ template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
     }
 }
 
+// Exclusive scan of byte counts.  Sums are kept in 64 bits and SATURATE at 0xffffffff on the way out: offsets are
+// 32-bit by format, and a batch whose records pass 4 GiB must come back as R433_EOVERFLOW (the host checks the total),
+// never as offsets that wrapped around and records that overwrite each other.
 __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t const *in, uint32_t *out, uint32_t const *n_ptr,
         uint32_t n_cap, uint32_t *total)
 {
-    __shared__ uint32_t part[1024];
-    __shared__ uint32_t carry;
+    __shared__ uint64_t part[1024];
+    __shared__ uint64_t carry;
     uint32_t const n = min(*n_ptr, n_cap);
     int const tid = (int)threadIdx.x;
     if (tid == 0)
@@ -156,24 +159,26 @@ __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t const *in, uint32_t 
     __syncthreads();
     for (uint32_t base = 0; base < n; base += 1024) {
         uint32_t i = base + (uint32_t)tid;
-        uint32_t v = i < n ? in[i] : 0u;
+        uint64_t v = i < n ? in[i] : 0u;
         part[tid] = v;
         __syncthreads();
         for (int o = 1; o < 1024; o <<= 1) {
-            uint32_t add = tid >= o ? part[tid - o] : 0u;
+            uint64_t add = tid >= o ? part[tid - o] : 0u;
             __syncthreads();
             part[tid] += add;
             __syncthreads();
         }
-        if (i < n)
-            out[i] = carry + part[tid] - v;
+        if (i < n) {
+            uint64_t const off = carry + part[tid] - v;
+            out[i] = off > 0xffffffffull ? 0xffffffffu : (uint32_t)off;
+        }
         __syncthreads();
         if (tid == 1023)
             carry += part[1023];
         __syncthreads();
     }
     if (tid == 0)
-        *total = carry;
+        *total = carry > 0xffffffffull ? 0xffffffffu : (uint32_t)carry;
 }
 
 uint32_t slice_grid(uint32_t grid_pkgs, uint32_t n_rows)

@@ -80,6 +80,27 @@ class BatchEngine:
         rc = self.L.r433_batch_run(self.h, C.c_void_p(ptr), stride, sb, n_streams, C.c_void_p(stream))
         return _lib.check(rc, "r433_batch_run", self.L)
 
+    def run_host(self, captures):
+        """captures: list of numpy arrays in host memory (r433_batch_run_host: the library stages them itself)."""
+        arrs = [np.ascontiguousarray(a) for a in captures]
+        n = len(arrs)
+        ptrs = (C.c_void_p * max(1, n))(*[a.ctypes.data for a in arrs])
+        lens = (C.c_uint32 * max(1, n))(*[a.nbytes for a in arrs])
+        rc = self.L.r433_batch_run_host(self.h, C.cast(ptrs, C.c_void_p), C.cast(lens, C.c_void_p), n)
+        return _lib.check(rc, "r433_batch_run_host", self.L)
+
+    def dispatch_hooks(self, rdevices, hooks):
+        """hooks: a _lib.DispatchHooks (or None)."""
+        rc = self.L.r433_batch_dispatch_hooks(self.h, C.cast(rdevices, C.c_void_p), len(rdevices),
+                                              C.byref(hooks) if hooks is not None else None)
+        return _lib.check(rc, "r433_batch_dispatch_hooks", self.L)
+
+    def decoded(self):
+        """per package: events reported by its decoders in the last dispatch"""
+        p, n = C.c_void_p(), C.c_uint32()
+        _lib.check(self.L.r433_batch_decoded(self.h, C.byref(p), C.byref(n)), "r433_batch_decoded", self.L)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int)), shape=(n.value,)).copy() if n.value else np.zeros(0, dtype=np.int32)
+
     def run(self, iq, stream_bytes=None, stream=None):
         """iq: CUDA tensor [n_streams, stride] of uint8 (cu8) or int16 (cs16), contiguous."""
         import torch
@@ -98,6 +119,10 @@ class BatchEngine:
     def set_split(self, segment_samples):
         """Cut captures longer than segment_samples into independently processed, verified segments."""
         _lib.check(self.L.r433_batch_set_split(self.h, int(segment_samples)), "r433_batch_set_split", self.L)
+
+    def set_debug(self, flags):
+        """Development switches (R433_DEBUG_* of include/r433_hip.h): 1 blind cuts, 2 two-pass slicer, 1024 phase timing."""
+        _lib.check(self.L.r433_batch_set_debug(self.h, int(flags)), "r433_batch_set_debug", self.L)
 
     def split_stats(self):
         a, b = C.c_uint32(), C.c_uint32()

@@ -122,3 +122,61 @@ def grab_capture(name):
     if name == "one_frame":  # five close bursts: one tracked frame
         return np.concatenate([quiet(200000), make_case("ook_long")[0]])
     return np.concatenate([quiet(300000), synth.ook_stream(1)[0], quiet(400000), synth.ook_stream(2)[0], quiet(300000)])
+
+
+# ---- slicer matrix: every line-code slicer x random timings (oracle/gen_slicer_golden.py, tests/test_slicer_matrix.py) ----
+
+# enum modulation_types, reference include/r_device.h:24-40
+ALL_MODULATIONS = (3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 16, 17, 18)
+
+
+def slicer_matrix_rows(seed=77, per_modulation=12):
+    """Synthetic decoder rows: each of the 13 modulations with `per_modulation` random timing sets (us), including the
+    two no default-enabled protocol uses (OOK_PULSE_PIWM_RAW = 8, OOK_PULSE_NRZS = 12), Klimalogg's own row
+    (reference src/devices/klimalogg.c:112-121) and a few degenerate ones (zero widths)."""
+    from oracle.pyoracle import DEV_DTYPE
+    rng = np.random.default_rng(seed)
+    rows = []
+    for mod in ALL_MODULATIONS:
+        for k in range(per_modulation):
+            short = float(rng.choice([26, 40, 52, 100, 200, 300, 400, 500, 800])) * float(rng.uniform(0.9, 1.1))
+            long_ = short * float(rng.choice([1.0, 1.5, 2.0, 3.0]))
+            reset = float(rng.choice([600, 1000, 2500, 6000, 12000]))
+            gap = float(rng.choice([0, 0, 700, 1500, 3000]))
+            sync = float(rng.choice([0, 0, 0, 700, 1500]))
+            tol = float(rng.choice([0, 0, 20, 60, 150]))
+            if k == per_modulation - 1:  # degenerate: a width that rounds to zero samples / no long width
+                # (a zero long width is a SIGFPE in the reference's PCM / PPM / RZI slicers, e.g. src/pulse_slicer.c:97,
+                # not a case; OSv1 (10), NRZS (12) and FSK Manchester (18) never divide by it)
+                short, long_ = (short, 0.0) if mod in (10, 12, 18) else (2.0, 3.0)
+            rows.append((mod, np.float32(short), np.float32(long_), np.float32(reset), np.float32(gap), np.float32(sync),
+                         np.float32(tol), 0))
+    rows.append((12, 26.0, 0.0, 1000.0, 0.0, 0.0, 0.0, 0))  # Klimalogg
+    return np.array(rows, dtype=DEV_DTYPE)
+
+
+SLICER_CASES = ["ook20", "ook21", "ook22", "ook23", "ook24", "ook25", "nrz", "fsk_cu8", "fsk_cu8_mc", "random"]
+
+
+def make_slicer_case(name):
+    """-> (iq, sample_size, rate, centre frequency): what the slicer matrix is run over."""
+    if name.startswith("ook"):
+        return synth.ook_stream(int(name[3:]))[0], 2, 250000, 433920000
+    if name == "nrz":  # level shifts at multiples of 100 us: what PIWM_RAW / NRZS / PCM / RZI expect
+        rng = np.random.default_rng(5)
+        segs = [(3000, False)]
+        for rep in range(3):
+            level = True
+            for _ in range(60):
+                segs.append((25 * int(rng.integers(1, 5)), level))
+                level = not level
+            segs.append((4000 + 1500 * rep, False))
+        mask = synth._segments_to_mask(segs, 65536)
+        return synth.modulate_cu8(mask, rng, 250000, 20e3, 90.0, 1.0), 2, 250000, 433920000
+    if name == "fsk_cu8":
+        return synth.fsk_stream_cu8(13, 120000), 2, 250000, 433920000
+    if name == "fsk_cu8_mc":
+        return synth.fsk_stream_cu8(14, 120000, coding="mc", n_bursts=3), 2, 250000, 868300000
+    if name == "random":
+        return synth.random_cu8(15, 120000), 2, 250000, 433920000
+    raise KeyError(name)

@@ -21,7 +21,7 @@ def emu_lib():
     return _emu
 
 
-def emu_run(iq_list, ss, rate, devs, fpdm=0, taps=False, enable_fm=1, center_frequency=433920000, split=0, **kw):
+def emu_run(iq_list, ss, rate, devs, fpdm=0, taps=False, enable_fm=1, center_frequency=433920000, split=0, debug=0, **kw):
     """Same contract as tests/test_gpu_parity._gpu_run, on the emulator."""
     n = len(iq_list)
     lens = np.array([a.nbytes for a in iq_list], dtype=np.uint32)
@@ -35,6 +35,8 @@ def emu_run(iq_list, ss, rate, devs, fpdm=0, taps=False, enable_fm=1, center_fre
     eng = BatchEngine(cfg, devs, profiling=False, library=emu_lib())
     if split:
         eng.set_split(split)
+    if debug:
+        eng.set_debug(debug)
     tap_bufs = None
     if taps:
         ns = max(1, stride // (ss * (2 if kw.get('input_format') == 2 else 1)))

@@ -1,8 +1,9 @@
 """Decoder dispatch (r433_batch_dispatch / _mt) against the reference's rules (src/r_api.c:438-550,
 src/pulse_slicer.c:26-66): packages in detection order, priority levels ascending and only while no
 earlier level produced an event, devices in registration order inside a level, bitbuffers in pulse
-order, reference-layout bitbuffer_t contents, statistics, invalid return codes are fatal.  Runs on the
-emulator build of the library (the dispatch code is plain host C++, identical in the product)."""
+order, reference-layout bitbuffer_t contents, statistics, invalid return codes are fatal.  Every test runs twice:
+on the emulator build of the library (CPU suite) and, under -m gpu, on the product library
+(rtl_433_amd/lib/librtl433hip.so: another compiler, a version script -- and r433_batch_run_host in front)."""
 import ctypes as C
 
 import numpy as np
@@ -13,7 +14,13 @@ from rtl_433_amd import _lib, synth
 from rtl_433_amd.engine import BatchEngine, flow_cfg, make_rdevices
 from tests.emu import build_emu
 
-pytestmark = pytest.mark.skipif(not build_emu.available(), reason="wave emulator needs x86-64")
+BACKENDS = [pytest.param("emu", marks=pytest.mark.skipif(not build_emu.available(), reason="wave emulator needs x86-64")),
+            pytest.param("gpu", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=BACKENDS)
+def backend(request):
+    return request.param
 
 
 class BitBuffer(C.Structure):  # bitbuffer_t, reference include/bitbuffer.h:34-40
@@ -21,7 +28,11 @@ class BitBuffer(C.Structure):  # bitbuffer_t, reference include/bitbuffer.h:34-4
                 ("syncs_before_row", C.c_uint16 * 50), ("bb", (C.c_uint8 * 128) * 50)]
 
 
-def _setup(devs, iqs, **cfg_kw):
+def _setup(devs, iqs, backend="emu", **cfg_kw):
+    if backend == "gpu":  # the product library, fed from host memory like a C host would
+        eng = BatchEngine(flow_cfg(2, 250000, **cfg_kw), devs)
+        eng.run_host(iqs)
+        return eng, iqs
     from tests.emu import host
     lib = host.emu_lib()
     n = len(iqs)
@@ -70,10 +81,10 @@ def _expected_order(ev_blob, n_pkgs, prios, hit_dev):
 
 @pytest.mark.parametrize("threads", [1, 3])
 @pytest.mark.parametrize("hit_dev", [0, 3, None])
-def test_dispatch_order_priority_and_contents(threads, hit_dev):
+def test_dispatch_order_priority_and_contents(threads, hit_dev, backend):
     devs = _devices()
     iqs = [synth.ook_stream(900 + k, 30000)[0] for k in range(5)]
-    eng, keep = _setup(devs, iqs)
+    eng, keep = _setup(devs, iqs, backend)
     ev_blob, _ = eng.events()
     pk_blob, n_pkgs = eng.packages()
     by_key = {(e["pkg"], e["dev"], e["ordinal"]): e for e in po.parse_events(ev_blob)}
@@ -119,9 +130,9 @@ def test_dispatch_order_priority_and_contents(threads, hit_dev):
     eng.close()
 
 
-def test_invalid_decoder_return_is_fatal():
+def test_invalid_decoder_return_is_fatal(backend):
     devs = _devices()[:1]
-    eng, keep = _setup(devs, [synth.ook_stream(901, 30000)[0]])
+    eng, keep = _setup(devs, [synth.ook_stream(901, 30000)[0]], backend)
 
     @_lib.DECODE_FN
     def decode(rdev, bits_p):
@@ -133,13 +144,14 @@ def test_invalid_decoder_return_is_fatal():
     eng.close()
 
 
-def test_package_callback_levels():
+def test_package_callback_levels(backend):
     """pkg_cb receives a reference-layout pulse_data_t with calc_rssi_snr applied (src/r_flow.c:35-64)."""
     devs = _devices()[:1]
-    iq = np.fromfile("tests/golden/nice_250k.cu8", dtype=np.uint8)
+    import os
+    iq = np.fromfile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nice_250k.cu8"), dtype=np.uint8)
     # `rtl_433 -R 169` registers no FSK decoder, so FM demodulation is off and the detector reads the raw
     # envelope where it expects FM samples (include/r_private.h:32-36): the CLI's freq 433.955 comes from that
-    eng, keep = _setup(devs, [iq], enable_fm=0)
+    eng, keep = _setup(devs, [iq], backend, enable_fm=0)
     seen = []
 
     class PulseData(C.Structure):  # pulse_data_t, include/pulse_data.h:30-50
@@ -160,4 +172,99 @@ def test_package_callback_levels():
     eng.dispatch(rdevs, pkg_cb=on_pkg)
     # the reference CLI on this capture: rssi -2.312 snr 39.833 noise -42.144 freq 433.955 (tests/golden/kat.json)
     assert seen == [(0, 1, 53, 131, 123, -2.312, 39.833, -42.144, 433.955)]
+    eng.close()
+
+
+def test_dispatch_hooks(backend):
+    """r433_batch_dispatch_hooks: package_begin / event_done / package_end around the decoders, in reference order,
+    with the r_device counters already moved when event_done fires (account_event, src/pulse_slicer.c:35-47)."""
+    devs = _devices()
+    iqs = [synth.ook_stream(900 + k, 30000)[0] for k in range(4)]
+    eng, keep = _setup(devs, iqs, backend)
+    ev_blob, _ = eng.events()
+    pk_blob, n_pkgs = eng.packages()
+    pkgs = po.parse_packages(pk_blob)
+    L = eng.L
+    trace = []
+    hit_dev = 3
+
+    @_lib.DECODE_FN
+    def decode(rdev, bits_p):
+        info = _lib.DispatchInfo()
+        L.r433_dispatch_current(C.byref(info))
+        trace.append(("call", info.package, info.device, info.ordinal))
+        return 2 if info.device == hit_dev else -3
+
+    @_lib.HOOK_BEGIN_FN
+    def begin(user, rec, pd):
+        r, p = rec.contents, pd.contents
+        trace.append(("begin", r.stream, r.type, r.num_pulses, r.frame, p.num_pulses, p.pulse[0], p.gap[0], p.start_ago))
+
+    @_lib.HOOK_EVENT_FN
+    def event(user, rdev, ret, bits_p):
+        trace.append(("event", ret, rdev.contents.decode_events))
+
+    @_lib.HOOK_END_FN
+    def end(user, rec, p_events):
+        trace.append(("end", rec.contents.stream, p_events))
+
+    rdevs, objs = make_rdevices(devs, C.cast(decode, C.c_void_p).value, None)
+    hooks = _lib.DispatchHooks(None, begin, event, end)
+    n_ok = eng.dispatch_hooks(rdevs, hooks)
+    prios = [int(d["priority"]) for d in devs]
+    want_calls = _expected_order(ev_blob, n_pkgs, prios, hit_dev)
+    assert [t[1:] for t in trace if t[0] == "call"] == want_calls
+    assert n_ok == 2 * sum(1 for c in want_calls if c[1] == hit_dev)
+    # shape of the trace: begin, (call, event)*, end per package
+    at = 0
+    seen_events = [0] * len(devs)
+    for k, p in enumerate(pkgs):
+        assert trace[at] == ("begin", p["stream"], p["type"], p["num"], p["frame"], p["num"], int(p["pulse"][0]),
+                             int(p["gap"][0]), p["start_ago"])
+        at += 1
+        p_events = 0
+        for c in (c for c in want_calls if c[0] == k):
+            assert trace[at] == ("call",) + c
+            seen_events[c[1]] += 1
+            ret = 2 if c[1] == hit_dev else 0  # failures come back as 0 to the hook, like account_event returns them
+            assert trace[at + 1] == ("event", ret, seen_events[c[1]])
+            p_events += ret
+            at += 2
+        assert trace[at] == ("end", p["stream"], p_events)
+        at += 1
+    assert at == len(trace)
+    assert list(eng.decoded()) == [t[2] for t in trace if t[0] == "end"]
+    assert objs[hit_dev].decode_messages == n_ok and objs[0].decode_fails[3] == seen_events[0]
+    eng.close()
+
+
+def test_run_host_equals_run(backend):
+    """r433_batch_run_host (captures in host memory, ragged, not contiguous) == r433_batch_run on the staged layout."""
+    devs = _devices()
+    iqs = [synth.ook_stream(910 + k, 20000 + 3001 * k)[0] for k in range(5)] + [np.zeros(0, dtype=np.uint8)]
+    if backend == "gpu":
+        import torch
+        eng = BatchEngine(flow_cfg(2, 250000), devs)
+        n0 = eng.run_host(iqs)
+        got = (eng.packages(), eng.events())
+        lens = np.array([a.nbytes for a in iqs], dtype=np.uint32)
+        stride = int((lens.max() + 15) // 16 * 16)
+        host = np.zeros((len(iqs), stride), dtype=np.uint8)
+        for i, a in enumerate(iqs):
+            host[i, :a.nbytes] = a
+        n1 = eng.run(torch.from_numpy(host).cuda(), lens)
+        assert n0 == n1 and got == (eng.packages(), eng.events())
+        # contiguous and equally long: the single-copy path
+        same = np.ascontiguousarray(np.stack([synth.ook_stream(920 + k, 8192)[0] for k in range(4)]))
+        n2 = eng.run_host([same[k] for k in range(4)])
+        got2 = (eng.packages(), eng.events())
+        assert n2 == eng.run(torch.from_numpy(same).cuda()) and got2 == (eng.packages(), eng.events())
+    else:
+        from tests.emu import host as emu_host
+        eng = BatchEngine(flow_cfg(2, 250000), devs, library=emu_host.emu_lib())
+        n0 = eng.run_host(iqs)
+        got = (eng.packages(), eng.events())
+        eng2, keep = _setup(devs, iqs[:5] + [np.zeros(0, dtype=np.uint8)], "emu")
+        assert got == (eng2.packages(), eng2.events())
+        eng2.close()
     eng.close()

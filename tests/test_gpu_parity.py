@@ -177,7 +177,7 @@ def test_mixed_2000k_autolevel_filter(default_devices):
 
 
 @pytest.mark.parametrize("blind", [False, True])
-def test_split_captures(blind, default_devices, monkeypatch):
+def test_split_captures(blind, default_devices):
     """Several wavefronts per capture (r433_batch_set_split): byte-identical to the oracle whatever the cuts."""
     import torch
     from rtl_433_amd.engine import BatchEngine, flow_cfg
@@ -185,8 +185,6 @@ def test_split_captures(blind, default_devices, monkeypatch):
     from rtl_433_amd import synth
     devs = default_devices[0]
     caps = [long_capture(11, n_bursts=20), long_capture(12, sigma=1.0), long_capture(13, sigma=0.0), synth.noise_cu8(15, 400000, 3.0)]
-    if blind:
-        monkeypatch.setenv("R433_SPLIT_BLIND", "1")
     lens = np.array([a.nbytes for a in caps], dtype=np.uint32)
     stride = int((lens.max() + 15) // 16 * 16)
     host = np.zeros((len(caps), stride), dtype=np.uint8)
@@ -194,6 +192,7 @@ def test_split_captures(blind, default_devices, monkeypatch):
         host[i, :a.nbytes] = a
     eng = BatchEngine(flow_cfg(2, 250000), devs)
     eng.set_split(16384)
+    eng.set_debug(1 if blind else 0)  # R433_DEBUG_SPLIT_BLIND
     eng.run(torch.from_numpy(host).cuda(), lens)
     st = eng.split_stats()
     pk, ev = eng.packages()[0], eng.events()[0]
@@ -210,16 +209,12 @@ def test_split_captures(blind, default_devices, monkeypatch):
 
 
 @pytest.mark.parametrize("seed", [3, 19, 42, 77, 104, 1189, 5003, 5011])
-def test_fuzz_cases_on_gpu(seed, monkeypatch):
+def test_fuzz_cases_on_gpu(seed):
     """The seeded fuzz slice of tests/test_fuzz_emu.py through the product library (tools/fuzz_emu.py --gpu)."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_emu
-    monkeypatch.delenv("R433_SPLIT_BLIND", raising=False)
-    try:
-        assert fuzz_emu.one_case(seed, fuzz_emu.gpu_run) is None
-    finally:
-        os.environ.pop("R433_SPLIT_BLIND", None)
+    assert fuzz_emu.one_case(seed, fuzz_emu.gpu_run) is None
 
 
 def test_input_formats_cs8_cf32(default_devices):
@@ -258,3 +253,30 @@ def test_input_formats_cs8_cf32(default_devices):
     want16 = _cf32_to_cs16_like_c(f)
     o = po.oracle_flow(want16, devs, po.default_flow_cfg(4, 1024000, fpdm=1))
     assert run([f.view(np.uint8)], 4, 1024000, fpdm=1, center_frequency=868000000, input_format=2) == (o["packages"], o["events"])
+
+
+def test_full_size_config2_vs_reference(default_devices):
+    """BASELINE configs[1] at full size -- 1024 captures x 65536 samples, the 335 default decoders -- against the
+    UNMODIFIED reference (oracle/_ref/libr433ref.so, which travels with the repo): every package record (levels,
+    start_ago / end_ago, offsets, all pulse / gap widths) and every bitbuffer handed to a decoder, byte for byte."""
+    if not po.have_ref():
+        pytest.skip("oracle/_ref/libr433ref.so not present")
+    from rtl_433_amd import synth
+    devs = default_devices[0]
+    batch = synth.ook_batch(1024)
+    g = _gpu_run([batch[s] for s in range(1024)], 2, 250000, 433920000, devs)
+    ref = po.Ref(record=True)
+    rdevs, _, _ = ref.devices()
+    assert rdevs.tobytes() == np.ascontiguousarray(devs).tobytes()
+    for s in range(1024):
+        ref.run(batch[s], 2, 250000, 433920000, fpdm=2, stream_index=s)
+    pk_ref, n_ref = ref.packages()
+    ev_ref, nev_ref = ref.events()
+    ref.close()
+    pk, npk = g["packages"]
+    ev, nev = g["events"]
+    assert npk == n_ref and npk >= 1024
+    assert po.strip_ret_pos(pk) == pk_ref
+    assert nev == nev_ref and nev > 1000000
+    # the reference calls its decoders priority level by priority level; the records are (package, device, ordinal)
+    assert po.events_normalize(ev) == po.events_normalize(po.canonical_events(ev_ref))

@@ -234,3 +234,25 @@ def test_vcd_writer_matches_reference_file_emulator():
     got = (hb.raw[:n].decode() + "".join(out)).splitlines()
     assert got[0] == "$date D $end" and want[0].startswith("$date ")
     assert got[1:] == want[1:]
+
+
+def test_rfraw_full_package_takes_nothing_more_emulator():
+    """A line that fills a package (0xB0 repeat count) and then carries further segments: the reference keeps storing
+    past pulse[1200] (src/rfraw.c:141-163); this reader takes untrusted text and must stop at a full package."""
+    L = _text_lib()
+    # AA B0 len bins=2 repeats=FF, two bins (100 us, 200 us), 30 pulse/gap nibbles "8 1" (-> 15 pairs... x repeats), 55
+    seg = "AAB0" + "10" + "02" + "FF" + "0064" + "00C8" + "81" * 30 + "55"
+    tail = "+AAB1" + "02" + "0064" + "00C8" + "81" * 60 + "55"
+    text = (seg + tail * 6 + "\n").encode()
+    assert len(text) < 1023
+    arr = (_lib.PulseData * 3)()
+    n = L.r433_pulse_text_load(text, len(text), 250000, C.cast(arr, C.c_void_p), 3)
+    assert n >= 1
+    p = arr[0]
+    assert p.num_pulses <= 1200
+    assert p.num_pulses >= 1170  # the repeats filled it
+    # nothing spilled into the estimates behind gap[] or into the next element
+    assert p.ook_low_estimate == 0 and p.ook_high_estimate == 0 and p.fsk_f1_est == 0 and p.fsk_f2_est == 0
+    if n == 1:  # the slot of the (empty) next package is cleared and carries the rate, nothing else
+        nxt = arr[1]
+        assert nxt.num_pulses == 0 and nxt.pulse[0] == 0 and nxt.gap[0] == 0 and nxt.offset == 0 and nxt.ook_low_estimate == 0

@@ -1,5 +1,5 @@
 """Split captures (r433_batch_set_split): several wavefronts per long capture, speculative cuts verified at
-the stitch.  Whatever the cut positions -- chosen where the signal looks idle, or blindly (R433_SPLIT_BLIND,
+the stitch.  Whatever the cut positions -- chosen where the signal looks idle, or blindly (R433_DEBUG_SPLIT_BLIND,
 most cuts then fail and are dropped) -- the result must be byte-identical to the unsplit run and the oracle."""
 import os
 
@@ -36,16 +36,14 @@ def _oracle(caps, devs, cfg):
 
 @pytest.mark.parametrize("blind", [False, True])
 @pytest.mark.parametrize("split", [8192, 40000])
-def test_split_cu8(split, blind, default_devices, monkeypatch):
+def test_split_cu8(split, blind, default_devices):
     from tests.emu import host
     devs = default_devices[0][:40]
     caps = [long_capture(1), long_capture(2, sigma=1.0), long_capture(3, sigma=0.0), synth.noise_cu8(5, 150000, 3.0),
             synth.ook_stream(7, 40000)[0]]
-    if blind:
-        monkeypatch.setenv("R433_SPLIT_BLIND", "1")
     cfg = po.default_flow_cfg(2, 250000)
     pk, ev, base = _oracle(caps, devs, cfg)
-    g = host.emu_run(caps, 2, 250000, devs, split=split, taps=True)
+    g = host.emu_run(caps, 2, 250000, devs, split=split, taps=True, debug=1 if blind else 0)
     assert g["split"]["segments"] > len(caps), "nothing was split"
     assert g["packages"][0] == pk and g["events"][0] == ev
     o0 = po.oracle_flow(caps[0], None, cfg, taps=True)

@@ -138,11 +138,8 @@ def one_case(seed, run=None):
         caps = [long_ook(rng, rate)] + caps[:1]
         split = int(rng.choice([1, 1, 65536, 200000]))  # 1 = R433_SPLIT_AUTO
         kw.pop("frame_samples", None) if kw.get("frame_samples", 65536) < 2048 else None
-    if split and rng.random() < 0.5:
-        os.environ["R433_SPLIT_BLIND"] = "1"
-    else:
-        os.environ.pop("R433_SPLIT_BLIND", None)
-    g = run(caps, ss, rate, devs, fpdm=fpdm, taps=True, enable_fm=enable_fm, split=split, **kw)
+    blind = 1 if split and rng.random() < 0.5 else 0  # R433_DEBUG_SPLIT_BLIND
+    g = run(caps, ss, rate, devs, fpdm=fpdm, taps=True, enable_fm=enable_fm, split=split, debug=blind, **kw)
     cfg = po.default_flow_cfg(ss, rate, fpdm=fpdm, enable_fm=enable_fm, **kw)
     pk, ev, base = b"", b"", 0
     for s, a in enumerate(caps):
@@ -161,7 +158,7 @@ def one_case(seed, run=None):
     return None
 
 
-def gpu_run(caps, ss, rate, devs, fpdm=0, taps=False, enable_fm=1, split=0, **kw):
+def gpu_run(caps, ss, rate, devs, fpdm=0, taps=False, enable_fm=1, split=0, debug=0, **kw):
     """The same contract on the MI355X through the product library."""
     import torch
     from rtl_433_amd.engine import BatchEngine, flow_cfg
@@ -173,6 +170,7 @@ def gpu_run(caps, ss, rate, devs, fpdm=0, taps=False, enable_fm=1, split=0, **kw
         hostbuf[i, :a.nbytes] = a.view(np.uint8)
     eng = BatchEngine(flow_cfg(ss, rate, fpdm=fpdm, enable_fm=enable_fm, **kw), devs)
     eng.set_split(split)
+    eng.set_debug(debug)
     if taps:
         eng.enable_taps(n, max(1, stride // ss))
     npk = eng.run(torch.from_numpy(hostbuf).cuda(), lens)

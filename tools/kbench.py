@@ -1,6 +1,6 @@
 """Kernel-only timing of the detection kernel on the bench workload (HIP events inside the library).
     python tools/kbench.py [--streams N] [--samples M] [--reps R]
-Honors R433_DEBUG_FLAGS (phase-skip experiments)."""
+--debug FLAGS: R433_DEBUG_* of include/r433_hip.h (256 / 512 skip phases, 1024 per-phase shader clocks)."""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -13,6 +13,8 @@ ap.add_argument("--samples", type=int, default=65536)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--nodevs", action="store_true")
 ap.add_argument("--split", type=int, default=0)
+ap.add_argument("--debug", type=lambda x: int(x, 0), default=0)
+ap.add_argument("--sigma-only", action="store_true", help="only the captures with noise (sigma > 0): no closed-form silence")
 ap.add_argument("--fsk-cu8", action="store_true", help="250 kS/s cu8 FSK bursts at 433.92 MHz: the classic FSK detector")
 ap.add_argument("--analyze", action="store_true", help="also time the pulse analyzer (-A) over the packages of the run")
 ap.add_argument("--cs16", action="store_true", help="config 3 style: 1024 kS/s cs16 FSK Manchester bursts, minmax detector")
@@ -26,19 +28,30 @@ elif a.fsk_cu8:
     host = np.tile(host, ((a.streams + len(host) - 1) // len(host), 1))[: a.streams]
     cfg = flow_cfg(2, 250000, fpdm=0)
 else:
-    host = synth.ook_batch(a.streams, a.samples, 250000, seed0=0)
+    if a.sigma_only:  # the bench recipe draws sigma from {0, 1, 2}: keep the two thirds a real receiver could produce
+        rows, seed = [], 0
+        while len(rows) < a.streams:
+            iq, meta = synth.ook_stream(seed, a.samples, 250000)
+            if meta["sigma"] > 0:
+                rows.append(iq)
+            seed += 1
+        host = np.stack(rows)
+    else:
+        host = synth.ook_batch(a.streams, a.samples, 250000, seed0=0)
     cfg = flow_cfg(2, 250000)
 d = torch.from_numpy(host).cuda()
 devs = None if a.nodevs else load_device_table()[0]
 eng = BatchEngine(cfg, devs, profiling=True)
 if a.split:
     eng.set_split(a.split)
+if a.debug:
+    eng.set_debug(a.debug)
 ts = []
 for r in range(a.reps):
     n = eng.run(d)
     ts.append(eng.timing())
 best = min(ts, key=lambda t: t["detect_ms"])
-print(f"flags={os.environ.get('R433_DEBUG_FLAGS','0')} streams={a.streams} samples={a.samples} pkgs={n} " +
+print(f"flags={a.debug} streams={a.streams} samples={a.samples} pkgs={n} " +
       " ".join(f"{k}={v:.3f}" for k, v in best.items()) + (f" split={eng.split_stats()}" if a.split else ""))
 
 if a.analyze:
@@ -54,7 +67,7 @@ if a.analyze:
         hist[x.guess] = hist.get(x.guess, 0) + 1
     print(f"analyze: {len(res)} packages in {best * 1e3:.3f} ms (kernel + {len(res) * 1668 / 1e6:.1f} MB D2H + sync), guesses {dict(sorted(hist.items()))}")
 
-if int(os.environ.get("R433_DEBUG_FLAGS", "0"), 0) & 1024:
+if a.debug & 1024:
     import ctypes as C
     rec = 34 * 4  # sizeof(StreamState) upper bound; the real size comes back from the call
     buf = np.zeros(a.streams * 64, dtype=np.int32)
