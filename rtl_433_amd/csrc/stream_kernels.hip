@@ -33,6 +33,14 @@
 #include "dsp_device.hpp"
 #include "r433_internal.hpp"
 
+#ifdef R433_EMU_COUNTERS // development aid for the CPU emulator build only: how often each path of phase C runs
+extern "C" unsigned long long r433_dbg_counts[32];
+unsigned long long r433_dbg_counts[32];
+#define CNT(i, n) do { if (lane == 0) r433_dbg_counts[i] += (unsigned long long)(n); } while (0)
+#else
+#define CNT(i, n) do { } while (0)
+#endif
+
 namespace r433 {
 
 namespace {
@@ -182,6 +190,79 @@ __device__ __forceinline__ int div64(int v)
 __device__ __forceinline__ int div1024(int v)
 {
     return (v + ((v >> 31) & 1023)) >> 10;
+}
+
+// Eight steps of the two packed averages in their plain form, x += in - (x >> 6), inputs taken from lanes L .. L+7 of
+// `rot`.  On the GPU the v_readlane of step u + 2 is issued while step u computes: a value read from another lane into
+// an SGPR needs three instructions before a VALU instruction may use it, and left to itself the compiler fills that
+// gap with an s_nop per step (5 issue slots per sample); software-pipelined it is 4.
+template <int L> __device__ __forceinline__ void ema_group8(v2s &x, int rot)
+{
+#ifdef R433_EMU
+    for (int u = 0; u < 8; ++u) {
+        v2s const in = as_v2s(__builtin_amdgcn_readlane(rot, L + u));
+        x = x + (in - (x >> 6));
+    }
+#else
+    int xi, q, s0, s1;
+    __builtin_memcpy(&xi, &x, 4);
+    asm volatile("v_readlane_b32 %[s0], %[rot], %[l0]\n\t"
+                 "v_readlane_b32 %[s1], %[rot], %[l1]\n\t"
+                 "v_pk_ashrrev_i16 %[q], 6, %[x] op_sel_hi:[0,1]\n\t"
+                 "v_pk_sub_i16 %[x], %[x], %[q]\n\t"
+                 "v_pk_add_u16 %[x], %[x], %[s0]\n\t"
+                 "v_readlane_b32 %[s0], %[rot], %[l2]\n\t"
+                 "v_pk_ashrrev_i16 %[q], 6, %[x] op_sel_hi:[0,1]\n\t"
+                 "v_pk_sub_i16 %[x], %[x], %[q]\n\t"
+                 "v_pk_add_u16 %[x], %[x], %[s1]\n\t"
+                 "v_readlane_b32 %[s1], %[rot], %[l3]\n\t"
+                 "v_pk_ashrrev_i16 %[q], 6, %[x] op_sel_hi:[0,1]\n\t"
+                 "v_pk_sub_i16 %[x], %[x], %[q]\n\t"
+                 "v_pk_add_u16 %[x], %[x], %[s0]\n\t"
+                 "v_readlane_b32 %[s0], %[rot], %[l4]\n\t"
+                 "v_pk_ashrrev_i16 %[q], 6, %[x] op_sel_hi:[0,1]\n\t"
+                 "v_pk_sub_i16 %[x], %[x], %[q]\n\t"
+                 "v_pk_add_u16 %[x], %[x], %[s1]\n\t"
+                 "v_readlane_b32 %[s1], %[rot], %[l5]\n\t"
+                 "v_pk_ashrrev_i16 %[q], 6, %[x] op_sel_hi:[0,1]\n\t"
+                 "v_pk_sub_i16 %[x], %[x], %[q]\n\t"
+                 "v_pk_add_u16 %[x], %[x], %[s0]\n\t"
+                 "v_readlane_b32 %[s0], %[rot], %[l6]\n\t"
+                 "v_pk_ashrrev_i16 %[q], 6, %[x] op_sel_hi:[0,1]\n\t"
+                 "v_pk_sub_i16 %[x], %[x], %[q]\n\t"
+                 "v_pk_add_u16 %[x], %[x], %[s1]\n\t"
+                 "v_readlane_b32 %[s1], %[rot], %[l7]\n\t"
+                 "v_pk_ashrrev_i16 %[q], 6, %[x] op_sel_hi:[0,1]\n\t"
+                 "v_pk_sub_i16 %[x], %[x], %[q]\n\t"
+                 "v_pk_add_u16 %[x], %[x], %[s0]\n\t"
+                 "v_pk_ashrrev_i16 %[q], 6, %[x] op_sel_hi:[0,1]\n\t"
+                 "v_pk_sub_i16 %[x], %[x], %[q]\n\t"
+                 "v_pk_add_u16 %[x], %[x], %[s1]"
+                 : [x] "+v"(xi), [q] "=&v"(q), [s0] "=&s"(s0), [s1] "=&s"(s1)
+                 : [rot] "v"(rot), [l0] "n"(L), [l1] "n"(L + 1), [l2] "n"(L + 2), [l3] "n"(L + 3), [l4] "n"(L + 4),
+                   [l5] "n"(L + 5), [l6] "n"(L + 6), [l7] "n"(L + 7));
+    __builtin_memcpy(&x, &xi, 4);
+#endif
+}
+
+// up to eight such groups from lane 0 of `rot`
+__device__ __forceinline__ void ema_groups(v2s &x, int rot, int nb)
+{
+    ema_group8<0>(x, rot);
+    if (nb < 2) return;
+    ema_group8<8>(x, rot);
+    if (nb < 3) return;
+    ema_group8<16>(x, rot);
+    if (nb < 4) return;
+    ema_group8<24>(x, rot);
+    if (nb < 5) return;
+    ema_group8<32>(x, rot);
+    if (nb < 6) return;
+    ema_group8<40>(x, rot);
+    if (nb < 7) return;
+    ema_group8<48>(x, rot);
+    if (nb < 8) return;
+    ema_group8<56>(x, rot);
 }
 
 template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_wave(StreamParams p)
@@ -807,6 +888,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
         };
         pin_state();
         while (i < n_t) {
+            CNT(0, 1); // outer iterations
             long long const t_it = now();
             int const st_it = det.state;
             if (timing && lane == 0)
@@ -878,6 +960,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
             auto load_block = [&]() { // the 64 samples at `base`, one per lane, and what the fast paths want of them
                 if (loaded == base)
                     return;
+                CNT(1, 1); // block loads
                 int const il = base + lane;
                 am_l = il < n_t ? ld16(s_am, il) : 0;
                 fm_l = il < n_t ? ld16(s_fm, il) : 0;
@@ -896,11 +979,239 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
             // right there, without going round the outer loop.  Otherwise the general step takes over at k.
             int k = i;
             bool settled = false;
+            // ---- Inside a regular package: the train engine.  Between the second pulse of a package and its end the
+            // state machine does three things: wait for a falling edge while the level and carrier averages advance
+            // (pulse), count to ten (debounce), wait for a rising edge or the end-of-package count (gap).  With the
+            // FSK candidate out of the picture and nothing spurious pending, the legs of a block chain on a handful
+            // of scalars: the rising-edge mask of a block is one ballot per frozen level, the falling-edge candidates
+            // one ballot per pulse leg against the highest level the tile can produce, block changes reload two
+            // values per lane.  Anything irregular (first pulse, spurious pulse, package end, the 1200-pulse cap,
+            // levels outside int16) leaves the engine for the legs and the exact general step below.
+            bool const regular = det.state != ST_IDLE && det.ook_num >= 1 && det.fsk_num <= 16 && !det.eop_spurious
+                    && det.ook_num + 70 < R433_PD_MAX_PULSES && det.high >= 0 && det.high <= 32767 && cfg.min_high >= 0
+                    && cfg.min_high <= 32767;
+            bool engine_ran = false;
+            if (uni((int)regular) && !(p.flags & RUN_NO_TRAIN_ENGINE)) {
+                engine_ran = true;
+                // every loop condition below is a scalar: one value the compiler takes for per-lane (the detector's
+                // fields are, after the general step) would turn the whole loop into exec-masked vector code
+                int st = uni(det.state), run = uni(det.run), cur = uni(det.cur_pulse), mx = uni(det.max_pulse);
+                int n_pairs = uni((int)det.ook_num);
+                int const lim_u = uni(lim), n_tu = uni(n_t);
+                k = uni(k);
+                base = uni(base);
+                e = uni(e);
+                int const low = uni(det.low);
+                int const fl6 = uni(cfg.min_high >> 6);
+                int const amax_ub = __builtin_amdgcn_readlane(sfx_max, 0); // no filtered sample of this tile is larger
+                v2s hv = {(short)det.high, (short)det.ook_f1};
+                v2s const floor_v = {(short)cfg.min_high, (short)-32768};
+                v2s const m63 = {63, 63};
+                auto thr_of = [&](int level) -> int {
+                    int t = (int)(int16_t)((low + min(level, cfg.max_high)) / 2);
+                    if (cfg.fixed_high != 0)
+                        t = (int)(int16_t)cfg.fixed_high;
+                    return t;
+                };
+                int eop_lim = 10 * min(max(mx, cfg.per_ms), 10 * cfg.per_ms); // pulse_detect.c:446-450
+                int thi = 0;                   // rising-edge level of the frozen averages (debounce and gap)
+                unsigned long long m_hi = 0;   // lanes above it in this block
+                bool m_hi_ok = false;
+                unsigned long long vmask = e - base >= 64 ? ~0ull : ((1ull << (e - base)) - 1ull);
+                unsigned long long okp = __ballot(a64_l >= fl6 && f64_l >= 0);
+                unsigned long long okn = __ballot(a64_l >= fl6 && f64_l <= 0 && f64_l > -512);
+                bool need_general = false;
+                // The engine's window: 64 samples from k on, wherever k is (the legs below keep the blocks aligned; here a
+                // window that begins with a pulse lets the averages run from lane 0 without a rotation).
+                auto load_window = [&]() {
+                    CNT(14, 1); // engine window loads
+                    base = k;
+                    e = min(base + 64, lim_u);
+                    int const il = base + lane;
+                    am_l = il < n_tu ? ld16(s_am, il) : 0;
+                    fm_l = il < n_tu ? ld16(s_fm, il) : 0;
+                    a64_l = div64(am_l);
+                    f64_l = div64(fm_l);
+                    in_pk_l = (a64_l & 0xffff) | (f64_l << 16);
+                    in_pkn_l = (a64_l & 0xffff) | (-f64_l << 16);
+                    loaded = -1; // not a block as the legs below know them
+                    vmask = e - base >= 64 ? ~0ull : ((1ull << (e - base)) - 1ull);
+                    okp = __ballot(a64_l >= fl6 && f64_l >= 0);
+                    okn = __ballot(a64_l >= fl6 && f64_l <= 0 && f64_l > -512);
+                    m_hi_ok = false;
+                };
+                for (;;) {
+                    CNT(13, 1); // engine legs
+                    // a pulse that begins in the last third of a window gets a window of its own
+                    if (st == ST_PULSE && k - base > 40 && k < e && e < lim_u)
+                        load_window();
+                    if (st == ST_PULSE) {
+                        int const h0 = uni((int)hv[0]);
+                        int const thr_ub = thr_of(max(h0, amax_ub) + 1);
+                        int const tlo_ub = thr_ub - (int)(int16_t)(thr_ub / 8);
+                        unsigned long long cand = __ballot(am_l < tlo_ub) & vmask & (~0ull << (k - base));
+                        int const i0 = k;
+                        int j = k;
+                        bool fall = false;
+                        m_hi_ok = false;
+                        for (;;) {
+                            k = cand ? base + (__ffsll(cand) - 1) : e;
+                            int const kk = k;
+                            while (j < kk) { // the averages over [j, kk): see the pulse leg below for the three forms
+                                int const f1s = uni((int)hv[1]);
+                                bool const neg = f1s < 0;
+                                unsigned long long const bad = ~((neg ? okn : okp) >> (j - base));
+                                int const len = uni(f1s == -32768 ? 0 : min(kk - j, bad ? (int)__builtin_ctzll(bad) : 64));
+                                if (len >= 8) {
+                                    v2s const sv = {1, (short)(neg ? -1 : 1)};
+                                    int const sel = neg ? in_pkn_l : in_pk_l;
+                                    // windows begin where pulses begin: most runs start at lane 0 and need no rotation
+                                    int const rot = j == base ? sel : __builtin_amdgcn_ds_bpermute(((int)lane + (j - base)) << 2, sel);
+                                    int const nb = len >> 3;
+                                    v2s x = hv * sv;
+                                    ema_groups(x, rot, nb);
+                                    hv = x * sv;
+                                    j += nb * 8;
+                                    continue;
+                                }
+                                if (len > 0) {
+                                    v2s const sv = {1, (short)(neg ? -1 : 1)};
+                                    int const in_sel = neg ? in_pkn_l : in_pk_l;
+                                    v2s x = hv * sv;
+                                    for (int u = 0; u < len; ++u) {
+                                        v2s const in = as_v2s(__builtin_amdgcn_readlane(in_sel, j - base + u));
+                                        x = x + (in - (x >> 6));
+                                    }
+                                    hv = x * sv;
+                                    j += len;
+                                    continue;
+                                }
+                                int const cnt = uni(min(min(8, kk - j), f1s == -32768 ? 8 : (int)__builtin_ctzll(~bad | (1ull << 63))));
+                                for (int u = 0; u < cnt; ++u) {
+                                    v2s const in = as_v2s(__builtin_amdgcn_readlane(in_pk_l, j - base + u));
+                                    v2s const q = (hv + ((hv >> 15) & m63)) >> 6; // hv / 64, truncating toward zero
+                                    hv = pk_max(hv - q + in, floor_v);
+                                }
+                                j += cnt;
+                            }
+                            if (k >= e)
+                                break;
+                            // candidate: decide with the exact level.  Not an edge -> it is one more pulse sample.
+                            int const thr = thr_of(uni((int)hv[0]));
+                            int const am_k = __builtin_amdgcn_readlane(am_l, k - base);
+                            if (am_k < thr - (int)(int16_t)(thr / 8)) {
+                                fall = true;
+                                break;
+                            }
+                            v2s const in = as_v2s(__builtin_amdgcn_readlane(in_pk_l, k - base));
+                            v2s const q = (hv + ((hv >> 15) & m63)) >> 6;
+                            hv = pk_max(hv - q + in, floor_v);
+                            j = k + 1;
+                            cand &= cand - 1;
+                        }
+                        run += k - i0;
+                        if (fall) {
+                            if (run + 1 < 10) { // a spurious short pulse: the general step knows what that means
+                                need_general = true;
+                                break;
+                            }
+                            cur = run + 1; // pulse_detect.c:340-357: the width is known, the debounce begins
+                            mx = max(cur, mx);
+                            eop_lim = 10 * min(max(mx, cfg.per_ms), 10 * cfg.per_ms);
+                            run = 0;
+                            st = ST_GAP_START;
+                            k += 1;
+                        }
+                    }
+                    else {
+                        if (!m_hi_ok) {
+                            int const thr = thr_of(uni((int)hv[0]));
+                            thi = thr + (int)(int16_t)(thr / 8);
+                            m_hi = __ballot(am_l > thi) & vmask;
+                            m_hi_ok = true;
+                        }
+                        unsigned long long const m = m_hi & (~0ull << (k - base));
+                        int const ka = m ? base + (__ffsll(m) - 1) : e; // first sample above the level again
+                        if (st == ST_GAP_START) { // pulse_detect.c:376-421 without the FSK candidate
+                            int const kg = k + max(0, 9 - run); // sample at which the count reaches 10
+                            if (ka <= kg && ka < e) {
+                                run += (ka - k) + 1 + cur;
+                                st = ST_PULSE;
+                                k = ka + 1;
+                            }
+                            else if (kg < e) {
+                                run += (kg - k) + 1;
+                                st = ST_GAP;
+                                k = kg + 1;
+                            }
+                            else {
+                                run += e - k;
+                                k = e;
+                            }
+                        }
+                        else { // ST_GAP, pulse_detect.c:422-470
+                            int const togo = max(0, eop_lim - run);
+                            int const ke = togo < e - k ? k + togo : e; // first sample whose count ends the package
+                            if (ka <= ke && ka < e) {
+                                run += ka - k;
+                                det.cur_pulse = cur;
+                                ook_push_pair(det, run + 1); // the next pulse begins at ka: the pair is complete
+                                n_pairs += 1;
+                                cur = 0;
+                                run = 0;
+                                st = ST_PULSE;
+                                k = ka + 1;
+                            }
+                            else {
+                                run += ke - k;
+                                k = ke;
+                                if (ke < e) { // the package ends here: the general step emits it
+                                    need_general = true;
+                                    break;
+                                }
+                            }
+                        }
+                    }
+                    if (k < e)
+                        continue;
+                    // the block is used up
+                    if (k >= lim_u)
+                        break;
+                    if (st == ST_GAP) { // whole chunks without a sample above the level cannot end the gap
+                        if (!m_hi_ok) {
+                            int const thr = thr_of(uni((int)hv[0]));
+                            thi = thr + (int)(int16_t)(thr / 8);
+                        }
+                        unsigned long long const m = __ballot(lane >= (k >> 5) && my_cmax > thi);
+                        int const togo = max(0, eop_lim - run);
+                        int const je = togo < lim_u - k ? k + togo : lim_u;
+                        int const jump_to = min(min(m ? (__ffsll(m) - 1) * kChunk : n_tu, je), lim_u);
+                        if (jump_to > k) {
+                            run += jump_to - k;
+                            k = jump_to;
+                        }
+                        if (k >= lim_u)
+                            break;
+                    }
+                    if (n_pairs + 70 >= R433_PD_MAX_PULSES) // the 1200-pulse cap is the general step's business
+                        break;
+                    load_window();
+                }
+                det.state = st;
+                det.run = run;
+                det.cur_pulse = cur;
+                det.max_pulse = mx;
+                det.high = uni((int)hv[0]);
+                det.ook_f1 = uni((int)hv[1]);
+                settled = !need_general;
+            }
+            if (!engine_ran)
             for (;;) {
                 int const i0 = k;
                 bool const in_seg = base + lane >= i0 && base + lane < e;
                 int const st = det.state;
                 settled = false;
+                CNT(2 + (st & 3), 1); // legs by state
                 if (st == ST_IDLE) {
                     if (det.lead_in <= 1024) { // no pulse can start during the lead-in (pulse_detect.c:310)
                         k = min(e, i0 + (1025 - det.lead_in));
@@ -1007,11 +1318,13 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                             v2s const floor_v = {(short)cfg.min_high, (short)-32768};
                             v2s const m63 = {63, 63};
                             while (j < kk) {
+                                CNT(6, 1); // packed-loop iterations
                                 int const f1s = uni((int)hv[1]);
                                 bool const neg = f1s < 0;
                                 unsigned long long const bad = ~((neg ? okn : okp) >> (j - base));
                                 int const run = uni(f1s == -32768 ? 0 : min(kk - j, bad ? (int)__builtin_ctzll(bad) : 64));
                                 if (run >= 8) {
+                                    CNT(7, (run >> 3) * 8); // samples in unrolled groups
                                     v2s const sv = {1, (short)(neg ? -1 : 1)};
                                     int const rot = __builtin_amdgcn_ds_bpermute(((int)lane + (j - base)) << 2, neg ? in_pkn_l : in_pk_l);
                                     int const nb = run >> 3;
@@ -1031,6 +1344,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                                     continue;
                                 }
                                 if (run > 0) { // the tail of such a run: same plain form, lane numbers computed
+                                    CNT(8, run);
                                     v2s const sv = {1, (short)(neg ? -1 : 1)};
                                     int const in_sel = neg ? in_pkn_l : in_pk_l;
                                     v2s x = hv * sv;
@@ -1044,6 +1358,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                                 }
                                 // the samples the plain form must not take (and only those), at most 8 at a time
                                 int const cnt = uni(min(min(8, kk - j), f1s == -32768 ? 8 : (int)__builtin_ctzll(~bad | (1ull << 63))));
+                                CNT(9, cnt); // samples through the general 7-instruction form
                                 if (cnt == 8) {
     #pragma unroll
                                     for (int u = 0; u < 8; ++u) {
@@ -1197,6 +1512,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                             }
                         }
                         else {
+                            CNT(12, k - j); // samples through the scalar fallback
                             for (; j < k; ++j) {
                                 h += __builtin_amdgcn_readlane(a64_l, j - base) - div64(h);
                                 h = max(h, cfg.min_high);
@@ -1205,6 +1521,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                         }
                         if (k >= e)
                             break;
+                        CNT(10, 1); // candidates checked
                         // candidate: decide with the exact level.  Not an edge -> it is one more pulse sample.
                         int thr = (int)(int16_t)((det.low + min(h, cfg.max_high)) / 2);
                         if (cfg.fixed_high != 0)
@@ -1321,6 +1638,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                 int local_dc = dc + (k - i);
                 do {
                     int const am = __builtin_amdgcn_readlane(am_l, j - base), fm = __builtin_amdgcn_readlane(fm_l, j - base);
+                    CNT(11, 1); // general steps
                     int const r = det_step(det, cfg, am, fm, flen, local_dc, input_pos, frame);
                     if (r) { // package returned: the next call starts at the same sample, in the idle state
                         det_call_entry(det, cfg, flen, local_dc);

@@ -12,6 +12,7 @@ ap.add_argument("--streams", type=int, default=1024)
 ap.add_argument("--samples", type=int, default=65536)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--nodevs", action="store_true")
+ap.add_argument("--seed0", type=int, default=0)
 ap.add_argument("--split", type=int, default=0)
 ap.add_argument("--debug", type=lambda x: int(x, 0), default=0)
 ap.add_argument("--sigma-only", action="store_true", help="only the captures with noise (sigma > 0): no closed-form silence")
@@ -37,7 +38,7 @@ else:
             seed += 1
         host = np.stack(rows)
     else:
-        host = synth.ook_batch(a.streams, a.samples, 250000, seed0=0)
+        host = synth.ook_batch(a.streams, a.samples, 250000, seed0=a.seed0)
     cfg = flow_cfg(2, 250000)
 d = torch.from_numpy(host).cuda()
 devs = None if a.nodevs else load_device_table()[0]
