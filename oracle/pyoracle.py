@@ -282,6 +282,9 @@ class Ref:
         L.refh_digest2.argtypes = [C.c_void_p]
         L.refh_abi_sizes.argtypes = [C.c_void_p]
         L.refh_add_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.refh_plain_devices.restype = C.c_int
+        L.refh_plain_devices.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.refh_sink_count.restype = C.c_ulong
         if protocols is None:
             arr, n = None, 0
         else:
@@ -290,6 +293,17 @@ class Ref:
         flex_s = None if not flex else "\n".join(flex).encode()
         jp = None if not json_path else json_path.encode()
         self.h = L.refh_create(arr, n, flex_s, int(call_real), int(record), jp, report_meta, report_protocol)
+
+    def plain_devices(self):
+        """-> ctypes array of r_device* (as void*) with the reference's real decode_fn, in registration order."""
+        n = self.L.refh_num_devices(self.h)
+        arr = (C.c_void_p * n)()
+        got = self.L.refh_plain_devices(self.h, arr, n)
+        assert got == n
+        return arr
+
+    def sink_count(self):
+        return int(self.L.refh_sink_count())
 
     def add_rows(self, rows):
         """Register synthetic decoders (DEV_DTYPE timing rows, any modulation) after the devices registered so far."""

@@ -257,6 +257,39 @@ void refh_add_rows(void *hv, r433_dev_timing const *rows, int n_rows)
     wrap_devices(h->cfg);
 }
 
+/* The registered decoders with their REAL decode_fn, as plain r_device objects: what a host hands to a dispatcher that
+ * replays bitbuffers produced elsewhere (bench.py's "real decoders" leg hands them to r433_batch_dispatch).  Their
+ * output goes to a sink that counts and frees it.  Copies: the harness's own (recording) list is untouched. */
+static unsigned long g_sink_count;
+static void sink_output(r_device *decoder, data_t *data)
+{
+    (void)decoder;
+    data_free(data);
+    g_sink_count++;
+}
+
+int refh_plain_devices(void *hv, r_device **out, int cap)
+{
+    harness *h = hv;
+    int n = 0;
+    for (void **it = h->cfg->demod->r_devs.elems; it && *it && n < cap; ++it, ++n) {
+        wrapped_dev *w = (wrapped_dev *)*it;
+        r_device *p = malloc(sizeof(*p)); /* lives as long as the process: a handful of KB */
+        *p = w->dev;
+        p->decode_fn = w->real_decode;
+        p->output_fn = sink_output;
+        p->decode_events = p->decode_ok = p->decode_messages = 0;
+        memset(p->decode_fails, 0, sizeof(p->decode_fails));
+        out[n] = p;
+    }
+    return n;
+}
+
+unsigned long refh_sink_count(void)
+{
+    return g_sink_count;
+}
+
 /* ---- lifecycle ---- */
 
 static void quiet_log(log_level_t level, char const *src, char const *msg, void *userdata)

@@ -77,3 +77,29 @@ def merge_rank_records(per_rank):
         ev_all.append(rebase_events(ev, pkg_base))
         pkg_base += n_pkgs
     return b"".join(pk_all), b"".join(ev_all)
+
+
+# ---- the per-rank record that crosses the one collective of the path (bench.py, tests/test_dist_gloo.py) ----
+
+def pack_rank_record(first_stream: int, n_packages: int, n_events: int, digest: int, extra: int, packages: bytes = b"") -> bytes:
+    """What a rank sends to rank 0: where its shard starts in the capture list, how many packages / bitbuffers it
+    produced, the checksum of the bitbuffers, one caller-defined word, and (optionally) its package records."""
+    import struct
+    return struct.pack("<QQQQQ", first_stream, n_packages, n_events, digest & 0xFFFFFFFFFFFFFFFF, extra & 0xFFFFFFFFFFFFFFFF) + packages
+
+
+def unpack_rank_record(blob: bytes) -> dict:
+    import struct
+    f, npk, nev, dsum, x = struct.unpack_from("<QQQQQ", blob)
+    return dict(first=f, packages=npk, events=nev, digest=dsum, extra=x, pk=blob[40:])
+
+
+def gather_rank_records(payload: bytes, dist_on: bool, dst=0, device=None):
+    """All ranks call this with their packed record; rank `dst` gets the list of unpacked records in rank order (and
+    the package records merged into the canonical stream of the whole list under "merged"), the others None."""
+    got = gather_bytes(payload, dst=dst, device=device) if dist_on else [payload]
+    if got is None:
+        return None
+    per = [unpack_rank_record(b) for b in got]
+    merged, _ = merge_rank_records([(p["first"], p["packages"], p["pk"], b"") for p in per])
+    return dict(per_rank=per, merged=merged)

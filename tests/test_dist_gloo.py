@@ -86,3 +86,57 @@ def test_partition_is_contiguous_and_complete():
             b = shard.partition(n, w)
             assert b[0] == 0 and b[-1] == n and len(b) == w + 1
             assert all(0 <= b[i + 1] - b[i] <= (n + w - 1) // w for i in range(w))
+
+
+def _worker_bench_gather(rank, world, port, out_q):
+    """bench.py's collective, exactly: shard.pack_rank_record -> shard.gather_rank_records (config 2: real package
+    records travel; config 4: counts + checksums), two ranks over gloo, kernels on the emulator."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from oracle import pyoracle as po
+    from rtl_433_amd import shard, synth
+    from rtl_433_amd.engine import load_device_table
+    from tests.emu import host
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        devs = load_device_table()[0][:40]
+        n_list = 6
+        caps = [synth.ook_stream(500 + i, 8000 + 700 * i)[0] for i in range(n_list)]
+        b = shard.partition(n_list, world)
+        g = host.emu_run(caps[b[rank]:b[rank + 1]], 2, 250000, devs)
+        pk, npk = g["packages"]
+        ev, nev = g["events"]
+        dg = po.events_digest2(ev)[0]
+        got = shard.gather_rank_records(shard.pack_rank_record(b[rank], npk, nev, dg, len(pk), pk), True, dst=0)
+        if rank == 0:
+            cfg = po.default_flow_cfg(2, 250000)
+            pk_o, base = b"", 0
+            for s, a in enumerate(caps):
+                o = po.oracle_flow(a, devs, cfg, stream_index=s, pkg_base=base)
+                pk_o += o["packages"]
+                base += o["n_packages"]
+            per = got["per_rank"]
+            out_q.put((got["merged"] == pk_o, [p["first"] for p in per] == b[:-1], sum(p["packages"] for p in per) == base,
+                       all(p["extra"] == len(p["pk"]) for p in per)))
+        else:
+            assert got is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_bench_record_gather():
+    import torch.multiprocessing as mp
+    build_emu.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bench_gather, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(res), res
