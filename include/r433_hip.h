@@ -209,6 +209,31 @@ int r433_envelope_detect(void const *d_iq, void *d_env, uint32_t n, uint32_t *d_
 /* magnitude_est_cu8 (src/baseband.c:65-79) / magnitude_est_cs16 (:96-110) */
 int r433_magnitude_est_cu8(void const *d_iq, void *d_env, uint32_t n, uint32_t *d_sum, void *stream);
 int r433_magnitude_est_cs16(void const *d_iq, void *d_env, uint32_t n, uint32_t *d_sum, void *stream);
+/* The two low-passes of include/baseband.h on HOST buffers, one frame with the filter state in and out: what
+ * baseband_low_pass_filter (src/baseband.c:145-169), baseband_demod_FM (:210-272) and baseband_demod_FM_cs16 (:303-366) do
+ * for one call.  `carry` holds filter_state_t / demodfm_state_t in plain ints (am_y, am_x = y[-1], x[-1] of the AM filter;
+ * fm_y, fm_x = yf, xf; last_i, last_q = xr, xi) and is updated to the state after the frame's last sample.  The FM
+ * coefficients are the caller's (the reference keeps them in its state struct and recomputes them only when the rate
+ * changes): a16/b16 = alp_16[1] / blp_16[0], a32/b32 = alp_32[1] / blp_32[0].  Runs phases A and B of the detection
+ * kernel (chunk-parallel exact filters) on the frame; n_samples == 0 is a no-op like in the reference. */
+typedef struct r433_filter_carry {
+    int32_t am_y, am_x, fm_y, fm_x, last_i, last_q;
+} r433_filter_carry;
+#define R433_FILTER_AM 1u      /* h_in: u16 envelope  -> h_out: low-passed envelope (s16) */
+#define R433_FILTER_FM_CU8 2u  /* h_in: cu8 IQ        -> h_out: low-passed FM discriminator (s16) */
+#define R433_FILTER_FM_CS16 3u /* h_in: cs16 IQ       -> h_out: the same from 16-bit samples */
+int r433_filter_frame(uint32_t kind, void const *h_in, uint32_t n_samples, int16_t *h_out, r433_filter_carry *carry,
+        int32_t a16, int32_t b16, int64_t a32, int64_t b32);
+/* envelope_detect / magnitude_est_cu8 / magnitude_est_cs16 and the three evaluation variants the reference keeps next to
+ * them (envelope_detect_nolut, magnitude_true_cu8, magnitude_true_cs16, src/baseband.c:50-61,82-93,113-124) on HOST
+ * buffers; returns the wrapped u32 sum of the outputs through *sum (the reference derives its dB return value from it). */
+#define R433_ENV_AMP_CU8 0u
+#define R433_ENV_MAG_CU8 1u
+#define R433_ENV_MAG_CS16 2u
+#define R433_ENV_TRUE_CU8 3u
+#define R433_ENV_TRUE_CS16 4u
+int r433_envelope_host(uint32_t kind, void const *h_iq, uint16_t *h_env, uint32_t n_samples, uint32_t *sum);
+
 /* The file loop's input conversions (src/rtl_433.c:1811-1834) on device buffers: n = number of components
  * (2 per IQ sample).  cs8 -> cu8: +128.  cf32 -> cs16: (int)(f * 32767) clamped to +-32767, with C-on-x86
  * semantics for values no int can hold (they become -32767). */

@@ -122,7 +122,7 @@ EXPORTS = [
     "r433_batch_run_pulses", "r433_pulse_text_load", "r433_pulse_text_dump", "r433_batch_analyze", "r433_analysis_text",
     "r433_pulse_vcd_header", "r433_pulse_vcd", "r433_batch_grab_plan",
     "r433_sigmf_prefix", "r433_sigmf_trailer", "r433_sigmf_probe",
-    "r433_host_alloc", "r433_host_free", "r433_batch_run_host", "r433_batch_dispatch_hooks", "r433_batch_decoded",
+    "r433_filter_frame", "r433_envelope_host", "r433_host_alloc", "r433_host_free", "r433_batch_run_host", "r433_batch_dispatch_hooks", "r433_batch_decoded",
 ]
 
 
@@ -208,6 +208,10 @@ def bind(L):
     L.r433_sigmf_probe.argtypes = [vp, C.c_size_t, vp]
     L.r433_dump_convert.restype = C.c_int
     L.r433_dump_convert.argtypes = [C.c_int, C.c_uint32, vp, vp, C.c_uint64, vp]
+    L.r433_filter_frame.restype = C.c_int
+    L.r433_filter_frame.argtypes = [C.c_uint32, vp, C.c_uint32, vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int64]
+    L.r433_envelope_host.restype = C.c_int
+    L.r433_envelope_host.argtypes = [C.c_uint32, vp, vp, C.c_uint32, vp]
     L.r433_host_alloc.restype = vp
     L.r433_host_alloc.argtypes = [C.c_size_t]
     L.r433_host_free.restype = None

@@ -16,9 +16,10 @@ CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(HERE, "..", "include")
 OUT_DIR = os.path.join(HERE, "lib")
 OUT = os.path.join(OUT_DIR, "librtl433hip.so")
+SEAM_OUT = os.path.join(OUT_DIR, "librtl433seam.so")  # the reference's own function names over the C ABI (csrc/ref_seam.cpp)
 
 SOURCES = ["stream_kernels.hip", "slicer_kernels.hip", "baseband_kernels.hip", "analyzer_kernels.hip", "host_api.cpp", "batch_run.cpp",
-           "dispatch.cpp", "reports.cpp"]
+           "dispatch.cpp", "reports.cpp", "filter_frame.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function", "-x", "hip"]
 
@@ -31,9 +32,9 @@ def _hipcc():
 
 
 def _stale():
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not os.path.exists(SEAM_OUT):
         return True
-    t = os.path.getmtime(OUT)
+    t = min(os.path.getmtime(OUT), os.path.getmtime(SEAM_OUT))
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INC, f) for f in os.listdir(INC)]
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -62,7 +63,16 @@ def build(force=False, verbose=False):
     subprocess.check_call(cmd)
     for o in objs:
         os.remove(o)
+    build_seam(OUT_DIR, "rtl433hip", SEAM_OUT)
     return OUT
+
+
+def build_seam(lib_dir, lib_name, out):
+    """librtl433seam.so: plain host C++ (no device code), linked against the library whose C ABI it wraps."""
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-I", INC, os.path.join(CSRC, "ref_seam.cpp"), "-o", out,
+           "-L", lib_dir, "-l" + lib_name, "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link,/opt/rocm/lib", "-lm"]
+    subprocess.check_call(cmd)
+    return out
 
 
 if __name__ == "__main__":

@@ -20,13 +20,24 @@ template <int KIND> __device__ __forceinline__ uint32_t env_one(uint32_t pr)
         return env_amp_cu8(pr & 0xffu, (pr >> 8) & 0xffu);
     if (KIND == ENV_MAG_CU8)
         return env_mag_cu8(pr & 0xffu, (pr >> 8) & 0xffu);
+    if (KIND == ENV_TRUE_CU8) { // magnitude_true_cu8, src/baseband.c:82-93: (uint16_t)(sqrtf(x*x + y*y) * 128.0f), IEEE sqrt
+        int const x = (int)(pr & 0xffu) - 128, y = (int)((pr >> 8) & 0xffu) - 128;
+        return (uint32_t)(uint16_t)(int)__fmul_rn(__fsqrt_rn((float)(x * x + y * y)), 128.0f);
+    }
+    if (KIND == ENV_TRUE_CS16) { // magnitude_true_cs16, :113-124: (int)sqrtf((float)(x*x + y*y)) >> 1 with int32 x*x + y*y
+        int const x = (int)(int16_t)(pr & 0xffffu), y = (int)(int16_t)(pr >> 16);
+        int const ss = (int)((uint32_t)(x * x) + (uint32_t)(y * y)); // wraps like the C expression at (-32768, -32768)
+        float const r = __fsqrt_rn((float)ss);
+        int const ri = (r != r || r >= 2147483648.0f || r < -2147483648.0f) ? (int)0x80000000 : (int)r; // x86 cvttss2si
+        return (uint32_t)(uint16_t)(ri >> 1);
+    }
     return env_mag_cs16((int)(int16_t)(pr & 0xffffu), (int)(int16_t)(pr >> 16));
 }
 
 template <int KIND> __global__ __launch_bounds__(256) void k_envelope(uint8_t const *iq, uint16_t *env, uint32_t n,
         uint32_t *sum)
 {
-    constexpr int SS = KIND == ENV_MAG_CS16 ? 4 : 2;
+    constexpr int SS = (KIND == ENV_MAG_CS16 || KIND == ENV_TRUE_CS16) ? 4 : 2;
     constexpr int SPV = 16 / SS; // samples per 16-byte vector
     uint32_t const n_vec = n / SPV;
     uint32_t acc = 0;
@@ -349,7 +360,7 @@ void launch_frame_sums(int kind, void const *d_iq, uint64_t stride_bytes, uint32
 
 void launch_envelope(int kind, void const *d_iq, uint16_t *d_env, uint32_t n, uint32_t *d_sum, hipStream_t st)
 {
-    uint32_t spv = kind == ENV_MAG_CS16 ? 4 : 8;
+    uint32_t spv = (kind == ENV_MAG_CS16 || kind == ENV_TRUE_CS16) ? 4 : 8;
     uint32_t vecs = n / spv;
     uint32_t blocks = (vecs + 255) / 256;
     if (blocks < 1)
@@ -361,6 +372,10 @@ void launch_envelope(int kind, void const *d_iq, uint16_t *d_env, uint32_t n, ui
         hipLaunchKernelGGL(k_envelope<ENV_AMP_CU8>, dim3(blocks), dim3(256), 0, st, iq, d_env, n, d_sum);
     else if (kind == ENV_MAG_CU8)
         hipLaunchKernelGGL(k_envelope<ENV_MAG_CU8>, dim3(blocks), dim3(256), 0, st, iq, d_env, n, d_sum);
+    else if (kind == ENV_TRUE_CU8)
+        hipLaunchKernelGGL(k_envelope<ENV_TRUE_CU8>, dim3(blocks), dim3(256), 0, st, iq, d_env, n, d_sum);
+    else if (kind == ENV_TRUE_CS16)
+        hipLaunchKernelGGL(k_envelope<ENV_TRUE_CS16>, dim3(blocks), dim3(256), 0, st, iq, d_env, n, d_sum);
     else
         hipLaunchKernelGGL(k_envelope<ENV_MAG_CS16>, dim3(blocks), dim3(256), 0, st, iq, d_env, n, d_sum);
 }

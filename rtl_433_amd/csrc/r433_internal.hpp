@@ -60,6 +60,7 @@ enum : uint32_t {
 enum : uint32_t {
     RUN_CONTINUE = 1u, // resume from StreamState instead of a reset flow
     RUN_NOFLUSH = 2u,  // do not issue the end-of-input flush call
+    RUN_ENV_RAW16 = 4u, // filters-only launches: the input is a u16 envelope (2 B/sample), not IQ (baseband_low_pass_filter's x_buf)
     // profiling aids (env R433_DEBUG_FLAGS, never set by the product path): stop after a phase
     RUN_DBG_SKIP_DETECT = 256u,
     RUN_DBG_SKIP_FILTERS = 512u,
@@ -93,9 +94,15 @@ struct StreamParams {
     int16_t *tap_am;
     int16_t *tap_fm;
     uint64_t tap_stride;
+    // filters-only launches (launch_filters): the carries a frame starts from -- AM y[-1], x[-1]; FM y[-1], discriminator[-1];
+    // the last IQ sample, centred -- i.e. filter_state_t / demodfm_state_t of the reference (include/baseband.h:91-107).
+    // The carries after the frame's last sample come back in StreamState::lpf_y, lpf_x, fm_yf, fm_xf.
+    int const *seam_init;
 };
 
 void launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st);
+// phases A + B only, one frame, state in and out: the function-level seam of include/baseband.h
+void launch_filters(StreamParams const &p, uint32_t sample_size, hipStream_t st);
 
 // ---- slicer fan-out ----
 
@@ -148,7 +155,7 @@ void launch_slice_count(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st
 void launch_slice_write(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st);
 
 // ---- function-level baseband kernels (device pointers) ----
-enum { ENV_AMP_CU8 = 0, ENV_MAG_CU8 = 1, ENV_MAG_CS16 = 2 };
+enum { ENV_AMP_CU8 = 0, ENV_MAG_CU8 = 1, ENV_MAG_CS16 = 2, ENV_TRUE_CU8 = 3, ENV_TRUE_CS16 = 4 }; // == R433_ENV_* of r433_hip.h
 // input_format 1: cs8 -> cu8, 2: cf32 -> cs16; n_rows captures, row_in_bytes input bytes each
 void launch_analyze(uint8_t const *arena, uint32_t arena_stride, uint32_t const *dir_stream, uint32_t const *dir_off, uint32_t n_pkgs,
         r433_analysis *out, hipStream_t st);

@@ -265,7 +265,7 @@ __device__ __forceinline__ void ema_groups(v2s &x, int rot, int nb)
     ema_group8<56>(x, rot);
 }
 
-template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_wave(StreamParams p)
+template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_wave(StreamParams p)
 {
     using G = Geom<SS>;
     __shared__ __attribute__((aligned(16))) uint8_t s_env[64 * kPitch16];
@@ -318,6 +318,12 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
     int carry_ya = 0, carry_xa = 0; // AM low-pass: y[-1], x[-1]
     int carry_yf = 0, carry_ff = 0; // FM low-pass: y[-1], discriminator[-1]
     int carry_i = 0, carry_q = 0;   // last IQ sample, centred
+    if (SEAM && p.seam_init) { // a frame that continues a stream: filter_state_t / demodfm_state_t of the caller
+        carry_ya = p.seam_init[0], carry_xa = p.seam_init[1];
+        carry_yf = p.seam_init[2], carry_ff = p.seam_init[3];
+        carry_i = p.seam_init[4], carry_q = p.seam_init[5];
+    }
+    int seam_end[4] = {carry_ya, carry_xa, carry_yf, carry_ff}; // SEAM: the carries after the last sample
 
     // profiling aid (RUN_DBG_TIMING): shader-clock ticks per phase, returned in unused StreamState slots
     bool const timing = (p.flags & RUN_DBG_TIMING) != 0;
@@ -392,6 +398,8 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                 if (SS == 2) {
                     uint32_t bi = wd[j] & 0xffu, bq = (wd[j] >> 8) & 0xffu;
                     ev[j] = p.use_mag ? env_mag_cu8(bi, bq) : env_amp_cu8(bi, bq);
+                    if (SEAM && (p.flags & RUN_ENV_RAW16))
+                        ev[j] = wd[j]; // the caller's envelope as it is
                     ci = (int)bi - 128;
                     cq = (int)bq - 128;
                 }
@@ -491,6 +499,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
         sa.lo0 = sa.hi0 = sf.lo0 = sf.hi0 = 0;
         int csum = 0; // envelope sum of my chunk (frame average)
         int cmax = -0x7fffffff, cmin = 0x7fffffff;
+        int cap_ya = 0, cap_xa = 0, cap_yf = 0, cap_ff = 0; // SEAM: the state right after my chunk's last valid sample
 
         // one chunk of 32 steps for both filters; MAIN = my own chunk (publish, statistics)
         auto chunk_pass = [&](int c, auto main_tag) {
@@ -558,6 +567,13 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
                     else {
                         fm_out = (int)(int16_t)x; // buf.fm aliases the raw envelope (include/r_private.h:32-36)
                     }
+                    if (MAIN && SEAM) {
+                        bool const last = g * 8 + u == cnt - 1;
+                        cap_ya = last ? ta.lo : cap_ya;
+                        cap_xa = last ? x : cap_xa;
+                        cap_yf = last ? (SS == 2 ? tf16.lo : tf32.lo) : cap_yf;
+                        cap_ff = last ? ff1 : cap_ff;
+                    }
                     if (MAIN) {
                         sa.ident &= ((int)(ta.lo == alo) & (int)(ta.hi == ahi)) | (lv ^ 1);
                         sf.ident &= f_same | (lv ^ 1);
@@ -607,6 +623,7 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
         sa.ident &= ta.ok;
         sf.ident &= SS == 2 ? (tf16.ok & (int)(p.a16 >= 0 && p.a16 <= 16384)) : (tf32.ok & (int)(p.a32 >= 0 && p.a32 <= (1ll << 30)));
 
+        bool const seam_main_a = sa.start_known, seam_main_f = sf.start_known; // SEAM: my captures came from a proven carry
         // ---- resolve the lanes whose warm-up did not collapse, left to right ----
         // which: 0 = AM, 1 = FM.  Wave-uniform control flow; every round settles everything up to and
         // including the first lane of each run that needs an exact re-run (lanes 0..3 always start from
@@ -785,6 +802,15 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
             }
         }
 
+        if (SEAM) { // filters only: remember the carries after the frame's last sample (this tile may hold it)
+            int const L = (n_t - 1) >> 5;
+            int const ea = seam_main_a ? cap_ya : sa.y_end, ef = seam_main_f ? cap_yf : sf.y_end;
+            seam_end[0] = __builtin_amdgcn_readlane(ea, L);
+            seam_end[1] = __builtin_amdgcn_readlane(cap_xa, L);
+            seam_end[2] = __builtin_amdgcn_readlane(ef, L);
+            seam_end[3] = __builtin_amdgcn_readlane(cap_ff, L);
+            continue;
+        }
         tick(0, t_tile);
         // ================= phase C: pulse detector =================
         int i = (p.flags & RUN_DBG_SKIP_DETECT) ? n_t : 0;
@@ -1664,6 +1690,14 @@ template <int SS, bool FAST, bool FM> __global__ __launch_bounds__(64) __attribu
         tick(6, t_res); // the samples leave LDS with the tile
     }
 
+    if (SEAM) {
+        if (lane == 0) {
+            StreamState &S = p.state[s];
+            S.lpf_y = seam_end[0], S.lpf_x = seam_end[1], S.fm_yf = seam_end[2], S.fm_xf = seam_end[3];
+            S.overflow = det.overflow;
+        }
+        return;
+    }
     int const end_state = det.state, end_high = det.high; // before the flush: what the next segment has to agree with
     if (!(p.flags & RUN_NOFLUSH) && (seg_flags & SEG_LAST))
         det_flush(det, cfg, frame);
@@ -1803,6 +1837,33 @@ void launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st)
     else
         R433_LAUNCH_WAVE(4);
 #undef R433_LAUNCH_WAVE
+}
+
+void launch_filters(StreamParams const &p, uint32_t sample_size, hipStream_t st)
+{
+    if (p.n_streams == 0)
+        return;
+    dim3 grid(p.n_streams), block(64);
+    bool const fm = p.enable_fm != 0;
+    bool fast;
+    if (sample_size == 2)
+        fast = !fm || (p.a16 >= 0 && p.b16 >= 0 && p.a16 + 2 * p.b16 <= 16384);
+    else
+        fast = !fm || (p.a32 >= 0 && p.b32 >= 0 && p.a32 + 2 * p.b32 <= (1ll << 30));
+    if (sample_size == 2) {
+        if (!fm)
+            hipLaunchKernelGGL((k_wave<2, true, false, true>), grid, block, 0, st, p);
+        else if (fast)
+            hipLaunchKernelGGL((k_wave<2, true, true, true>), grid, block, 0, st, p);
+        else
+            hipLaunchKernelGGL((k_wave<2, false, true, true>), grid, block, 0, st, p);
+    }
+    else {
+        if (fast)
+            hipLaunchKernelGGL((k_wave<4, true, true, true>), grid, block, 0, st, p);
+        else
+            hipLaunchKernelGGL((k_wave<4, false, true, true>), grid, block, 0, st, p);
+    }
 }
 
 void launch_pkg_scan(StreamState const *state, uint32_t const *order, uint32_t n, uint32_t *pkg_base, uint32_t *scal,

@@ -17,6 +17,7 @@ CSRC = os.path.join(ROOT, "rtl_433_amd", "csrc")
 INC = os.path.join(ROOT, "include")
 OUT_DIR = os.path.join(HERE, "_build")
 OUT = os.path.join(OUT_DIR, "librtl433emu.so")
+SEAM_OUT = os.path.join(OUT_DIR, "librtl433seam.so")  # csrc/ref_seam.cpp over the emulator library
 FLAGS = ["-O2", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-strict-aliasing", "-Wall", "-Wno-unused-function",
          "-Wno-unknown-pragmas", "-Wno-unused-variable", "-Wno-sign-compare"]
 
@@ -31,9 +32,9 @@ def sources():
 
 
 def _stale():
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not os.path.exists(SEAM_OUT):
         return True
-    t = os.path.getmtime(OUT)
+    t = min(os.path.getmtime(OUT), os.path.getmtime(SEAM_OUT))
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INC, f) for f in os.listdir(INC)]
     deps += [os.path.join(HERE, "hip_emu_rt.cpp"), os.path.join(HERE, "selftest_kernels.hip"), os.path.join(HERE, "include", "hip", "hip_runtime.h")]
     return any(os.path.getmtime(d) > t for d in deps)
@@ -56,6 +57,8 @@ def build(force=False):
     subprocess.check_call(["g++", "-shared", "-o", OUT] + objs)
     for o in objs:
         os.remove(o)
+    from rtl_433_amd.build import build_seam
+    build_seam(OUT_DIR, "rtl433emu", SEAM_OUT)
     return OUT
 
 

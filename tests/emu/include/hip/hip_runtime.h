@@ -191,6 +191,7 @@ static inline float __fmul_rn(float a, float b) { volatile float r = a * b; retu
 static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
 static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
 static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
+static inline float __fsqrt_rn(float a) { volatile float r = __builtin_sqrtf(a); return r; }
 static inline double __dmul_rn(double a, double b) { volatile double r = a * b; return r; }
 static inline double __dadd_rn(double a, double b) { volatile double r = a + b; return r; }
 

@@ -23,6 +23,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref", "rtl_433_ref")
 EMU = os.path.join(ROOT, "dropin", "_build", "rtl_433_emu")
 HIP = os.path.join(ROOT, "dropin", "_build", "rtl_433_hip")
+# the same with src/baseband.c, src/pulse_detect*.c and src/pulse_slicer.c left out as well: librtl433seam.so stands in
+EMU_SEAM = os.path.join(ROOT, "dropin", "_build", "rtl_433_emu_seam")
+HIP_SEAM = os.path.join(ROOT, "dropin", "_build", "rtl_433_hip_seam")
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 FLEX = ["-X", "n=pwm,m=OOK_PWM,s=300,l=600,r=5000,g=2000,t=150",
@@ -39,11 +42,11 @@ def _ensure_built(binary):
         pytest.skip(f"{os.path.relpath(binary, ROOT)} not built and no reference tree to build it from")
     from oracle import pyoracle as po
     po.build_ref()
-    if binary == EMU:
+    if binary in (EMU, EMU_SEAM):
         from tests.emu import build_emu
         build_emu.build()
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "dropin"), "emu" if binary == EMU else "hip"],
-                          stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "dropin"), "emu" if binary in (EMU, EMU_SEAM) else "hip"]
+                          + (["SEAM=1"] if binary in (EMU_SEAM, HIP_SEAM) else []), stdout=subprocess.DEVNULL)
 
 
 def run_cli(binary, args, cwd, env=None):
@@ -182,3 +185,35 @@ def test_hip_config3(tmp_path):
 def test_hip_mixed_list(tmp_path):
     _ensure_built(HIP)
     check_mixed_list(HIP, tmp_path)
+
+
+def check_analyzer(binary, tmp_path):
+    """-A through the seam: the reference's pulse_analyzer runs its trial demodulation through pulse_slicer_pwm, which
+    here is librtl433seam.so's (GPU slicer + the reference's own decoder_log_bitbuffer for the printout)."""
+    shutil.copy(os.path.join(GOLD, "nice_250k.cu8"), tmp_path / "g001_433.92M_250k.cu8")
+    args = ["-r", "g001_433.92M_250k.cu8", "-A", "-R", "0"]
+
+    def run(b):
+        p = subprocess.run([b] + args, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0
+        return p.stdout.decode(), "\n".join(l for l in p.stderr.decode().splitlines() if "Detected OOK package" in l or "codes" in l
+                                            or "distribution" in l or "Guessing" in l or "Attempting" in l or "flex decoder" in l)
+    ref, got = run(REF), run(binary)
+    assert "{52}e7a760b94372e" in ref[0] + ref[1]
+    assert got == ref
+
+
+def test_emu_seam_variant(tmp_path):
+    _ensure_built(EMU_SEAM)
+    check_kat(EMU_SEAM, tmp_path)
+    check_batch(EMU_SEAM, tmp_path, range(3))
+    check_analyzer(EMU_SEAM, tmp_path)
+
+
+@pytest.mark.gpu
+def test_hip_seam_variant(tmp_path):
+    _ensure_built(HIP_SEAM)
+    check_kat(HIP_SEAM, tmp_path)
+    check_batch(HIP_SEAM, tmp_path, range(8))
+    check_analyzer(HIP_SEAM, tmp_path)
+    check_config3(HIP_SEAM, tmp_path)

@@ -1,0 +1,222 @@
+"""librtl433seam.so -- the reference's own function names over the GPU library (rtl_433_amd/csrc/ref_seam.cpp):
+
+  * the reference's tests/baseband-test.c, UNCHANGED, linked against it (dropin/Makefile `bbtest`) writes the same seven
+    files as the same test linked against the reference's src/baseband.c;
+  * every exported function against the function of the same name in the unmodified reference (oracle/_ref/libr433ref.so
+    exports them like any shared object): envelopes and levels, the two low-passes chained over frames of awkward lengths
+    with the filter state carried in the reference's own structs, the ten slicers + decoder call.
+
+CPU suite: the seam over the emulator library.  -m gpu: over the product library."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from rtl_433_amd import synth
+from tests.emu import build_emu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "dropin", "_build")
+BACKENDS = [pytest.param("emu", marks=pytest.mark.skipif(not build_emu.available(), reason="wave emulator needs x86-64")),
+            pytest.param("hip", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=BACKENDS)
+def backend(request):
+    return request.param
+
+
+class FilterState(C.Structure):  # filter_state_t, include/baseband.h:91-94
+    _fields_ = [("y", C.c_int16 * 1), ("x", C.c_int16 * 1)]
+
+
+class FmState(C.Structure):  # demodfm_state_t, include/baseband.h:97-107
+    _fields_ = [("xr", C.c_int32), ("xi", C.c_int32), ("xf", C.c_int32), ("yf", C.c_int32), ("rate", C.c_uint32),
+                ("alp_16", C.c_int32 * 2), ("blp_16", C.c_int32 * 2), ("alp_32", C.c_int64 * 2), ("blp_32", C.c_int64 * 2)]
+
+
+def seam_lib(backend):
+    if backend == "emu":
+        build_emu.build()
+        path = os.path.join(ROOT, "tests", "emu", "_build", "librtl433seam.so")
+    else:
+        path = os.path.join(ROOT, "rtl_433_amd", "lib", "librtl433seam.so")
+    assert os.path.exists(path), path
+    return proto(C.CDLL(path, mode=C.RTLD_GLOBAL))
+
+
+def proto(L):
+    vp = C.c_void_p
+    for f in ("envelope_detect", "envelope_detect_nolut", "magnitude_est_cu8", "magnitude_true_cu8", "magnitude_est_cs16", "magnitude_true_cs16"):
+        getattr(L, f).restype = C.c_float
+        getattr(L, f).argtypes = [vp, vp, C.c_uint32]
+    L.baseband_low_pass_filter.restype = None
+    L.baseband_low_pass_filter.argtypes = [C.POINTER(FilterState), vp, vp, C.c_uint32]
+    for f in ("baseband_demod_FM", "baseband_demod_FM_cs16"):
+        getattr(L, f).restype = None
+        getattr(L, f).argtypes = [C.POINTER(FmState), vp, vp, C.c_ulong, C.c_uint32, C.c_float]
+    return L
+
+
+def ref_lib():
+    if not po.have_ref():
+        pytest.skip("oracle/_ref/libr433ref.so not present")
+    L = proto(C.CDLL(po.REF_SO))
+    L.baseband_init()
+    return L
+
+
+def _ensure_bbtest(names):
+    if all(os.path.exists(os.path.join(BUILD, n)) for n in names):
+        return
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("baseband-test binaries not built and no reference tree to build them from")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "dropin"), "bbtest"], stdout=subprocess.DEVNULL)
+
+
+def test_reference_baseband_test_links_unchanged(backend, tmp_path):
+    names = ["bbtest_ref", f"bbtest_seam_{backend}"]
+    if backend == "emu":
+        build_emu.build()
+    _ensure_bbtest(names)
+    cap = np.concatenate([synth.ook_stream(3)[0], synth.fsk_stream_cu8(5, 50000), synth.random_cu8(7, 3001)])
+    cap.tofile(tmp_path / "in.cu8")
+    outs = {}
+    for n in names:
+        d = tmp_path / n
+        d.mkdir()
+        subprocess.run([os.path.join(BUILD, n), str(tmp_path / "in.cu8")], cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+        outs[n] = {f: (d / f).read_bytes() for f in sorted(os.listdir(d))}
+    a, b = outs[names[0]], outs[names[1]]
+    assert sorted(a) == sorted(b) == ["bb.am.s16", "bb.cs16", "bb.cs16.fm.s16", "bb.fm.s16", "bb.lp.am.s16", "bb.mag.lp.s16", "bb.mag.s16"]
+    for f in a:
+        assert a[f] == b[f], f
+
+
+@pytest.mark.parametrize("fn,cs16", [("envelope_detect", False), ("envelope_detect_nolut", False), ("magnitude_est_cu8", False),
+                                     ("magnitude_true_cu8", False), ("magnitude_est_cs16", True), ("magnitude_true_cs16", True)])
+def test_envelope_functions(fn, cs16, backend):
+    S, R = seam_lib(backend), ref_lib()
+    rng = np.random.default_rng(11)
+    for n in (1, 7, 8, 9, 4097, 131072):
+        if cs16:
+            iq = rng.integers(-32768, 32768, 2 * n).astype(np.int16)
+            iq[:4] = [-32768, -32768, 32767, -32768][: min(4, iq.size)]
+        else:
+            iq = rng.integers(0, 256, 2 * n).astype(np.uint8)
+            iq[:4] = [0, 0, 255, 0][: min(4, iq.size)]
+        ya, yb = np.zeros(n, dtype=np.uint16), np.zeros(n, dtype=np.uint16)
+        da = getattr(S, fn)(iq.ctypes.data, ya.ctypes.data, n)
+        db = getattr(R, fn)(iq.ctypes.data, yb.ctypes.data, n)
+        assert np.array_equal(ya, yb), (fn, n)
+        assert np.float32(da) == np.float32(db), (fn, n, da, db)
+
+
+LENGTHS = [1, 2, 31, 32, 33, 95, 96, 97, 2047, 2048, 2049, 4096, 5000, 131072, 13, 70001]
+
+
+def test_low_pass_filter_chained_frames(backend):
+    """baseband_low_pass_filter over frames of awkward lengths, the state carried in filter_state_t from call to call."""
+    S, R = seam_lib(backend), ref_lib()
+    rng = np.random.default_rng(12)
+    sa, sb = FilterState(), FilterState()
+    for k, n in enumerate(LENGTHS):
+        x = rng.integers(0, 32769, n).astype(np.uint16)
+        if k % 3 == 0:
+            x[:] = 32768 if k % 2 else 0  # stalls on a fixed point / the int16 x[-1] slot
+        if k % 4 == 1:
+            x[n // 2:] = 777  # constant tail: unproven tracks
+        ya, yb = np.zeros(n, dtype=np.int16), np.zeros(n, dtype=np.int16)
+        S.baseband_low_pass_filter(C.byref(sa), x.ctypes.data, ya.ctypes.data, n)
+        R.baseband_low_pass_filter(C.byref(sb), x.ctypes.data, yb.ctypes.data, n)
+        assert np.array_equal(ya, yb), (k, n)
+        assert (sa.y[0], sa.x[0]) == (sb.y[0], sb.x[0]), (k, n)
+
+
+@pytest.mark.parametrize("cs16,low_pass", [(False, 0.1), (False, 0.2), (False, 0.45), (True, 0.1), (True, 0.2)])
+def test_fm_demod_chained_frames(cs16, low_pass, backend):
+    S, R = seam_lib(backend), ref_lib()
+    rng = np.random.default_rng(13)
+    sa, sb = FmState(), FmState()
+    fn = "baseband_demod_FM_cs16" if cs16 else "baseband_demod_FM"
+    rate = 1024000 if cs16 else 250000
+    for k, n in enumerate(LENGTHS):
+        if cs16:
+            iq = synth.fsk_stream_cs16(20 + k, n, lead_in=min(n // 3, 500), gap=300, nbits=16) if n > 64 else rng.integers(-32768, 32768, 2 * n).astype(np.int16)
+            if k % 3 == 0:
+                iq[:] = 0
+        else:
+            iq = synth.fsk_stream_cu8(20 + k, n, lead_in=min(n // 3, 500), gap=300, nbits=16) if n > 64 else rng.integers(0, 256, 2 * n).astype(np.uint8)
+            if k % 3 == 0:
+                iq[:] = 128
+        iq = np.ascontiguousarray(iq)
+        ya, yb = np.zeros(n, dtype=np.int16), np.zeros(n, dtype=np.int16)
+        getattr(S, fn)(C.byref(sa), iq.ctypes.data, ya.ctypes.data, n, rate, low_pass)
+        getattr(R, fn)(C.byref(sb), iq.ctypes.data, yb.ctypes.data, n, rate, low_pass)
+        assert np.array_equal(ya, yb), (k, n)
+        assert bytes(sa) == bytes(sb), (k, n, [getattr(sa, f) for f in ("xr", "xi", "xf", "yf")], [getattr(sb, f) for f in ("xr", "xi", "xf", "yf")])
+
+
+SLICERS = [("pulse_slicer_pcm", 4), ("pulse_slicer_ppm", 5), ("pulse_slicer_pwm", 6), ("pulse_slicer_manchester_zerobit", 3),
+           ("pulse_slicer_dmc", 9), ("pulse_slicer_piwm_raw", 8), ("pulse_slicer_piwm_dc", 11), ("pulse_slicer_nrzs", 12),
+           ("pulse_slicer_osv1", 10), ("pulse_slicer_rzi", 13)]
+
+
+@pytest.mark.parametrize("fn,mod", SLICERS)
+def test_slicers_against_reference(fn, mod, backend):
+    """pulse_slicer_*(pulse_data_t const *, r_device *) of the seam and of the reference on the same packages and the same
+    r_device: identical bitbuffers reach decode_fn, identical return values and statistics."""
+    from rtl_433_amd import _lib
+    S, R = seam_lib(backend), ref_lib()
+    cfg = po.default_flow_cfg(2, 250000)
+    pkgs = []
+    for seed in (30, 31, 32, 33):
+        o = po.oracle_flow(synth.ook_stream(seed)[0], None, cfg)
+        pkgs += po.parse_packages(o["packages"])
+    assert len(pkgs) >= 4
+    seen = {"a": [], "b": []}
+
+    class BitBuffer(C.Structure):
+        _fields_ = [("num_rows", C.c_uint16), ("free_row", C.c_uint16), ("bits_per_row", C.c_uint16 * 50),
+                    ("syncs_before_row", C.c_uint16 * 50), ("bb", (C.c_uint8 * 128) * 50)]
+
+    def make_cb(key):
+        @_lib.DECODE_FN
+        def cb(rdev, bits_p):
+            bb = C.cast(bits_p, C.POINTER(BitBuffer)).contents
+            rows = [(bb.bits_per_row[r], bb.syncs_before_row[r], bytes(bb.bb[r])[: (bb.bits_per_row[r] + 7) // 8]) for r in range(min(bb.num_rows, 50))]
+            seen[key].append((bb.num_rows, bb.free_row, rows))
+            return 1 if len(seen[key]) % 3 == 0 else -1
+        return cb
+    cbs = {k: make_cb(k) for k in seen}
+    rets = {"a": [], "b": []}
+    devs = {}
+    for key, L in (("a", S), ("b", R)):
+        d = _lib.RDevice()
+        d.name = b"probe"
+        d.modulation = mod
+        d.short_width, d.long_width, d.reset_limit, d.gap_limit, d.sync_width, d.tolerance = 400.0, 800.0, 6000.0, 2000.0, 0.0, 150.0
+        d.decode_fn = C.cast(cbs[key], C.c_void_p)
+        devs[key] = d
+        f = getattr(L, fn)
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        for p in pkgs:
+            pd = _lib.PulseData()
+            pd.sample_rate = 250000
+            pd.num_pulses = p["num"]
+            for i in range(p["num"]):
+                pd.pulse[i] = int(p["pulse"][i])
+                pd.gap[i] = int(p["gap"][i])
+            pd.fsk_f2_est = 5  # an OOK-numbered slicer runs whatever the package's estimates say
+            rets[key].append(f(C.byref(pd), C.byref(d)))
+    assert seen["a"] == seen["b"]
+    assert rets["a"] == rets["b"]
+    for f in ("decode_events", "decode_ok", "decode_messages"):
+        assert getattr(devs["a"], f) == getattr(devs["b"], f)
+    assert list(devs["a"].decode_fails) == list(devs["b"].decode_fails)
+    if mod not in (10,):  # Oregon v1 needs its own preamble to say anything
+        assert len(seen["a"]) > 0
