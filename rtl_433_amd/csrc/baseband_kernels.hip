@@ -22,12 +22,12 @@ template <int KIND> __device__ __forceinline__ uint32_t env_one(uint32_t pr)
         return env_mag_cu8(pr & 0xffu, (pr >> 8) & 0xffu);
     if (KIND == ENV_TRUE_CU8) { // magnitude_true_cu8, src/baseband.c:82-93: (uint16_t)(sqrtf(x*x + y*y) * 128.0f), IEEE sqrt
         int const x = (int)(pr & 0xffu) - 128, y = (int)((pr >> 8) & 0xffu) - 128;
-        return (uint32_t)(uint16_t)(int)__fmul_rn(__fsqrt_rn((float)(x * x + y * y)), 128.0f);
+        return (uint32_t)(uint16_t)(int)__fmul_rn(sqrtf((float)(x * x + y * y)), 128.0f);
     }
     if (KIND == ENV_TRUE_CS16) { // magnitude_true_cs16, :113-124: (int)sqrtf((float)(x*x + y*y)) >> 1 with int32 x*x + y*y
         int const x = (int)(int16_t)(pr & 0xffffu), y = (int)(int16_t)(pr >> 16);
         int const ss = (int)((uint32_t)(x * x) + (uint32_t)(y * y)); // wraps like the C expression at (-32768, -32768)
-        float const r = __fsqrt_rn((float)ss);
+        float const r = sqrtf((float)ss); // IEEE: the build sets -fhip-fp32-correctly-rounded-divide-sqrt (__fsqrt_rn is the native approximation here)
         int const ri = (r != r || r >= 2147483648.0f || r < -2147483648.0f) ? (int)0x80000000 : (int)r; // x86 cvttss2si
         return (uint32_t)(uint16_t)(ri >> 1);
     }
