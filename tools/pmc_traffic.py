@@ -1,0 +1,74 @@
+"""HBM traffic of the dominant kernel per launch from rocprofv3 PMC passes, the way /opt/skills/guides/MI355X_MICROARCH.md
+(HBM section) prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (they do not fit one), counters only
+(--kernel-trace, no other tracing domain), FETCH_SIZE doubled on gfx950 (128-byte requests of wide coalesced streaming
+reads are tallied at 64 bytes), WRITE_SIZE as it is (uncalibrated).  Run on the GPU box:
+
+    python tools/pmc_traffic.py            -> gpurun_out/r02_pmc/traffic.json   (copy to profiles/r02_pmc_traffic.json)
+"""
+import json
+import os
+import sqlite3
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out", "r02_pmc")
+
+WORKLOADS = {
+    # key: (command, kernel name pattern, algorithmic bytes per launch, what a launch is)
+    "config2": ([sys.executable, os.path.join(ROOT, "tools", "kbench.py"), "--reps", "2"], "k_wave<2", 2 * 1024 * 65536,
+                "k_wave<2,true,true>, 1024 captures x 65536 cu8 samples (tools/kbench.py, all decoders), one launch"),
+    "config3": ([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "3", "--quick", "--steps", "2", "--warmup", "1"], "k_wave<4", 4 * (64 << 20),
+                "k_wave<4,true,true> over the verified segments of one 64 Mi-sample cs16 stream (bench.py --config 3): all its launches of one pass"),
+}
+
+
+def one_pass(tag, counter, cmd):
+    d = os.path.join(OUT, f"{tag}_{counter}")
+    os.makedirs(d, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "r", "--"] + cmd, cwd="/tmp", env=env,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, timeout=1200)
+    dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+    if not dbs:
+        return None
+    c = sqlite3.connect(dbs[0])
+    rows = c.execute("select name, dispatch_id, sum(counter_value) from pmc_events where counter_name = ? group by name, dispatch_id", (counter,)).fetchall()
+    for f in dbs:
+        if os.path.getsize(f) > (8 << 20):
+            os.remove(f)
+    return rows
+
+
+def main():
+    res = {}
+    for key, (cmd, pat, alg, what) in WORKLOADS.items():
+        got = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            rows = one_pass(key, counter, cmd)
+            if rows is None:
+                got = None
+                break
+            mine = [(n, d, v) for n, d, v in rows if pat in n]
+            got[counter] = mine
+        if not got:
+            continue
+        n_disp = len(got["FETCH_SIZE"])
+        if key == "config2":
+            per = n_disp  # every dispatch is one launch of the workload
+        else:
+            per = 3  # bench.py --config 3 --steps 2 --warmup 1: three passes over the stream
+        fetch_kb = sum(v for _, _, v in got["FETCH_SIZE"]) / per
+        write_kb = sum(v for _, _, v in got["WRITE_SIZE"]) / per
+        res[key] = dict(kernel=what, dispatches_seen=n_disp, launches_or_passes=per,
+                        FETCH_SIZE_kb_raw=round(fetch_kb, 1), WRITE_SIZE_kb_raw=round(write_kb, 1),
+                        correction="gfx950 FETCH_SIZE counts the 128-byte requests of 16-byte-per-lane coalesced streaming reads as 64 bytes "
+                                   "(MI355X_MICROARCH.md, HBM section): x2; WRITE_SIZE uncalibrated, taken as is; separate --pmc passes",
+                        hbm_bytes_per_launch=int(fetch_kb * 1024 * 2 + write_kb * 1024), algorithmic_bytes_per_launch=alg)
+        print(key, res[key])
+    os.makedirs(OUT, exist_ok=True)
+    json.dump(res, open(os.path.join(OUT, "traffic.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
