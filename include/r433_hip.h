@@ -111,6 +111,11 @@ int r433_batch_set_taps(r433_batch *b, void *d_env, void *d_am, void *d_fm, uint
  * counterpart: the reference walks a file sample by sample (src/rtl_433.c:1826-1845). */
 #define R433_SPLIT_AUTO 1u
 int r433_batch_set_split(r433_batch *b, uint32_t segment_samples);
+/* Several engines of one process, each on its own stream (a software pipeline over batches): with this set, their
+ * detection kernels take turns instead of sharing the compute units -- a launch fills every SIMD by itself, two of them
+ * side by side only stretch each other -- while everything after detection (slicers, record copies) still overlaps the
+ * next engine's detection.  Off by default: a lone engine has nobody to wait for. */
+int r433_batch_set_exclusive_detect(r433_batch *b, int on);
 /* of the last run: wavefront slots planned (segments incl. parity variants), pieces run again after a dropped cut */
 int r433_batch_split_stats(r433_batch *b, uint32_t *segments, uint32_t *pieces_rerun);
 

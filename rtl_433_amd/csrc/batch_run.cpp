@@ -4,6 +4,8 @@
 
 using namespace r433;
 
+std::mutex g_detect_turn;
+
 // ---- r433_batch_run, stage by stage --------------------------------------------------------------
 namespace {
 
@@ -448,6 +450,14 @@ int run_detect(RunCtx &r)
 {
     r433_batch *const b = r.b;
     int rc;
+    // the calling thread waits for the detection kernel below anyway (it needs the package count): holding the turn until
+    // then keeps two engines' detection kernels from running side by side
+    std::unique_lock<std::mutex> turn(g_detect_turn, std::defer_lock);
+    if (b->exclusive_detect) {
+        turn.lock();
+        if (b->profiling) // the time spent waiting for the turn is not the kernel's
+            HIP_TRY(hipEventRecord(b->ev[0], r.st));
+    }
     for (int attempt = 0;; ++attempt) {
         if ((rc = b->d_arena.ensure((size_t)r.n_slots * b->arena_stride)))
             return rc;

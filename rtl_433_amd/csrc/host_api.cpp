@@ -298,6 +298,14 @@ int r433_batch_set_split(r433_batch *b, uint32_t segment_samples)
     return 0;
 }
 
+int r433_batch_set_exclusive_detect(r433_batch *b, int on)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    b->exclusive_detect = on != 0;
+    return 0;
+}
+
 int r433_batch_set_debug(r433_batch *b, uint32_t flags)
 {
     if (!b)

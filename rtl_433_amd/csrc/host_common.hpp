@@ -194,6 +194,7 @@ struct r433_batch {
     // split captures (r433_batch_set_split)
     uint32_t split_samples = R433_SPLIT_AUTO;
     uint32_t debug_flags = 0; // r433_batch_set_debug
+    bool exclusive_detect = false; // r433_batch_set_exclusive_detect
     DevBuf<uint32_t> d_tile_max, d_order;
     DevBuf<SegDesc> d_segs;
     PinBuf<uint32_t> h_tile_max;
@@ -236,6 +237,8 @@ struct r433_batch {
     r433_pulse_data *pulses = nullptr;
     Pool pool;
 };
+
+extern std::mutex g_detect_turn; // engines with exclusive_detect take turns on the detection kernel (batch_run.cpp)
 
 inline hipError_t stream_wait(r433_batch *b, hipStream_t st)
 {

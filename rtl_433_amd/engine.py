@@ -120,6 +120,10 @@ class BatchEngine:
         """Cut captures longer than segment_samples into independently processed, verified segments."""
         _lib.check(self.L.r433_batch_set_split(self.h, int(segment_samples)), "r433_batch_set_split", self.L)
 
+    def set_exclusive_detect(self, on=True):
+        """Engines of a software pipeline take turns on the detection kernel (r433_batch_set_exclusive_detect)."""
+        _lib.check(self.L.r433_batch_set_exclusive_detect(self.h, int(on)), "r433_batch_set_exclusive_detect", self.L)
+
     def set_debug(self, flags):
         """Development switches (R433_DEBUG_* of include/r433_hip.h): 1 blind cuts, 2 two-pass slicer, 1024 phase timing."""
         _lib.check(self.L.r433_batch_set_debug(self.h, int(flags)), "r433_batch_set_debug", self.L)
