@@ -40,6 +40,7 @@
 #include <stdbool.h>
 #include <string.h>
 #include <math.h>
+#include <unistd.h>
 
 #include "r_flow.h"
 #include "rtl_433.h"
@@ -117,6 +118,18 @@ static size_t batch_limit(void)
 #else
     return 1;
 #endif
+}
+
+/* host threads of the decoder replay: RTL433_HIP_THREADS, default min(16, online cores) */
+static int replay_threads(void)
+{
+    char const *e = getenv("RTL433_HIP_THREADS");
+    if (e && *e) {
+        int v = atoi(e);
+        return v < 1 ? 1 : v;
+    }
+    long n = sysconf(_SC_NPROCESSORS_ONLN);
+    return n < 1 ? 1 : n > 16 ? 16 : (int)n;
 }
 
 static void hip_fatal(char const *what)
@@ -451,8 +464,26 @@ static int run_group(r_cfg_t *cfg, hip_capture *group, size_t n)
     H.group      = group;
     H.cur_stream = UINT32_MAX;
     r433_batch_frame_sums(H.eng, &H.frame_sums, &H.sums_cap);
-    r433_dispatch_hooks hooks = {NULL, on_package_begin, on_event_done, on_package_end};
-    int events = r433_batch_dispatch_hooks(H.eng, (r433_r_device *const *)demod->r_devs.elems, (uint32_t)demod->r_devs.len, &hooks);
+    /* The replay.  account_event's debug printout (a decoder without decode_fn, -vv) needs every bitbuffer after its
+       decoder ran: then everything stays on this thread.  Otherwise the decoders are spread over host threads -- each
+       decoder on one thread, its calls in reference order -- and what they hand to output_fn is committed here in
+       reference order (r433_batch_dispatch_ordered). */
+    int chatty = 0;
+    for (void **iter = demod->r_devs.elems; iter && *iter; ++iter) {
+        r_device const *d = *iter;
+        if (!d->decode_fn || d->verbose)
+            chatty = 1;
+    }
+    int n_threads = replay_threads();
+    int events;
+    if (chatty || n_threads <= 1) {
+        r433_dispatch_hooks hooks = {NULL, on_package_begin, on_event_done, on_package_end};
+        events = r433_batch_dispatch_hooks(H.eng, (r433_r_device *const *)demod->r_devs.elems, (uint32_t)demod->r_devs.len, &hooks);
+    }
+    else {
+        r433_dispatch_hooks hooks = {NULL, on_package_begin, NULL, on_package_end};
+        events = r433_batch_dispatch_ordered(H.eng, (r433_r_device *const *)demod->r_devs.elems, (uint32_t)demod->r_devs.len, &hooks, (uint32_t)n_threads);
+    }
     if (events == R433_EDECODER) {
         /* src/pulse_slicer.c:44-47 */
         print_logf(LOG_ERROR, "pulse_slicer", "%s: notify maintainer", r433_last_error());

@@ -180,6 +180,19 @@ typedef struct r433_dispatch_hooks {
 } r433_dispatch_hooks;
 int r433_batch_dispatch_hooks(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices,
         r433_dispatch_hooks const *hooks);
+/* The same, replayed on n_threads host threads WITHOUT giving up the reference's order where it can be observed:
+ *   - a decoder is only ever called by one thread, for its bitbuffers in package order -- decoders that keep state
+ *     between calls (e.g. src/devices/secplus_v1.c:142) see exactly the call sequence of the single-threaded replay;
+ *   - the priority rule (src/r_api.c:442-451) holds: the devices of a level run for a package only if no lower level
+ *     produced an event for it (levels are passes);
+ *   - what decoders hand to r_device.output_fn / log_fn during decode_fn is captured and committed on the calling
+ *     thread afterwards, package by package, in the order the single-threaded replay would have produced it, between the
+ *     package_begin and package_end hooks.
+ * hooks->event_done must be NULL (it would need every bitbuffer after its decoder ran; callers that want account_event's
+ * debug printout use r433_batch_dispatch_hooks).  r_device.output_fn / log_fn are swapped for the capture during the call
+ * and restored before it returns.  Returns the number of successful decode events. */
+int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices,
+        r433_dispatch_hooks const *hooks, uint32_t n_threads);
 /* per package of the last dispatch: the events its decoders reported (p_events) */
 int r433_batch_decoded(r433_batch *b, int const **per_package, uint32_t *count);
 

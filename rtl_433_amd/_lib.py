@@ -122,7 +122,7 @@ EXPORTS = [
     "r433_batch_run_pulses", "r433_pulse_text_load", "r433_pulse_text_dump", "r433_batch_analyze", "r433_analysis_text",
     "r433_pulse_vcd_header", "r433_pulse_vcd", "r433_batch_grab_plan",
     "r433_sigmf_prefix", "r433_sigmf_trailer", "r433_sigmf_probe",
-    "r433_filter_frame", "r433_envelope_host", "r433_host_alloc", "r433_host_free", "r433_batch_run_host", "r433_batch_dispatch_hooks", "r433_batch_decoded",
+    "r433_filter_frame", "r433_envelope_host", "r433_host_alloc", "r433_host_free", "r433_batch_run_host", "r433_batch_dispatch_hooks", "r433_batch_dispatch_ordered", "r433_batch_decoded",
 ]
 
 
@@ -222,6 +222,8 @@ def bind(L):
     L.r433_batch_run_host.argtypes = [vp, vp, vp, C.c_uint32]
     L.r433_batch_dispatch_hooks.restype = C.c_int
     L.r433_batch_dispatch_hooks.argtypes = [vp, vp, C.c_uint32, vp]
+    L.r433_batch_dispatch_ordered.restype = C.c_int
+    L.r433_batch_dispatch_ordered.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
     L.r433_batch_decoded.restype = C.c_int
     L.r433_batch_decoded.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint32)]
     for f in (L.r433_envelope_detect, L.r433_magnitude_est_cu8, L.r433_magnitude_est_cs16):

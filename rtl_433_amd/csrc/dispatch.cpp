@@ -308,6 +308,278 @@ int r433_batch_dispatch_hooks(r433_batch *b, r433_r_device *const *devices, uint
     return decoded;
 }
 
+// ---- ordered multi-threaded replay: threads own decoders, outputs are committed in reference order ----
+
+namespace {
+
+struct Captured {
+    uint32_t pkg, level_rank, dev, ordinal, seq;
+    int is_log, log_level;
+    struct data *payload;
+};
+
+struct CaptureCtx {
+    std::vector<Captured> *out = nullptr;
+    uint32_t level_rank = 0, seq = 0;
+};
+thread_local CaptureCtx g_capture;
+
+void capture_output(r433_r_device *decoder, struct data *payload)
+{
+    (void)decoder;
+    if (g_capture.out)
+        g_capture.out->push_back({g_current.package, g_capture.level_rank, g_current.device, g_current.ordinal, g_capture.seq++, 0, 0, payload});
+}
+
+void capture_log(r433_r_device *decoder, int level, struct data *payload)
+{
+    (void)decoder;
+    if (g_capture.out)
+        g_capture.out->push_back({g_current.package, g_capture.level_rank, g_current.device, g_current.ordinal, g_capture.seq++, 1, level, payload});
+}
+
+void inflate_bits(r433_bitbuffer *bits, uint8_t const *rec, r433_evt_rec const &eh)
+{
+    bits->num_rows = eh.num_rows;
+    bits->free_row = eh.free_row;
+    uint8_t const *rp = rec + sizeof(eh);
+    for (uint32_t r = 0; r < eh.num_rows && r < R433_BITBUF_ROWS; ++r) {
+        r433_row_rec rr;
+        memcpy(&rr, rp, sizeof(rr));
+        bits->bits_per_row[r] = rr.bits;
+        bits->syncs_before_row[r] = rr.syncs;
+        size_t room = (size_t)(R433_BITBUF_ROWS - r) * R433_BITBUF_COLS;
+        memcpy(bits->bb[r], rp + sizeof(rr), rr.nbytes < room ? rr.nbytes : room);
+        rp += sizeof(rr) + ((rr.nbytes + 3u) & ~3u);
+    }
+}
+
+} // namespace
+
+int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices,
+        r433_dispatch_hooks const *hooks, uint32_t n_threads)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    if (hooks && hooks->event_done)
+        return fail(R433_EINVAL, "the ordered replay has no event_done hook: use r433_batch_dispatch_hooks");
+    if (n_devices != b->timing.size())
+        return fail(R433_EINVAL, "dispatch needs the %zu devices the engine was created with", b->timing.size());
+    uint32_t const np = b->n_pkgs;
+    b->pkg_decoded.assign(np, 0);
+    b->dispatched = true;
+    if (n_threads < 1)
+        n_threads = 1;
+    uint8_t const *ev = b->h_events.p;
+    uint8_t const *pk = b->h_pkg_blob.p;
+
+    // index: the events of every device, in package order (the stream is sorted by package, device, ordinal)
+    std::vector<uint32_t> dev_count(n_devices + 1, 0);
+    size_t at = 0;
+    size_t const end = b->evt_bytes;
+    while (at + sizeof(r433_evt_rec) <= end) {
+        r433_evt_rec eh;
+        memcpy(&eh, ev + at, sizeof(eh));
+        if (eh.dev >= n_devices || eh.pkg >= np || eh.total_bytes < sizeof(eh) || at + eh.total_bytes > end)
+            return fail(R433_EHIP, "corrupt event stream at byte %zu", at);
+        dev_count[eh.dev + 1]++;
+        at += eh.total_bytes;
+    }
+    for (uint32_t d = 0; d < n_devices; ++d)
+        dev_count[d + 1] += dev_count[d];
+    std::vector<uint32_t> dev_fill(dev_count.begin(), dev_count.end() - 1);
+    std::vector<uint32_t> ev_off(dev_count[n_devices]);
+    for (at = 0; at + sizeof(r433_evt_rec) <= end;) {
+        r433_evt_rec eh;
+        memcpy(&eh, ev + at, sizeof(eh));
+        ev_off[dev_fill[eh.dev]++] = (uint32_t)at;
+        at += eh.total_bytes;
+    }
+    std::vector<uint32_t> pkg_stream(np), pkg_type(np), pkg_start_ago(np);
+    for (uint32_t p = 0; p < np; ++p) {
+        r433_pkg_rec ph;
+        memcpy(&ph, pk + b->h_rec_off.p[p], sizeof(ph));
+        pkg_stream[p] = ph.stream;
+        pkg_type[p] = ph.type;
+        pkg_start_ago[p] = ph.start_ago;
+    }
+
+    // outputs go to the capture while the threads run
+    std::vector<void (*)(r433_r_device *, struct data *)> keep_out(n_devices);
+    std::vector<void (*)(r433_r_device *, int, struct data *)> keep_log(n_devices);
+    for (uint32_t d = 0; d < n_devices; ++d) {
+        if (!devices[d])
+            continue;
+        keep_out[d] = devices[d]->output_fn;
+        keep_log[d] = devices[d]->log_fn;
+        devices[d]->output_fn = capture_output;
+        devices[d]->log_fn = capture_log;
+    }
+    std::vector<std::vector<Captured>> captured(n_threads);
+    std::vector<std::atomic<int>> p_events(np);
+    for (auto &x : p_events)
+        x.store(0, std::memory_order_relaxed);
+    std::atomic<int> failed{0};
+    std::string err;
+    std::mutex err_m;
+
+    for (uint32_t li = 0; li < b->prio_levels.size() && !failed.load(); ++li) {
+        uint32_t const level = b->prio_levels[li];
+        std::vector<uint32_t> devs_of_level;
+        for (uint32_t d = 0; d < n_devices; ++d)
+            if (b->timing[d].priority == level && dev_count[d + 1] > dev_count[d])
+                devs_of_level.push_back(d);
+        // heaviest decoders first: the pass ends when the last thread does
+        std::sort(devs_of_level.begin(), devs_of_level.end(), [&](uint32_t x, uint32_t y) {
+            return dev_count[x + 1] - dev_count[x] > dev_count[y + 1] - dev_count[y];
+        });
+        // a package whose lower levels produced an event is closed for this level (src/r_api.c:442)
+        std::vector<uint8_t> open(np);
+        for (uint32_t p = 0; p < np; ++p)
+            open[p] = p_events[p].load(std::memory_order_relaxed) == 0;
+        std::atomic<uint32_t> cursor{0};
+        uint32_t const nt = std::max<uint32_t>(1, std::min<uint32_t>(n_threads, (uint32_t)devs_of_level.size()));
+        b->pool.run(nt, [&](unsigned w) {
+            r433_bitbuffer *bits = (r433_bitbuffer *)calloc(1, sizeof(r433_bitbuffer));
+            g_capture.out = &captured[w];
+            g_capture.level_rank = li;
+            for (;;) {
+                uint32_t const k = cursor.fetch_add(1, std::memory_order_relaxed);
+                if (k >= devs_of_level.size() || failed.load(std::memory_order_relaxed))
+                    break;
+                uint32_t const dev = devs_of_level[k];
+                r433_r_device *rd = devices[dev];
+                unsigned n_ev = 0, n_ok = 0, n_msg = 0, fails[5] = {0, 0, 0, 0, 0};
+                for (uint32_t e = dev_count[dev]; e < dev_count[dev + 1]; ++e) {
+                    uint8_t const *rec = ev + ev_off[e];
+                    r433_evt_rec eh;
+                    memcpy(&eh, rec, sizeof(eh));
+                    if (!open[eh.pkg])
+                        continue;
+                    inflate_bits(bits, rec, eh);
+                    uint32_t used_rows = std::max<uint32_t>(eh.num_rows, eh.free_row);
+                    g_current.stream = pkg_stream[eh.pkg];
+                    g_current.package = eh.pkg;
+                    g_current.device = dev;
+                    g_current.ordinal = eh.ordinal;
+                    g_current.package_type = pkg_type[eh.pkg];
+                    g_current.start_ago = pkg_start_ago[eh.pkg];
+                    g_capture.seq = 0;
+                    int ret = 0;
+                    if (rd && rd->decode_fn)
+                        ret = rd->decode_fn(rd, bits);
+                    n_ev += 1;
+                    if (ret > 0) {
+                        n_ok += 1;
+                        n_msg += (unsigned)ret;
+                        p_events[eh.pkg].fetch_add(ret, std::memory_order_relaxed);
+                    }
+                    else if (ret >= R433_DECODE_FAIL_SANITY) {
+                        fails[-ret] += 1;
+                    }
+                    else {
+                        std::lock_guard<std::mutex> g(err_m);
+                        char buf[200];
+                        snprintf(buf, sizeof(buf), "decoder \"%s\" gave invalid return value %d", rd && rd->name ? rd->name : "?", ret);
+                        err = buf;
+                        failed.store(1);
+                        break;
+                    }
+                    used_rows = std::max<uint32_t>(used_rows, std::max<uint32_t>(bits->num_rows, bits->free_row));
+                    if (used_rows > R433_BITBUF_ROWS)
+                        used_rows = R433_BITBUF_ROWS;
+                    memset(bits->bb, 0, (size_t)used_rows * R433_BITBUF_COLS);
+                    memset(bits, 0, offsetof(r433_bitbuffer, bb));
+                }
+                if (rd) { // this thread is the only one that touches this decoder
+                    rd->decode_events += n_ev;
+                    rd->decode_ok += n_ok;
+                    rd->decode_messages += n_msg;
+                    for (int f = 0; f < 5; ++f)
+                        rd->decode_fails[f] += fails[f];
+                }
+            }
+            g_capture.out = nullptr;
+            digest_publish();
+            free(bits);
+        });
+    }
+    for (uint32_t d = 0; d < n_devices; ++d) {
+        if (!devices[d])
+            continue;
+        devices[d]->output_fn = keep_out[d];
+        devices[d]->log_fn = keep_log[d];
+    }
+
+    // commit: what the decoders handed out, in the order the single-threaded replay produces it
+    std::vector<Captured> all;
+    for (auto &c : captured)
+        all.insert(all.end(), c.begin(), c.end());
+    std::sort(all.begin(), all.end(), [](Captured const &x, Captured const &y) {
+        if (x.pkg != y.pkg) return x.pkg < y.pkg;
+        if (x.level_rank != y.level_rank) return x.level_rank < y.level_rank;
+        if (x.dev != y.dev) return x.dev < y.dev;
+        if (x.ordinal != y.ordinal) return x.ordinal < y.ordinal;
+        return x.seq < y.seq;
+    });
+    bool const want_pkgs = hooks && (hooks->package_begin || hooks->package_end);
+    r433_pulse_data *pd = want_pkgs && hooks->package_begin ? (r433_pulse_data *)calloc(1, sizeof(r433_pulse_data)) : nullptr;
+    size_t ci = 0;
+    int decoded = 0;
+    for (uint32_t p = 0; p < np; ++p) {
+        int const pe = p_events[p].load(std::memory_order_relaxed);
+        b->pkg_decoded[p] = pe;
+        decoded += pe;
+        bool const has_out = ci < all.size() && all[ci].pkg == p;
+        if (!want_pkgs && !has_out)
+            continue;
+        r433_pkg_rec ph;
+        memcpy(&ph, pk + b->h_rec_off.p[p], sizeof(ph));
+        if (pd) {
+            memset(pd, 0, sizeof(*pd));
+            pd->offset = ph.offset;
+            pd->sample_rate = ph.sample_rate;
+            pd->start_ago = ph.start_ago;
+            pd->end_ago = ph.end_ago;
+            pd->num_pulses = ph.num_pulses;
+            int32_t const *pairs = (int32_t const *)(pk + b->h_rec_off.p[p] + sizeof(ph));
+            for (uint32_t i = 0; i < ph.num_pulses && i < R433_MAX_PULSES; ++i) {
+                pd->pulse[i] = pairs[2 * i];
+                pd->gap[i] = pairs[2 * i + 1];
+            }
+            pd->ook_low_estimate = ph.ook_low;
+            pd->ook_high_estimate = ph.ook_high;
+            pd->fsk_f1_est = ph.fsk_f1;
+            pd->fsk_f2_est = ph.fsk_f2;
+            fill_levels(b->cfg, *pd);
+            hooks->package_begin(hooks->user, &ph, pd);
+        }
+        for (; ci < all.size() && all[ci].pkg == p; ++ci) {
+            Captured const &c = all[ci];
+            r433_r_device *rd = devices[c.dev];
+            g_current.stream = ph.stream;
+            g_current.package = p;
+            g_current.device = c.dev;
+            g_current.ordinal = c.ordinal;
+            g_current.package_type = ph.type;
+            g_current.start_ago = ph.start_ago;
+            if (c.is_log) {
+                if (rd && rd->log_fn)
+                    rd->log_fn(rd, c.log_level, c.payload);
+            }
+            else if (rd && rd->output_fn) {
+                rd->output_fn(rd, c.payload);
+            }
+        }
+        if (hooks && hooks->package_end && !failed.load())
+            hooks->package_end(hooks->user, &ph, pe);
+    }
+    free(pd);
+    if (failed.load())
+        return fail(R433_EDECODER, "%s", err.c_str());
+    return decoded;
+}
+
 int r433_batch_decoded(r433_batch *b, int const **per_package, uint32_t *count)
 {
     if (!b)

@@ -95,6 +95,12 @@ class BatchEngine:
                                               C.byref(hooks) if hooks is not None else None)
         return _lib.check(rc, "r433_batch_dispatch_hooks", self.L)
 
+    def dispatch_ordered(self, rdevices, hooks=None, n_threads=8):
+        """Threads own decoders, outputs committed in reference order (r433_batch_dispatch_ordered)."""
+        rc = self.L.r433_batch_dispatch_ordered(self.h, C.cast(rdevices, C.c_void_p), len(rdevices),
+                                                C.byref(hooks) if hooks is not None else None, n_threads)
+        return _lib.check(rc, "r433_batch_dispatch_ordered", self.L)
+
     def decoded(self):
         """per package: events reported by its decoders in the last dispatch"""
         p, n = C.c_void_p(), C.c_uint32()

@@ -268,3 +268,72 @@ def test_run_host_equals_run(backend):
         assert got == (eng2.packages(), eng2.events())
         eng2.close()
     eng.close()
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_dispatch_ordered_equals_single_thread(threads, backend):
+    """r433_batch_dispatch_ordered: decoders spread over threads, each decoder's calls in reference order, the priority
+    rule kept, and what decoders hand to output_fn / log_fn committed in the order of the single-threaded replay."""
+    devs = _devices()
+    iqs = [synth.ook_stream(930 + k, 30000)[0] for k in range(6)]
+    eng, keep = _setup(devs, iqs, backend)
+    L = eng.L
+    OUT_FN = C.CFUNCTYPE(None, C.POINTER(_lib.RDevice), C.c_void_p)
+    LOG_FN = C.CFUNCTYPE(None, C.POINTER(_lib.RDevice), C.c_int, C.c_void_p)
+    hit_dev = 3
+
+    def run(ordered):
+        trace, per_dev_calls = [], {}
+
+        @_lib.DECODE_FN
+        def decode(rdev, bits_p):
+            info = _lib.DispatchInfo()
+            L.r433_dispatch_current(C.byref(info))
+            per_dev_calls.setdefault(info.device, []).append((info.package, info.ordinal))
+            d = rdev.contents
+            token = (info.package << 20) | (info.device << 10) | info.ordinal
+            # a decoder that talks: one log line for every call of device 0, two outputs for every hit of hit_dev
+            if info.device == 0:
+                C.cast(d.log_fn, LOG_FN)(rdev, 2, C.c_void_p(token | (1 << 40)))
+            if info.device == hit_dev:
+                C.cast(d.output_fn, OUT_FN)(rdev, C.c_void_p(token))
+                C.cast(d.output_fn, OUT_FN)(rdev, C.c_void_p(token | (1 << 41)))
+                return 2
+            return -1
+
+        @OUT_FN
+        def real_out(rdev, payload):
+            trace.append(("out", rdev.contents.protocol_num, payload))
+
+        @LOG_FN
+        def real_log(rdev, level, payload):
+            trace.append(("log", rdev.contents.protocol_num, level, payload))
+
+        @_lib.HOOK_BEGIN_FN
+        def begin(user, rec, pd):
+            trace.append(("begin", rec.contents.stream, rec.contents.num_pulses, round(pd.contents.rssi_db, 3)))
+
+        @_lib.HOOK_END_FN
+        def end(user, rec, p_events):
+            trace.append(("end", rec.contents.stream, p_events))
+
+        rdevs, objs = make_rdevices(devs, C.cast(decode, C.c_void_p).value, None, protocols=list(range(100, 100 + len(devs))))
+        for o in objs:
+            o.output_fn = C.cast(real_out, C.c_void_p)
+            o.log_fn = C.cast(real_log, C.c_void_p)
+        null_event = C.cast(None, _lib.HOOK_EVENT_FN)
+        hooks = _lib.DispatchHooks(None, begin, null_event, end)
+        n = eng.dispatch_ordered(rdevs, hooks, threads) if ordered else eng.dispatch_hooks(rdevs, hooks)
+        stats = [(o.decode_events, o.decode_ok, o.decode_messages, list(o.decode_fails)) for o in objs]
+        fns = all(o.output_fn == C.cast(real_out, C.c_void_p).value and o.log_fn == C.cast(real_log, C.c_void_p).value for o in objs)
+        return n, trace, per_dev_calls, stats, list(eng.decoded()), fns
+
+    a = run(False)
+    b = run(True)
+    assert a[0] == b[0] and a[0] > 0
+    assert a[1] == b[1]            # hooks and committed outputs: same sequence
+    assert a[2] == b[2]            # every decoder saw the same calls in the same order (priority gating included)
+    assert a[3] == b[3] and a[4] == b[4]
+    assert a[5] and b[5]           # output_fn / log_fn restored
+    assert any(t[0] == "out" for t in a[1]) and any(t[0] == "log" for t in a[1])
+    eng.close()
