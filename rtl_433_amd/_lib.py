@@ -131,6 +131,13 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # PyTorch ships its own HIP runtime (same soname as /opt/rocm's).  Whichever is loaded first serves the whole
+        # process; if the system one wins, torch finds "no HIP GPUs" later.  Python callers use torch for device memory
+        # anyway, so let it load first.  (A C host -- dropin/ -- has no torch and uses the system runtime.)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run `python -m rtl_433_amd.build` (hipcc, gfx950). "
                            "rtl_433_amd has no CPU fallback.")

@@ -13,6 +13,7 @@ ap.add_argument("--samples", type=int, default=65536)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--nodevs", action="store_true")
 ap.add_argument("--seed0", type=int, default=0)
+ap.add_argument("--rotate", type=int, default=1, help="distinct input batches taken in turn (no launch re-reads the batch before it)")
 ap.add_argument("--split", type=int, default=0)
 ap.add_argument("--debug", type=lambda x: int(x, 0), default=0)
 ap.add_argument("--sigma-only", action="store_true", help="only the captures with noise (sigma > 0): no closed-form silence")
@@ -41,6 +42,7 @@ else:
         host = synth.ook_batch(a.streams, a.samples, 250000, seed0=a.seed0)
     cfg = flow_cfg(2, 250000)
 d = torch.from_numpy(host).cuda()
+ds = [d] + [torch.from_numpy(np.roll(host, k + 1, axis=0).copy()).cuda() for k in range(a.rotate - 1)]
 devs = None if a.nodevs else load_device_table()[0]
 eng = BatchEngine(cfg, devs, profiling=True)
 if a.split:
@@ -49,9 +51,10 @@ if a.debug:
     eng.set_debug(a.debug)
 ts = []
 for r in range(a.reps):
-    n = eng.run(d)
+    n = eng.run(ds[r % len(ds)])
     ts.append(eng.timing())
 best = min(ts, key=lambda t: t["detect_ms"])
+print("detect_ms per rep:", [round(t["detect_ms"], 3) for t in ts])
 print(f"flags={a.debug} streams={a.streams} samples={a.samples} pkgs={n} " +
       " ".join(f"{k}={v:.3f}" for k, v in best.items()) + (f" split={eng.split_stats()}" if a.split else ""))
 
