@@ -31,7 +31,7 @@
 
     Not served by this flow (reported once, then ignored): the sample grabber (-S), the raw rtl_tcp output's
     per-frame pacing is kept, S16_AM / S16_FM pseudo-IQ input files, and sample dumpers other than the input's own
-    format (-w/-W .ook and .vcd are served).
+    format (-w/-W .ook, .vcd and .u8 are served).
  */
 
 #include <stdio.h>
@@ -454,7 +454,31 @@ static int run_group(r_cfg_t *cfg, hip_capture *group, size_t n)
         ptrs[i]  = H.stage + group[i].offset;
         bytes[i] = group[i].bytes;
     }
+    /* a `-w file.u8` dumper: the detection kernel paints the logic bytes (src/r_flow.c:236-237,271-272,314-315,364-371) */
+    int want_logic = 0;
+    for (void **iter = demod->dumper.elems; iter && *iter; ++iter) {
+        file_info_t const *dumper = *iter;
+        if (dumper->format == U8_LOGIC && dumper->file)
+            want_logic = 1;
+    }
+    r433_batch_enable_logic_dump(H.eng, want_logic);
     int n_pkgs = r433_batch_run_host(H.eng, ptrs, bytes, (uint32_t)n);
+    if (n_pkgs >= 0 && want_logic) {
+        uint8_t const *logic = NULL;
+        uint64_t stride      = 0;
+        if (r433_batch_logic_dump(H.eng, &logic, &stride) < 0)
+            hip_fatal("r433_batch_logic_dump");
+        for (void **iter = demod->dumper.elems; iter && *iter; ++iter) {
+            file_info_t const *dumper = *iter;
+            if (dumper->format != U8_LOGIC || !dumper->file)
+                continue;
+            for (size_t i = 0; i < n; ++i) {
+                size_t n_samples = group[i].bytes / group[i].sample_size;
+                if (fwrite(logic + i * stride, 1, n_samples, dumper->file) != n_samples)
+                    print_log(LOG_ERROR, __func__, "Short write, samples lost, exiting!");
+            }
+        }
+    }
     free(ptrs);
     free(bytes);
     if (n_pkgs < 0)
@@ -676,6 +700,9 @@ int push_sdr_flow(r_cfg_t *cfg, unsigned char *iq_buf, uint32_t len)
         file_info_t const *dumper = *iter;
         if (!dumper->file || dumper->format == VCD_LOGIC || dumper->format == PULSE_OOK) {
             continue;
+        }
+        if (dumper->format == U8_LOGIC) {
+            continue; /* written when the capture has been through the detection kernel */
         }
         if ((dumper->format == CU8_IQ && demod->sample_size == 2) || (dumper->format == CS16_IQ && demod->sample_size == 4)) {
             if (fwrite(iq_buf, 1, len, dumper->file) != len) {

@@ -98,6 +98,15 @@ int r433_batch_frame_sums(r433_batch *b, uint32_t const **sums, uint32_t *frames
 /* device-side record arenas of the last run (for consumers that stay on the GPU) */
 int r433_batch_device_events(r433_batch *b, void const **d_events, size_t *len);
 
+/* The `u8` logic dump (-w file.u8 / U8_LOGIC, reference src/r_flow.c:236-237,271-272,314-315,364-371,480, src/pulse_data.c:58-67):
+ * one byte per sample -- 0x01 where a package's pulse/gap list covers the sample, | 0x02 on the pulses of OOK packages, | 0x04
+ * on the pulses of FSK packages (and of the FSK candidate that every OOK package carries through its first pulse) -- painted
+ * by the detection kernel at the moments the reference paints (package returns, frame ends) with its clipping and overwrite
+ * order, so that the bytes equal the reference's file.  With it on, captures are not split (r433_batch_set_split is ignored).
+ * r433_batch_logic_dump gives the host copy of the last run: capture s at host + s * stride, as many bytes as it has samples. */
+int r433_batch_enable_logic_dump(r433_batch *b, int on);
+int r433_batch_logic_dump(r433_batch *b, uint8_t const **host, uint64_t *stride);
+
 /* Optional parity taps: per-sample envelope (u16), low-passed envelope (s16) and FM (s16) of every
  * capture, written to device buffers of n_streams*tap_stride samples.  Pass NULLs to disable. */
 int r433_batch_set_taps(r433_batch *b, void *d_env, void *d_am, void *d_fm, uint64_t tap_stride);

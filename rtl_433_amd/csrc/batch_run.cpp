@@ -95,6 +95,13 @@ int run_size_buffers(RunCtx &r)
     }
     b->frames_cap = r.frames_cap;
     b->n_streams = r.n_streams;
+    if (b->logic_on) {
+        b->logic_stride = ((uint64_t)r.max_samples + 15u) & ~15ull;
+        size_t const bytes = (size_t)r.n_streams * b->logic_stride + 16;
+        if ((rc = b->d_logic.ensure(bytes)) || (rc = b->h_logic.ensure(bytes)))
+            return rc;
+        HIP_TRY(hipMemsetAsync(b->d_logic.p, 0, bytes, r.st));
+    }
 
     // arena: worst case is one (pulse, gap) pair per 20 samples plus headers; start at ~1 B/sample
     r.want_stride = std::max<uint32_t>(16384u, ((r.max_samples + 4096u) + 15u) & ~15u);
@@ -122,6 +129,8 @@ int run_autolevel(RunCtx &r)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(b->h_frame_sums.p, b->d_frame_sums.p, (size_t)r.n_streams * r.frames_cap * sizeof(uint32_t),
             hipMemcpyDeviceToHost, r.st));
+    if (b->logic_on && r.d_iq)
+        HIP_TRY(hipMemcpyAsync(b->h_logic.p, b->d_logic.p, (size_t)r.n_streams * b->logic_stride, hipMemcpyDeviceToHost, r.st));
     HIP_TRY(stream_wait(b, r.st));
     b->h_frame_min_high.assign((size_t)r.n_streams * r.frames_cap, b->det.min_high);
     int const is_mag = r.ss == 4 || b->cfg.use_mag_est;
@@ -247,7 +256,7 @@ int run_plan(RunCtx &r)
     b->stream_samples = r.cap_n;
     // automatic: only where one wavefront per capture would leave the chip empty -- few, long captures.
     // Aim at ~4096 segments, at least 32 Ki samples each.
-    uint32_t split_samples = b->split_samples;
+    uint32_t split_samples = b->logic_on ? 0u : b->split_samples; // the logic dump is painted by whole-capture wavefronts
     if (split_samples == R433_SPLIT_AUTO) {
         uint64_t total = 0;
         for (uint32_t c = 0; c < r.n_streams; ++c)
@@ -298,6 +307,10 @@ StreamParams stream_params(RunCtx const &r)
     sp.frame_sums = b->d_frame_sums.p;
     sp.frames_cap = r.frames_cap;
     sp.frame_min_high = r.d_min_high;
+    if (b->logic_on) {
+        sp.logic = b->d_logic.p;
+        sp.logic_stride = b->logic_stride;
+    }
     sp.tap_env = (uint16_t *)b->tap_env;
     sp.tap_am = (int16_t *)b->tap_am;
     sp.tap_fm = (int16_t *)b->tap_fm;
@@ -603,6 +616,8 @@ int run_slice_and_mirror(RunCtx &r)
     }
     HIP_TRY(hipMemcpyAsync(b->h_frame_sums.p, b->d_frame_sums.p, (size_t)r.n_streams * r.frames_cap * sizeof(uint32_t),
             hipMemcpyDeviceToHost, r.st));
+    if (b->logic_on && r.d_iq)
+        HIP_TRY(hipMemcpyAsync(b->h_logic.p, b->d_logic.p, (size_t)r.n_streams * b->logic_stride, hipMemcpyDeviceToHost, r.st));
     if (b->profiling)
         HIP_TRY(hipEventRecord(b->ev[6], r.st));
     HIP_TRY(stream_wait(b, r.st));

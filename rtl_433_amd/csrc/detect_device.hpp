@@ -56,6 +56,7 @@ struct DetLane {
     bool writer;        // the one lane that performs the memory accesses
     uint32_t arena_cap;
     uint32_t cursor;    // bytes of finished records
+    uint32_t ook_base;  // cursor when the current (or last) package began: its OOK pairs sit at arena + ook_base + 64
     uint32_t n_pkgs;
     uint32_t overflow;
     uint32_t stream;
@@ -350,6 +351,7 @@ __device__ __forceinline__ void det_idle(DetLane &d, DetCfg const &c, int am, in
     int const hys = (int)(int16_t)(thr / 8);
     if (am > thr + hys && d.lead_in > 1024) {
         d.ook_num = 0;
+        d.ook_base = d.cursor;
         d.cur_pulse = 0;
         d.ook_f1 = 0;
         d.fsk_num = 0;

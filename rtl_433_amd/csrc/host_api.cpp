@@ -257,6 +257,8 @@ void r433_batch_destroy(r433_batch *b)
     b->d_analysis.release();
     b->h_arena_stage.release();
     b->d_input.release();
+    b->d_logic.release();
+    b->h_logic.release();
     if (b->own_stream)
         (void)hipStreamDestroy(b->own_stream);
     b->h_scal.release();
@@ -295,6 +297,27 @@ int r433_batch_set_split(r433_batch *b, uint32_t segment_samples)
     if (segment_samples > R433_SPLIT_AUTO && segment_samples < 4096)
         return fail(R433_EINVAL, "segments shorter than 4096 samples make no sense (the establishing tile alone is 2048)");
     b->split_samples = segment_samples;
+    return 0;
+}
+
+int r433_batch_enable_logic_dump(r433_batch *b, int on)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    b->logic_on = on != 0;
+    return 0;
+}
+
+int r433_batch_logic_dump(r433_batch *b, uint8_t const **host, uint64_t *stride)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    if (!b->logic_on || !b->h_logic.p)
+        return fail(R433_EINVAL, "no logic dump: r433_batch_enable_logic_dump before the run");
+    if (host)
+        *host = b->h_logic.p;
+    if (stride)
+        *stride = b->logic_stride;
     return 0;
 }
 

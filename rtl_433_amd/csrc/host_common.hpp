@@ -195,6 +195,10 @@ struct r433_batch {
     uint32_t split_samples = R433_SPLIT_AUTO;
     uint32_t debug_flags = 0; // r433_batch_set_debug
     bool exclusive_detect = false; // r433_batch_set_exclusive_detect
+    bool logic_on = false;         // r433_batch_enable_logic_dump
+    DevBuf<uint8_t> d_logic;
+    PinBuf<uint8_t> h_logic;
+    uint64_t logic_stride = 0;
     DevBuf<uint32_t> d_tile_max, d_order;
     DevBuf<SegDesc> d_segs;
     PinBuf<uint32_t> h_tile_max;

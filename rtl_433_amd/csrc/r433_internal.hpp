@@ -98,6 +98,10 @@ struct StreamParams {
     // the last IQ sample, centred -- i.e. filter_state_t / demodfm_state_t of the reference (include/baseband.h:91-107).
     // The carries after the frame's last sample come back in StreamState::lpf_y, lpf_x, fm_yf, fm_xf.
     int const *seam_init;
+    // optional `u8` logic dump (-w file.u8, reference src/r_flow.c:236-237,271-272,314-315,364-371, src/pulse_data.c:58-67):
+    // one byte per sample, n_streams * logic_stride bytes, zeroed by the host before the launch
+    uint8_t *logic;
+    uint64_t logic_stride;
 };
 
 void launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st);

@@ -47,7 +47,9 @@ namespace {
 
 constexpr int kChunk = 32;          // samples per lane in phase B
 constexpr int kTile = 64 * kChunk;  // samples per tile
-constexpr int kWarmChunks = 3;      // 96 warm-up samples: 0.854^96 * 2^16 < 1, 0.727^96 * 2^32 < 1
+constexpr int kWarmChunks = 3;      // chunks a lane reads before its own
+constexpr int kWarmSkip = 24;       // ... minus their first 24 samples: 72 warm-up samples, 0.854^72 * 2^16 = 0.77 < 1, 0.727^72 * 2^32 = 0.46 < 1
+                                    // (whether the two tracks have met is CHECKED, never assumed: a shorter warm-up can only cost resolve rounds)
 constexpr int kRow = 512;           // samples per phase-A row (8 per lane)
 constexpr int kRows = kTile / kRow;
 constexpr int kPitch16 = kChunk * 2 + 16;  // LDS pitch of a chunk of 16-bit samples: conflict-free b128 per lane
@@ -303,6 +305,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
     det.stream = cap;
     det.writer = lane == 0;
     det.cursor = 0;
+    det.ook_base = 0;
     det.n_pkgs = 0;
     det.overflow = 0;
     uint32_t frame = seg_start / F;
@@ -340,6 +343,38 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
         }
     };
     auto now = [&]() -> long long { return timing ? (long long)clock64() : 0ll; };
+
+    // ---- `u8` logic dump (optional): the reference paints one byte per sample into a per-frame buffer -- 0x01 | bits over the
+    // pulses of a package, 0x01 over its gaps -- when a package is returned, and again for whatever its two pulse_data_t hold
+    // when the frame ends (src/r_flow.c:271-272,314-315,364-371; bounded_memset clips to the frame; later paints overwrite
+    // earlier ones, src/pulse_data.c:45-67).  Same paints, same order, same clipping; lanes share the pairs of a paint.
+    uint8_t *const logic = (!SEAM && p.logic && seg_primary) ? p.logic + (uint64_t)cap * p.logic_stride : nullptr;
+    auto paint = [&](uint64_t offset, uint32_t n_pairs, int2 const *pairs, int bits, uint64_t win0, int win_len) {
+        long long run = (long long)offset - (long long)win0; // position of the pair being painted, relative to the frame
+        for (uint32_t b0 = 0; b0 < n_pairs; b0 += 64) {
+            uint32_t const kx = b0 + (uint32_t)lane;
+            int pw = 0, gw = 0;
+            if (kx < n_pairs) { // lane 0 wrote these: read them past the vector cache
+                pw = __hip_atomic_load(&pairs[kx].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gw = __hip_atomic_load(&pairs[kx].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            int incl = pw + gw;
+            for (int o = 1; o < 64; o <<= 1) {
+                int const t = __shfl_up(incl, (unsigned)o, 64);
+                if (lane >= o)
+                    incl += t;
+            }
+            long long const start = run + (long long)(incl - (pw + gw));
+            auto span = [&](long long from, int len, int value) { // bounded_memset
+                long long a = from < 0 ? 0 : from, z = from + len > win_len ? win_len : from + len;
+                for (long long x = a; x < z; ++x)
+                    logic[win0 + (uint64_t)x] = (uint8_t)value;
+            };
+            span(start, pw, 0x01 | bits);
+            span(start + pw, gw, 0x01);
+            run += (long long)__shfl(incl, 63, 64);
+        }
+    };
 
     uint4 pf[G::loads];
     auto issue_loads = [&](uint32_t tile) {
@@ -485,12 +520,13 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
             tf16.lo = -32768, tf16.hi = 32767;
             tf32.lo = INT32_MIN, tf32.hi = INT32_MAX;
             xa1 = ff1 = 0; // lanes 0..2 of an establishing tile have no history at all: never proven, never used
-            if (first > 0) {
-                xa1 = (int)*(uint16_t const *)(s_env + (first - 1) * kPitch16 + (kChunk - 1) * 2);
-                ff1 = SS == 2 ? (int)*(int16_t const *)(s_f + (first - 1) * G::f_pitch + (kChunk - 1) * 2)
-                              : *(int const *)(s_f + (first - 1) * G::f_pitch + (kChunk - 1) * 4);
+            if (lane >= kWarmChunks) { // the warm-up starts kWarmSkip samples into chunk `first`: its predecessor is in that chunk
+                xa1 = (int)*(uint16_t const *)(s_env + first * kPitch16 + (kWarmSkip - 1) * 2);
+                ff1 = SS == 2 ? (int)*(int16_t const *)(s_f + first * G::f_pitch + (kWarmSkip - 1) * 2)
+                              : *(int const *)(s_f + first * G::f_pitch + (kWarmSkip - 1) * 4);
             }
         }
+        bool const skip_head = !from_carry && lane >= kWarmChunks; // my first warm-up chunk starts at sample kWarmSkip
         ta.ok = tf16.ok = tf32.ok = 1;
 
         ChunkStatus sa, sf; // AM, FM
@@ -502,10 +538,10 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
         int cap_ya = 0, cap_xa = 0, cap_yf = 0, cap_ff = 0; // SEAM: the state right after my chunk's last valid sample
 
         // one chunk of 32 steps for both filters; MAIN = my own chunk (publish, statistics)
-        auto chunk_pass = [&](int c, auto main_tag) {
+        auto chunk_pass = [&](int c, auto main_tag, int g0) {
             constexpr bool MAIN = decltype(main_tag)::value;
             // a frame starts here: the AM filter state keeps x[-1] in an int16 slot (baseband.c:166-168)
-            if ((fs_mask >> c) & 1ull)
+            if (((fs_mask >> c) & 1ull) && g0 == 0)
                 xa1 = (int)(int16_t)xa1;
             if (MAIN) {
                 sa.start_known = ta.exact();
@@ -520,7 +556,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                 }
             }
 #pragma unroll 1
-            for (int g = 0; g < kChunk / 8; ++g) {
+            for (int g = g0; g < kChunk / 8; ++g) {
                 uint4 const e4 = *(uint4 const *)(s_env + c * kPitch16 + g * 16);
                 uint32_t const ew[4] = {e4.x, e4.y, e4.z, e4.w};
                 uint4 f4a = make_uint4(0, 0, 0, 0), f4b = make_uint4(0, 0, 0, 0);
@@ -594,9 +630,9 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
         for (int q = 0; q < kWarmChunks; ++q) {
             int const c = lane - kWarmChunks + q; // chunk being read
             if (c >= 0)
-                chunk_pass(c, std::false_type{});
+                chunk_pass(c, std::false_type{}, q == 0 && skip_head ? kWarmSkip / 8 : 0);
         }
-        chunk_pass(lane, std::true_type{});
+        chunk_pass(lane, std::true_type{}, 0);
         sa.end_known = ta.exact();
         sa.y_end = ta.lo;
         if (!FM) {
@@ -913,6 +949,18 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
             det.fsk_num = (uint32_t)uni((int)det.fsk_num);
         };
         pin_state();
+        // the end of a frame (= of a push_sdr_flow call): "Dump partial pulse data, might overlap with the last complete
+        // package" (src/r_flow.c:364-371) -- whatever the two structs hold right now, OOK first, FSK over it
+        auto frame_done = [&]() {
+            if (logic) {
+                __threadfence();
+                paint(det.offset, det.ook_num, (int2 const *)(det.arena + det.ook_base + sizeof(r433_pkg_rec)), 0x02, input_pos, flen);
+                paint(det.fsk_offset, det.fsk_num, det.fsk_ring, 0x04, input_pos, flen);
+            }
+            input_pos += (uint64_t)flen;
+            frame += 1;
+            dc = 0;
+        };
         while (i < n_t) {
             CNT(0, 1); // outer iterations
             long long const t_it = now();
@@ -971,11 +1019,8 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                     int const done = jump_to - i;
                     i += done;
                     dc += done;
-                    if (dc == flen) {
-                        input_pos += (uint64_t)flen;
-                        frame += 1;
-                        dc = 0;
-                    }
+                    if (dc == flen)
+                        frame_done();
                     tick(st_it == ST_IDLE ? 1 : 2, t_it);
                     continue;
                 }
@@ -1647,11 +1692,8 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                 int const done = k - i;
                 i += done;
                 dc += done;
-                if (dc == flen) {
-                    input_pos += (uint64_t)flen;
-                    frame += 1;
-                    dc = 0;
-                }
+                if (dc == flen)
+                    frame_done();
                 tick(st_it == ST_IDLE ? 1 : st_it == ST_GAP ? 2 : st_it == ST_PULSE ? 3 : 4, t_it);
                 continue;
             }
@@ -1666,6 +1708,13 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                     int const am = __builtin_amdgcn_readlane(am_l, j - base), fm = __builtin_amdgcn_readlane(fm_l, j - base);
                     CNT(11, 1); // general steps
                     int const r = det_step(det, cfg, am, fm, flen, local_dc, input_pos, frame);
+                    if (r && logic) { // the returned struct, before the re-examined sample may start the next package
+                        __threadfence();
+                        if (r == R433_PKG_OOK)
+                            paint(det.offset, det.ook_num, (int2 const *)(det.arena + det.ook_base + sizeof(r433_pkg_rec)), 0x02, input_pos, flen);
+                        else
+                            paint(det.fsk_offset, det.fsk_num, det.fsk_ring, 0x04, input_pos, flen);
+                    }
                     if (r) { // package returned: the next call starts at the same sample, in the idle state
                         det_call_entry(det, cfg, flen, local_dc);
                         det_idle(det, cfg, am, flen, local_dc, input_pos);
@@ -1678,11 +1727,8 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
             }
             i += consumed;
             dc += consumed;
-            if (dc == flen) {
-                input_pos += (uint64_t)flen;
-                frame += 1;
-                dc = 0;
-            }
+            if (dc == flen)
+                frame_done();
             tick(5, t_fast);
         }
         long long const t_res = now();

@@ -126,6 +126,18 @@ class BatchEngine:
         """Cut captures longer than segment_samples into independently processed, verified segments."""
         _lib.check(self.L.r433_batch_set_split(self.h, int(segment_samples)), "r433_batch_set_split", self.L)
 
+    def enable_logic_dump(self, on=True):
+        _lib.check(self.L.r433_batch_enable_logic_dump(self.h, int(on)), "r433_batch_enable_logic_dump", self.L)
+
+    def logic_dump(self, lengths):
+        """-> list of uint8 arrays, one per capture (lengths in samples): the `-w file.u8` bytes of the last run."""
+        p, st = C.c_void_p(), C.c_uint64()
+        _lib.check(self.L.r433_batch_logic_dump(self.h, C.byref(p), C.byref(st)), "r433_batch_logic_dump", self.L)
+        out = []
+        for s, n in enumerate(lengths):
+            out.append(np.ctypeslib.as_array(C.cast(p.value + s * st.value, C.POINTER(C.c_uint8)), shape=(int(n),)).copy() if n else np.zeros(0, dtype=np.uint8))
+        return out
+
     def set_exclusive_detect(self, on=True):
         """Engines of a software pipeline take turns on the detection kernel (r433_batch_set_exclusive_detect)."""
         _lib.check(self.L.r433_batch_set_exclusive_detect(self.h, int(on)), "r433_batch_set_exclusive_detect", self.L)

@@ -215,6 +215,11 @@ template <typename T> static inline T atomicOr(T *p, T v)
     return o;
 }
 
+#define __ATOMIC_RELAXED_HIP 0
+#define __HIP_MEMORY_SCOPE_AGENT 4
+template <typename T> static inline T __hip_atomic_load(T const *p, int, int) { return *p; }
+static inline void __threadfence() {}
+
 // ---- runtime API subset ----
 typedef int hipError_t;
 typedef void *hipStream_t;

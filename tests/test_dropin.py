@@ -217,3 +217,30 @@ def test_hip_seam_variant(tmp_path):
     check_batch(HIP_SEAM, tmp_path, range(8))
     check_analyzer(HIP_SEAM, tmp_path)
     check_config3(HIP_SEAM, tmp_path)
+
+
+def check_pulse_dumpers(binary, tmp_path):
+    """-w out.ook / out.u8 next to the JSON: package dumps in reference order, the logic bytes of every capture."""
+    names = write_ook_files(tmp_path, [21, 22]) + ["long_433.92M_250k.cu8"]
+    np.concatenate([synth.ook_stream(100 + k)[0] for k in range(5)]).tofile(tmp_path / "long_433.92M_250k.cu8")
+    outs = {}
+    for tag, b in (("ref", REF), ("got", binary)):
+        args = file_args(names) + ["-F", "json", "-w", f"{tag}.u8", "-w", f"{tag}.ook"]
+        outs[tag] = run_cli(b, args, tmp_path)
+    assert outs["ref"] == outs["got"]
+    assert (tmp_path / "ref.u8").read_bytes() == (tmp_path / "got.u8").read_bytes()
+    assert (tmp_path / "ref.u8").stat().st_size == 2 * 65536 + 5 * 65536
+    a, b = (tmp_path / "ref.ook").read_text().splitlines(), (tmp_path / "got.ook").read_text().splitlines()
+    wall = (";received", ";timestamp", ";created")  # wall-clock lines
+    assert [l for l in a if not l.startswith(wall)] == [l for l in b if not l.startswith(wall)]
+
+
+def test_emu_pulse_dumpers(tmp_path):
+    _ensure_built(EMU)
+    check_pulse_dumpers(EMU, tmp_path)
+
+
+@pytest.mark.gpu
+def test_hip_pulse_dumpers(tmp_path):
+    _ensure_built(HIP)
+    check_pulse_dumpers(HIP, tmp_path)
