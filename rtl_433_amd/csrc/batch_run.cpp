@@ -105,8 +105,9 @@ int run_size_buffers(RunCtx &r)
 
     // arena: worst case is one (pulse, gap) pair per 20 samples plus headers; start at ~1 B/sample
     r.want_stride = std::max<uint32_t>(16384u, ((r.max_samples + 4096u) + 15u) & ~15u);
-    if (b->arena_stride < r.want_stride)
-        b->arena_stride = r.want_stride;
+    // sized from THIS run's longest piece (a capture here, a segment once the plan is known) times what earlier overflows
+    // taught; never inherited from a run with longer captures
+    b->arena_stride = (uint32_t)std::min<uint64_t>((uint64_t)r.want_stride * b->arena_growth, 1u << 30);
 
     if (b->profiling)
         HIP_TRY(hipEventRecord(b->ev[0], r.st));
@@ -270,8 +271,8 @@ int run_plan(RunCtx &r)
         return rc;
     r.n_planned = r.split ? (uint32_t)r.segs.size() : r.n_streams;
     r.n_slots = r.split ? 3 * r.n_planned : r.n_streams; // + re-run slots for cuts that have to be dropped
-    if (r.split && b->arena_stride == r.want_stride) // sized for whole captures above: segments need less
-        b->arena_stride = std::max<uint32_t>(16384u, ((r.max_seg_samples + 4096u) + 15u) & ~15u);
+    if (r.split) // sized for whole captures above: segments need less (merged pieces that outgrow it take the overflow retry)
+        b->arena_stride = (uint32_t)std::min<uint64_t>((uint64_t)std::max<uint32_t>(16384u, ((r.max_seg_samples + 4096u) + 15u) & ~15u) * b->arena_growth, 1u << 30);
     if ((rc = b->d_ring.ensure((size_t)r.n_slots * R433_PD_MAX_PULSES)) || (rc = b->d_state.ensure(r.n_slots))
             || (rc = b->d_pkg_base.ensure(r.n_slots)) || (rc = b->h_state.ensure(r.n_slots)) || (rc = b->d_order.ensure(r.n_slots))
             || (rc = b->d_segs.ensure(r.n_slots)))
@@ -505,7 +506,8 @@ int run_detect(RunCtx &r)
             break;
         if (attempt >= 6 || b->arena_stride > (1u << 28))
             return fail(R433_EOVERFLOW, "package arena overflow (stride %u)", b->arena_stride);
-        b->arena_stride *= 4;
+        b->arena_growth *= 4;
+        b->arena_stride = (uint32_t)std::min<uint64_t>((uint64_t)b->arena_stride * 4, 1u << 30);
     }
     return 0;
 }
