@@ -39,7 +39,11 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, timing=False):
+    """timing=True: the development variant lib/librtl433hip_timing.so whose detection kernel keeps per-phase shader
+    clocks (R433_DEBUG_TIMING, tools/kbench.py --debug 1024); the product library is built without that code."""
+    if timing:
+        return _build_variant("librtl433hip_timing.so", ["-DR433_KERNEL_TIMING"], verbose)
     if not force and not _stale():
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
@@ -67,6 +71,29 @@ def build(force=False, verbose=False):
     return OUT
 
 
+def _build_variant(name, extra, verbose):
+    out = os.path.join(OUT_DIR, name)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INC, f) for f in os.listdir(INC)]
+    if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    hipcc = _hipcc()
+    objs, procs = [], []
+    tmp = os.path.join(OUT_DIR, "_" + name)
+    os.makedirs(tmp, exist_ok=True)
+    for src in SOURCES:
+        obj = os.path.join(tmp, src.rsplit(".", 1)[0] + ".o")
+        cmd = [hipcc] + FLAGS + extra + ["-I", INC, "-I", CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, p in procs:
+        o, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{o.decode(errors='replace')}")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", out] + objs)
+    shutil.rmtree(tmp)
+    return out
+
+
 def build_seam(lib_dir, lib_name, out):
     """librtl433seam.so: plain host C++ (no device code), linked against the library whose C ABI it wraps."""
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-I", INC, os.path.join(CSRC, "ref_seam.cpp"), "-o", out,
@@ -76,4 +103,4 @@ def build_seam(lib_dir, lib_name, out):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, timing="--timing" in sys.argv))

@@ -47,9 +47,8 @@ namespace {
 
 constexpr int kChunk = 32;          // samples per lane in phase B
 constexpr int kTile = 64 * kChunk;  // samples per tile
-constexpr int kWarmChunks = 3;      // chunks a lane reads before its own
-constexpr int kWarmSkip = 24;       // ... minus their first 24 samples: 72 warm-up samples, 0.854^72 * 2^16 = 0.77 < 1, 0.727^72 * 2^32 = 0.46 < 1
-                                    // (whether the two tracks have met is CHECKED, never assumed: a shorter warm-up can only cost resolve rounds)
+constexpr int kWarmChunks = 3;      // 96 warm-up samples: 0.854^96 * 2^16 < 1, 0.727^96 * 2^32 < 1 (72 were tried: the bound
+                                    // still holds in the reals, but truncation keeps tracks one apart longer -- twice the resolve rounds)
 constexpr int kRow = 512;           // samples per phase-A row (8 per lane)
 constexpr int kRows = kTile / kRow;
 constexpr int kPitch16 = kChunk * 2 + 16;  // LDS pitch of a chunk of 16-bit samples: conflict-free b128 per lane
@@ -329,11 +328,15 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
     int seam_end[4] = {carry_ya, carry_xa, carry_yf, carry_ff}; // SEAM: the carries after the last sample
 
     // profiling aid (RUN_DBG_TIMING): shader-clock ticks per phase, returned in unused StreamState slots
+#ifdef R433_KERNEL_TIMING // a development build (python -m rtl_433_amd.build --timing): the counters cost registers in the hot loops
     bool const timing = (p.flags & RUN_DBG_TIMING) != 0;
+#else
+    constexpr bool timing = false;
+#endif
     // phase timing (RUN_DBG_TIMING only): A+B, idle, gap, pulse, gap-start, general step, resolve, iterations.
     // In LDS behind a scalar branch: an array in registers costs a select chain per update even when unused.
-    __shared__ long long s_tk[8];
-    if (timing && lane < 8)
+    __shared__ long long s_tk[16]; // 8..15: inside the train engine (window loads, pulse prologue, averages, candidate check, debounce, gap, chunk skip, legs)
+    if (timing && lane < 16)
         s_tk[lane] = 0;
     auto tick = [&](int slot, long long since) {
         if (timing) {
@@ -520,13 +523,12 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
             tf16.lo = -32768, tf16.hi = 32767;
             tf32.lo = INT32_MIN, tf32.hi = INT32_MAX;
             xa1 = ff1 = 0; // lanes 0..2 of an establishing tile have no history at all: never proven, never used
-            if (lane >= kWarmChunks) { // the warm-up starts kWarmSkip samples into chunk `first`: its predecessor is in that chunk
-                xa1 = (int)*(uint16_t const *)(s_env + first * kPitch16 + (kWarmSkip - 1) * 2);
-                ff1 = SS == 2 ? (int)*(int16_t const *)(s_f + first * G::f_pitch + (kWarmSkip - 1) * 2)
-                              : *(int const *)(s_f + first * G::f_pitch + (kWarmSkip - 1) * 4);
+            if (first > 0) {
+                xa1 = (int)*(uint16_t const *)(s_env + (first - 1) * kPitch16 + (kChunk - 1) * 2);
+                ff1 = SS == 2 ? (int)*(int16_t const *)(s_f + (first - 1) * G::f_pitch + (kChunk - 1) * 2)
+                              : *(int const *)(s_f + (first - 1) * G::f_pitch + (kChunk - 1) * 4);
             }
         }
-        bool const skip_head = !from_carry && lane >= kWarmChunks; // my first warm-up chunk starts at sample kWarmSkip
         ta.ok = tf16.ok = tf32.ok = 1;
 
         ChunkStatus sa, sf; // AM, FM
@@ -538,10 +540,10 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
         int cap_ya = 0, cap_xa = 0, cap_yf = 0, cap_ff = 0; // SEAM: the state right after my chunk's last valid sample
 
         // one chunk of 32 steps for both filters; MAIN = my own chunk (publish, statistics)
-        auto chunk_pass = [&](int c, auto main_tag, int g0) {
+        auto chunk_pass = [&](int c, auto main_tag) {
             constexpr bool MAIN = decltype(main_tag)::value;
             // a frame starts here: the AM filter state keeps x[-1] in an int16 slot (baseband.c:166-168)
-            if (((fs_mask >> c) & 1ull) && g0 == 0)
+            if ((fs_mask >> c) & 1ull)
                 xa1 = (int)(int16_t)xa1;
             if (MAIN) {
                 sa.start_known = ta.exact();
@@ -556,7 +558,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                 }
             }
 #pragma unroll 1
-            for (int g = g0; g < kChunk / 8; ++g) {
+            for (int g = 0; g < kChunk / 8; ++g) {
                 uint4 const e4 = *(uint4 const *)(s_env + c * kPitch16 + g * 16);
                 uint32_t const ew[4] = {e4.x, e4.y, e4.z, e4.w};
                 uint4 f4a = make_uint4(0, 0, 0, 0), f4b = make_uint4(0, 0, 0, 0);
@@ -630,9 +632,9 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
         for (int q = 0; q < kWarmChunks; ++q) {
             int const c = lane - kWarmChunks + q; // chunk being read
             if (c >= 0)
-                chunk_pass(c, std::false_type{}, q == 0 && skip_head ? kWarmSkip / 8 : 0);
+                chunk_pass(c, std::false_type{});
         }
-        chunk_pass(lane, std::true_type{}, 0);
+        chunk_pass(lane, std::true_type{});
         sa.end_known = ta.exact();
         sa.y_end = ta.lo;
         if (!FM) {
@@ -720,6 +722,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                 if (__ballot(bad))
                     det.overflow = 3; // refuse the result (the host reports it)
                 if (__ballot(rerun)) {
+                    CNT(15, 1); // resolve rounds with an exact re-run
                     // exact re-run of my chunk from the proven carry
                     int x1 = 0, f1 = 0;
                     if (rerun) {
@@ -1060,7 +1063,8 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
             // levels outside int16) leaves the engine for the legs and the exact general step below.
             bool const regular = det.state != ST_IDLE && det.ook_num >= 1 && det.fsk_num <= 16 && !det.eop_spurious
                     && det.ook_num + 70 < R433_PD_MAX_PULSES && det.high >= 0 && det.high <= 32767 && cfg.min_high >= 0
-                    && cfg.min_high <= 32767;
+                    && cfg.min_high <= 32767 && det.low >= -1 && det.low <= 32767 && cfg.min_high >= 1 && cfg.fixed_high >= 0
+                    && cfg.fixed_high <= 32767; // (the floor sits at -1 half of the time over digital silence)
             bool engine_ran = false;
             if (uni((int)regular) && !(p.flags & RUN_NO_TRAIN_ENGINE)) {
                 engine_ran = true;
@@ -1078,12 +1082,10 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                 v2s hv = {(short)det.high, (short)det.ook_f1};
                 v2s const floor_v = {(short)cfg.min_high, (short)-32768};
                 v2s const m63 = {63, 63};
-                auto thr_of = [&](int level) -> int {
-                    int t = (int)(int16_t)((low + min(level, cfg.max_high)) / 2);
-                    if (cfg.fixed_high != 0)
-                        t = (int)(int16_t)cfg.fixed_high;
-                    return t;
-                };
+                // thresholds (pulse_detect.c:300-304): the floor is >= -1 and every level >= min_high >= 1 here, so the sums are
+                // in [0, 49150]: the C divisions are shifts and the int16 narrowing is the identity
+                int const thr_fixed = uni(cfg.fixed_high), max_high = uni(cfg.max_high);
+                auto thr_of = [&](int level) -> int { return thr_fixed != 0 ? thr_fixed : (low + min(level, max_high)) >> 1; };
                 int eop_lim = 10 * min(max(mx, cfg.per_ms), 10 * cfg.per_ms); // pulse_detect.c:446-450
                 int thi = 0;                   // rising-edge level of the frozen averages (debounce and gap)
                 unsigned long long m_hi = 0;   // lanes above it in this block
@@ -1095,6 +1097,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                 // The engine's window: 64 samples from k on, wherever k is (the legs below keep the blocks aligned; here a
                 // window that begins with a pulse lets the averages run from lane 0 without a rotation).
                 auto load_window = [&]() {
+                    long long const t_w = now();
                     CNT(14, 1); // engine window loads
                     base = k;
                     e = min(base + 64, lim_u);
@@ -1110,24 +1113,30 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                     okp = __ballot(a64_l >= fl6 && f64_l >= 0);
                     okn = __ballot(a64_l >= fl6 && f64_l <= 0 && f64_l > -512);
                     m_hi_ok = false;
+                    tick(8, t_w);
                 };
                 for (;;) {
                     CNT(13, 1); // engine legs
+                    if (timing && lane == 0)
+                        s_tk[15] += 1;
+                    long long const t_leg = now();
                     // a pulse that begins in the last third of a window gets a window of its own
                     if (st == ST_PULSE && k - base > 40 && k < e && e < lim_u)
                         load_window();
                     if (st == ST_PULSE) {
                         int const h0 = uni((int)hv[0]);
                         int const thr_ub = thr_of(max(h0, amax_ub) + 1);
-                        int const tlo_ub = thr_ub - (int)(int16_t)(thr_ub / 8);
+                        int const tlo_ub = thr_ub - (thr_ub >> 3);
                         unsigned long long cand = __ballot(am_l < tlo_ub) & vmask & (~0ull << (k - base));
                         int const i0 = k;
                         int j = k;
                         bool fall = false;
                         m_hi_ok = false;
+                        tick(9, t_leg);
                         for (;;) {
                             k = cand ? base + (__ffsll(cand) - 1) : e;
                             int const kk = k;
+                            long long const t_ema = now();
                             while (j < kk) { // the averages over [j, kk): see the pulse leg below for the three forms
                                 int const f1s = uni((int)hv[1]);
                                 bool const neg = f1s < 0;
@@ -1141,8 +1150,14 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                                     int const nb = len >> 3;
                                     v2s x = hv * sv;
                                     ema_groups(x, rot, nb);
-                                    hv = x * sv;
                                     j += nb * 8;
+                                    int const rem = len - nb * 8; // the rest of the run right away: same form, lane numbers computed
+                                    for (int u = 0; u < rem; ++u) {
+                                        v2s const in = as_v2s(__builtin_amdgcn_readlane(sel, j - base + u));
+                                        x = x + (in - (x >> 6));
+                                    }
+                                    j += rem;
+                                    hv = x * sv;
                                     continue;
                                 }
                                 if (len > 0) {
@@ -1165,13 +1180,16 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                                 }
                                 j += cnt;
                             }
+                            tick(10, t_ema);
                             if (k >= e)
                                 break;
+                            long long const t_cand = now();
                             // candidate: decide with the exact level.  Not an edge -> it is one more pulse sample.
                             int const thr = thr_of(uni((int)hv[0]));
                             int const am_k = __builtin_amdgcn_readlane(am_l, k - base);
-                            if (am_k < thr - (int)(int16_t)(thr / 8)) {
+                            if (am_k < thr - (thr >> 3)) {
                                 fall = true;
+                                tick(11, t_cand);
                                 break;
                             }
                             v2s const in = as_v2s(__builtin_amdgcn_readlane(in_pk_l, k - base));
@@ -1179,7 +1197,9 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                             hv = pk_max(hv - q + in, floor_v);
                             j = k + 1;
                             cand &= cand - 1;
+                            tick(11, t_cand);
                         }
+                        long long const t_pe = now();
                         run += k - i0;
                         if (fall) {
                             if (run + 1 < 10) { // a spurious short pulse: the general step knows what that means
@@ -1193,11 +1213,13 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                             st = ST_GAP_START;
                             k += 1;
                         }
+                        tick(9, t_pe);
                     }
                     else {
+                        int const st_in = st;
                         if (!m_hi_ok) {
                             int const thr = thr_of(uni((int)hv[0]));
-                            thi = thr + (int)(int16_t)(thr / 8);
+                            thi = thr + (thr >> 3);
                             m_hi = __ballot(am_l > thi) & vmask;
                             m_hi_ok = true;
                         }
@@ -1242,16 +1264,18 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                                 }
                             }
                         }
+                        tick(st_in == ST_GAP_START ? 12 : 13, t_leg);
                     }
                     if (k < e)
                         continue;
+                    long long const t_bu = now();
                     // the block is used up
                     if (k >= lim_u)
                         break;
                     if (st == ST_GAP) { // whole chunks without a sample above the level cannot end the gap
                         if (!m_hi_ok) {
                             int const thr = thr_of(uni((int)hv[0]));
-                            thi = thr + (int)(int16_t)(thr / 8);
+                            thi = thr + (thr >> 3);
                         }
                         unsigned long long const m = __ballot(lane >= (k >> 5) && my_cmax > thi);
                         int const togo = max(0, eop_lim - run);
@@ -1266,6 +1290,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                     }
                     if (n_pairs + 70 >= R433_PD_MAX_PULSES) // the 1200-pulse cap is the general step's business
                         break;
+                    tick(14, t_bu);
                     load_window();
                 }
                 det.state = st;
@@ -1764,6 +1789,8 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
         if (timing) {
             S.lpf_y = (int)(s_tk[0] >> 6), S.lpf_x = (int)(s_tk[1] >> 6), S.fm_xr = (int)(s_tk[2] >> 6), S.fm_xi = (int)(s_tk[3] >> 6);
             S.fm_xf = (int)(s_tk[4] >> 6), S.fm_yf = (int)(s_tk[5] >> 6), S.state = (int)(s_tk[6] >> 6), S.run = (int)s_tk[7];
+            S.max_pulse = (int)(s_tk[8] >> 6), S.lead_in = (int)(s_tk[9] >> 6), S.low = (int)(s_tk[10] >> 6), S.high = (int)(s_tk[11] >> 6);
+            S.f_state = (int)(s_tk[12] >> 6), S.f_f1 = (int)(s_tk[13] >> 6), S.f_f2 = (int)(s_tk[14] >> 6), S.f_vmax = (int)s_tk[15];
         }
     }
 }

@@ -44,7 +44,12 @@ else:
 d = torch.from_numpy(host).cuda()
 ds = [d] + [torch.from_numpy(np.roll(host, k + 1, axis=0).copy()).cuda() for k in range(a.rotate - 1)]
 devs = None if a.nodevs else load_device_table()[0]
-eng = BatchEngine(cfg, devs, profiling=True)
+lib = None
+if a.debug & 1024:  # the per-phase clocks live in the development build of the library only
+    import ctypes
+    from rtl_433_amd import _lib, build
+    lib = _lib.bind(ctypes.CDLL(build.build(timing=True)))
+eng = BatchEngine(cfg, devs, profiling=True, library=lib)
 if a.split:
     eng.set_split(a.split)
 if a.debug:
@@ -87,6 +92,12 @@ if a.debug & 1024:
     for j, nm in enumerate(names):
         print(f"  {nm:9s} mean={cols[:, j].mean():12.0f}  slowest-capture={cols[worst, j]:12d}")
     print(f"  total     mean={tot.mean():12.0f}  slowest={tot[worst]} (capture {worst})  fastest={tot[order[0]]}")
+    # inside the train engine (StreamState slots max_pulse, lead_in, low, high, f_state, f_f1, f_f2, f_vmax)
+    en = ["window loads", "pulse pro/epilogue", "averages", "candidate check", "debounce legs", "gap legs", "block end + chunk skip", "legs (count)"]
+    ecols = st[:, [8, 9, 10, 11, 13, 14, 15, 16]].astype(np.int64)
+    ecols[:, :7] *= 64
+    for j, nm in enumerate(en):
+        print(f"  engine {nm:24s} mean={ecols[:, j].mean():12.0f}  slowest-capture={ecols[worst, j]:12d}")
     metas = [synth.ook_stream(int(s))[1] for s in order[-5:]]
     for s, m in zip(order[-5:], metas):
         print("  slow capture", int(s), {k: m[k] for k in ("family", "nbits", "short", "amp", "sigma", "repeats", "used")})
