@@ -76,6 +76,19 @@ __device__ __forceinline__ int wave_sum(int v)
     return v;
 }
 
+// The lanes of ONE wavefront exchange data through LDS: its own LDS instructions execute in order, so all that is needed is
+// that the compiler keeps them in order (no workgroup barrier -- the other wavefront of the workgroup runs other code).
+__device__ __forceinline__ void wave_sync()
+{
+#ifdef R433_EMU
+    (void)emu::exchange<int>(0, 77); // the emulator runs lanes as fibers: a rendezvous makes every lane's stores land
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+}
+
 __device__ __forceinline__ int ld16(uint8_t const *buf, int i)
 {
     return (int)*(int16_t const *)(buf + i * 2);
@@ -266,16 +279,27 @@ __device__ __forceinline__ void ema_groups(v2s &x, int rot, int nb)
     ema_group8<56>(x, rot);
 }
 
-template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_wave(StreamParams p)
+template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_wave(StreamParams p)
 {
     using G = Geom<SS>;
     __shared__ __attribute__((aligned(16))) uint8_t s_env[64 * kPitch16];
     __shared__ __attribute__((aligned(16))) uint8_t s_f[64 * G::f_pitch];
-    __shared__ __attribute__((aligned(16))) uint8_t s_am[64 * kPitchOut];
-    __shared__ __attribute__((aligned(16))) uint8_t s_fm[64 * kPitchOut];
-    __shared__ int s_cmax[64], s_cmin[64];
+    // Two wavefronts per capture when launched with 128 threads: wavefront 0 PRODUCES (phases A + B of tile t + 1 into
+    // buffer (t + 1) & 1) while wavefront 1 CONSUMES (phase C of tile t from buffer t & 1); one workgroup barrier per tile.
+    // The two sit on different SIMDs of the CU (a workgroup's wavefronts are dealt out round-robin), each next to a
+    // wavefront of another capture, so a SIMD issues for two wavefronts instead of one.  Launched with 64 threads the one
+    // wavefront does both in turn (filters-only launches; R433_DEBUG_ONE_WAVE for A/B timing).
+    __shared__ __attribute__((aligned(16))) uint8_t s_am[2 * 64 * kPitchOut];
+    __shared__ __attribute__((aligned(16))) uint8_t s_fm[2 * 64 * kPitchOut];
+    __shared__ int s_cmax[2 * 64], s_cmin[2 * 64];
+    __shared__ int s_pflag[2]; // producer -> consumer, per buffer: the establishing tile could not be proven
+    __shared__ int s_pover;    // producer -> consumer: a filter carry was refused (det.overflow codes 2, 3)
 
-    int const lane = (int)threadIdx.x;
+    int const lane = (int)threadIdx.x & 63;
+    int const wave = (int)threadIdx.x >> 6;
+    bool const solo = blockDim.x == 64; // one wavefront does both halves
+    if (threadIdx.x == 0)
+        s_pover = 0;
     uint32_t const s = blockIdx.x; // wavefront = one capture, or one segment of a split capture
     uint32_t const cap = p.segs ? p.segs[s].capture : s;
     uint32_t const my_bytes = p.stream_bytes ? p.stream_bytes[cap] : p.uniform_bytes;
@@ -391,16 +415,20 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
             pf[k] = v;
         }
     };
-    issue_loads(tile_first);
+    if (wave == 0)
+        issue_loads(tile_first);
+    int p_fail = 0, p_over = 0; // producer side of seg_fail / det.overflow
 
-    for (uint32_t tile = tile_first; tile < tile_end; ++tile) {
+    // ======================================= the producer: phases A and B of one tile =======================================
+    auto produce = [&](uint32_t tile, int buf) {
         uint32_t const t0 = tile * kTile;                        // absolute sample index of the tile
         int const n_t = (int)min((uint32_t)kTile, seg_end - t0); // valid samples in it
         bool const warm = !seg_first && tile == tile_first;      // the establishing tile of a later segment
+        uint8_t *const p_am = s_am + buf * (64 * kPitchOut), *const p_fm = s_fm + buf * (64 * kPitchOut);
 
         // ================= phase A: envelope + discriminator, 8 samples per lane and row =================
         long long const t_tile = now();
-        __syncthreads(); // previous tile's readers are done with the LDS buffers
+        wave_sync(); // phase B of the tile before this one is done with s_env / s_f
 #pragma unroll
         for (int r = 0; r < kRows; ++r) {
             uint32_t wd[8];
@@ -496,10 +524,10 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                 }
             }
         }
-        issue_loads(tile + 1); // in flight while phases B and C run
-        __syncthreads();
+        issue_loads(tile + 1); // in flight while phase B runs
+        wave_sync();
         if (p.flags & RUN_DBG_SKIP_FILTERS)
-            continue;
+            return;
 
         // ================= phase B: the two low-passes, lane = chunk of 32 samples =================
         int const cs = lane * kChunk;                       // chunk start inside the tile
@@ -623,8 +651,8 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                     }
                 }
                 if (MAIN) {
-                    *(uint4 *)(s_am + lane * kPitchOut + g * 16) = make_uint4(oa[0], oa[1], oa[2], oa[3]);
-                    *(uint4 *)(s_fm + lane * kPitchOut + g * 16) = make_uint4(of[0], of[1], of[2], of[3]);
+                    *(uint4 *)(p_am + lane * kPitchOut + g * 16) = make_uint4(oa[0], oa[1], oa[2], oa[3]);
+                    *(uint4 *)(p_fm + lane * kPitchOut + g * 16) = make_uint4(of[0], of[1], of[2], of[3]);
                 }
             }
         };
@@ -674,9 +702,9 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                     break;
                 if (round > 64) { // cannot happen in a regular tile (the first open lane settles every round)
                     if (warm)
-                        seg_fail = 1; // a stall reaching back past the establishing tile: the carry is not provable here
+                        p_fail = 1; // a stall reaching back past the establishing tile: the carry is not provable here
                     else
-                        det.overflow = 2;
+                        p_over = 2;
                     break;
                 }
                 // What does the carry look like when it leaves each lane?  CONST(y_end) where the end is
@@ -706,7 +734,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                         // every step of my chunk leaves y0 where it is: outputs are constant
                         int const out = (which == 0 || SS == 2) ? y0 : (int)(int16_t)(y0 >> 16);
                         uint32_t const w2 = ((uint32_t)out & 0xffffu) * 0x10001u;
-                        uint8_t *dst = (which == 0 ? s_am : s_fm) + lane * kPitchOut;
+                        uint8_t *dst = (which == 0 ? p_am : p_fm) + lane * kPitchOut;
                         for (int g = 0; g < kChunk / 8; ++g)
                             *(uint4 *)(dst + g * 16) = make_uint4(w2, w2, w2, w2);
                         st.y_end = y0;
@@ -720,7 +748,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                     }
                 }
                 if (__ballot(bad))
-                    det.overflow = 3; // refuse the result (the host reports it)
+                    p_over = 3; // refuse the result (the host reports it)
                 if (__ballot(rerun)) {
                     CNT(15, 1); // resolve rounds with an exact re-run
                     // exact re-run of my chunk from the proven carry
@@ -763,7 +791,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                                 f1 = f;
                                 out = (int)(int16_t)(y >> 16);
                             }
-                            *(int16_t *)((which == 0 ? s_am : s_fm) + lane * kPitchOut + i * 2) = (int16_t)out;
+                            *(int16_t *)((which == 0 ? p_am : p_fm) + lane * kPitchOut + i * 2) = (int16_t)out;
                         }
                     }
                     if (rerun) {
@@ -779,20 +807,69 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
         carry_yf = __builtin_amdgcn_readlane(sf.y_end, 63);
         carry_xa = __builtin_amdgcn_readlane(xa1, 63);
         carry_ff = __builtin_amdgcn_readlane(ff1, 63);
-        s_cmax[lane] = cmax;
-        s_cmin[lane] = cmin;
+        s_cmax[buf * 64 + lane] = cmax;
+        s_cmin[buf * 64 + lane] = cmin;
+        if (p_over && lane == 0)
+            s_pover = p_over;
 
         if (warm) {
             // ---- establishing tile of a later segment: no detection here.  The carries just taken must be
             // proven, and so must the last sixteen chunks (the floor is walked over their samples).
             bool const tail_ok = lane < 64 - kFloorWindow / kChunk || (sa.start_known && sa.end_known && sf.start_known && sf.end_known);
             if (__ballot(!tail_ok))
+                p_fail = 1;
+            if (lane == 0)
+                s_pflag[buf] = p_fail;
+            return; // the consumer walks the floor over this tile
+        }
+        // per-frame envelope sums (u32, wraps like the reference's accumulator, baseband.c:39-44)
+        if (p.frame_sums && seg_primary) {
+            uint32_t const f_first = t0 / F, f_last = (t0 + (uint32_t)n_t - 1) / F;
+            uint32_t const my_frame = (t0 + (uint32_t)cs) / F;
+            for (uint32_t f = f_first; f <= f_last; ++f) {
+                int const part = wave_sum(cnt > 0 && my_frame == f ? csum : 0);
+                if (lane == 0 && f < p.frames_cap) // several segments of a capture may share a frame
+                    atomicAdd(&p.frame_sums[(uint64_t)cap * p.frames_cap + f], (uint32_t)part);
+            }
+        }
+        wave_sync();
+
+        if (p.tap_am && seg_primary) {
+            for (int idx = lane; idx < n_t; idx += 64) {
+                uint64_t o = (uint64_t)cap * p.tap_stride + t0 + (uint32_t)idx;
+                p.tap_am[o] = (int16_t)ld16(p_am, idx);
+                p.tap_fm[o] = (int16_t)ld16(p_fm, idx);
+            }
+        }
+
+        if (SEAM) { // filters only: remember the carries after the frame's last sample (this tile may hold it)
+            int const L = (n_t - 1) >> 5;
+            int const ea = seam_main_a ? cap_ya : sa.y_end, ef = seam_main_f ? cap_yf : sf.y_end;
+            seam_end[0] = __builtin_amdgcn_readlane(ea, L);
+            seam_end[1] = __builtin_amdgcn_readlane(cap_xa, L);
+            seam_end[2] = __builtin_amdgcn_readlane(ef, L);
+            seam_end[3] = __builtin_amdgcn_readlane(cap_ff, L);
+            return;
+        }
+        tick(0, t_tile);
+    };
+
+
+    // ======================================= the consumer: phase C of one tile =======================================
+    auto consume = [&](uint32_t tile, int buf) {
+        uint32_t const t0 = tile * kTile;
+        int const n_t = (int)min((uint32_t)kTile, seg_end - t0);
+        bool const warm = !seg_first && tile == tile_first;
+        uint8_t const *const c_am = s_am + buf * (64 * kPitchOut), *const c_fm = s_fm + buf * (64 * kPitchOut);
+        if (p.flags & RUN_DBG_SKIP_FILTERS)
+            return;
+        if (warm) {
+            if (s_pflag[buf])
                 seg_fail = 1;
-            __syncthreads();
             // Noise floor at the segment's first sample: the detector is assumed idle over the last 512
             // samples with a floor of the assumed parity somewhere inside the tile's sample range; both
             // extremes of that parity are walked and must meet (see the lazy floor below).
-            int rmax = lane >= 4 ? cmax : -0x7fffffff, rmin = lane >= 4 ? cmin : 0x7fffffff;
+            int rmax = lane >= 4 ? s_cmax[buf * 64 + lane] : -0x7fffffff, rmin = lane >= 4 ? s_cmin[buf * 64 + lane] : 0x7fffffff;
             for (int o = 32; o > 0; o >>= 1) {
                 rmax = max(rmax, __shfl_xor(rmax, o, 64));
                 rmin = min(rmin, __shfl_xor(rmin, o, 64));
@@ -804,7 +881,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
             a += (a ^ par) & 1;
             b -= (b ^ par) & 1;
             for (int w = kTile - kFloorWindow; w < kTile; w += 64) { // chunks 48..63: proven above
-                int const v = ld16(s_am, w + lane);
+                int const v = ld16(c_am, w + lane);
 #pragma unroll 8
                 for (int u = 0; u < 64; ++u) {
                     int const x = __builtin_amdgcn_readlane(v, u);
@@ -818,39 +895,9 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
             det.high = max(cfg.ratio * a, cfg.min_high);
             seg_init_low = a;
             seg_init_high = det.high;
-            continue;
+            return;
         }
 
-        // per-frame envelope sums (u32, wraps like the reference's accumulator, baseband.c:39-44)
-        if (p.frame_sums && seg_primary) {
-            uint32_t const f_first = t0 / F, f_last = (t0 + (uint32_t)n_t - 1) / F;
-            uint32_t const my_frame = (t0 + (uint32_t)cs) / F;
-            for (uint32_t f = f_first; f <= f_last; ++f) {
-                int const part = wave_sum(cnt > 0 && my_frame == f ? csum : 0);
-                if (lane == 0 && f < p.frames_cap) // several segments of a capture may share a frame
-                    atomicAdd(&p.frame_sums[(uint64_t)cap * p.frames_cap + f], (uint32_t)part);
-            }
-        }
-        __syncthreads();
-
-        if (p.tap_am && seg_primary) {
-            for (int idx = lane; idx < n_t; idx += 64) {
-                uint64_t o = (uint64_t)cap * p.tap_stride + t0 + (uint32_t)idx;
-                p.tap_am[o] = (int16_t)ld16(s_am, idx);
-                p.tap_fm[o] = (int16_t)ld16(s_fm, idx);
-            }
-        }
-
-        if (SEAM) { // filters only: remember the carries after the frame's last sample (this tile may hold it)
-            int const L = (n_t - 1) >> 5;
-            int const ea = seam_main_a ? cap_ya : sa.y_end, ef = seam_main_f ? cap_yf : sf.y_end;
-            seam_end[0] = __builtin_amdgcn_readlane(ea, L);
-            seam_end[1] = __builtin_amdgcn_readlane(cap_xa, L);
-            seam_end[2] = __builtin_amdgcn_readlane(ef, L);
-            seam_end[3] = __builtin_amdgcn_readlane(cap_ff, L);
-            continue;
-        }
-        tick(0, t_tile);
         // ================= phase C: pulse detector =================
         int i = (p.flags & RUN_DBG_SKIP_DETECT) ? n_t : 0;
         int loaded = -1;           // block whose samples the lanes hold
@@ -861,7 +908,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
         int ff_pk_l = 0;           // fm / 64 in both halves (the package's and the FSK detector's carrier averages)
         int bmax = 0, bmin = 0;
         // chunk statistics (lane = chunk) and their suffix extrema, for jumping over whole chunks
-        int const my_cmax = s_cmax[lane], my_cmin = s_cmin[lane];
+        int const my_cmax = s_cmax[buf * 64 + lane], my_cmin = s_cmin[buf * 64 + lane];
         int sfx_max = my_cmax, sfx_min = my_cmin;
         for (int o = 1; o < 64; o <<= 1) {
             int const qa = __shfl_down(sfx_max, o, 64), qb = __shfl_down(sfx_min, o, 64);
@@ -891,7 +938,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                 a += (a ^ par) & 1; // lowest / highest candidate of that parity
                 b -= (b ^ par) & 1;
                 if (uni(b - a) <= 256) { // the two close in by at most 2 per sample: further apart they cannot meet in 128
-                    int const v0 = ld16(s_am, w0 + lane), v1 = ld16(s_am, w0 + 64 + lane); // w0 + 127 < upto <= n_t
+                    int const v0 = ld16(c_am, w0 + lane), v1 = ld16(c_am, w0 + 64 + lane); // w0 + 127 < upto <= n_t
 #pragma unroll 8
                     for (int u = 0; u < 64; ++u) {
                         int const x = __builtin_amdgcn_readlane(v0, u);
@@ -913,7 +960,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
             if (!done) {
                 lo_est = uni(lo_est);
                 for (int j0 = uni(lz_from); j0 < upto; j0 += 64) {
-                    int const v = j0 + lane < upto ? ld16(s_am, j0 + lane) : 0;
+                    int const v = j0 + lane < upto ? ld16(c_am, j0 + lane) : 0;
                     int const cntj = uni(min(64, upto - j0));
                     if (cntj == 64) { // whole blocks: constant lane numbers, no loop control (a noisy floor walks every sample)
 #pragma unroll
@@ -1036,15 +1083,15 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                     return;
                 CNT(1, 1); // block loads
                 int const il = base + lane;
-                am_l = il < n_t ? ld16(s_am, il) : 0;
-                fm_l = il < n_t ? ld16(s_fm, il) : 0;
+                am_l = il < n_t ? ld16(c_am, il) : 0;
+                fm_l = il < n_t ? ld16(c_fm, il) : 0;
                 a64_l = div64(am_l);
                 f64_l = div64(fm_l);
                 in_pk_l = (a64_l & 0xffff) | (f64_l << 16);
                 in_pkn_l = (a64_l & 0xffff) | (-f64_l << 16);
                 ff_pk_l = (f64_l & 0xffff) | (f64_l << 16);
-                bmax = uni(max(s_cmax[base >> 5], s_cmax[(base >> 5) + 1]));
-                bmin = uni(min(s_cmin[base >> 5], s_cmin[(base >> 5) + 1]));
+                bmax = uni(max(s_cmax[buf * 64 + (base >> 5)], s_cmax[buf * 64 + (base >> 5) + 1]));
+                bmin = uni(min(s_cmin[buf * 64 + (base >> 5)], s_cmin[buf * 64 + (base >> 5) + 1]));
                 loaded = base;
             };
             load_block();
@@ -1102,8 +1149,8 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                     base = k;
                     e = min(base + 64, lim_u);
                     int const il = base + lane;
-                    am_l = il < n_tu ? ld16(s_am, il) : 0;
-                    fm_l = il < n_tu ? ld16(s_fm, il) : 0;
+                    am_l = il < n_tu ? ld16(c_am, il) : 0;
+                    fm_l = il < n_tu ? ld16(c_fm, il) : 0;
                     a64_l = div64(am_l);
                     f64_l = div64(fm_l);
                     in_pk_l = (a64_l & 0xffff) | (f64_l << 16);
@@ -1759,7 +1806,34 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
         long long const t_res = now();
         resolve_low(n_t);
         tick(6, t_res); // the samples leave LDS with the tile
+    };
+
+    // tile t + 1 is produced while tile t is consumed; one barrier per tile hands a buffer over and takes one back
+    if (solo) {
+        for (uint32_t tile = tile_first; tile < tile_end; ++tile) {
+            produce(tile, 0);
+            wave_sync();
+            if (!SEAM)
+                consume(tile, 0);
+        }
     }
+    else {
+        for (uint32_t it = tile_first; it <= tile_end; ++it) {
+            if (wave == 0) {
+                if (it < tile_end)
+                    produce(it, (int)(it & 1u));
+            }
+            else if (it > tile_first) {
+                consume(it - 1, (int)((it - 1) & 1u));
+            }
+            __syncthreads();
+        }
+    }
+    if (!solo && wave == 0)
+        return; // the consumer wavefront reports
+    if (s_pover)
+        det.overflow = (uint32_t)s_pover;
+
 
     if (SEAM) {
         if (lane == 0) {
@@ -1884,7 +1958,8 @@ void launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st)
 {
     if (p.n_streams == 0)
         return;
-    dim3 grid(p.n_streams), block(64);
+    // two wavefronts per capture (producer + consumer), or one doing both in turn (development: RUN_ONE_WAVE)
+    dim3 grid(p.n_streams), block((p.flags & RUN_ONE_WAVE) ? 64 : 128);
     // FAST: no filter step can wrap and both feedback coefficients are non-negative (see Track16).
     // The AM filter always qualifies (13993 + 2*1195 <= 16384); the FM filter does for every cutoff
     // up to half the Nyquist rate, which includes the defaults.

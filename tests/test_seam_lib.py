@@ -45,7 +45,7 @@ def seam_lib(backend):
     else:
         path = os.path.join(ROOT, "rtl_433_amd", "lib", "librtl433seam.so")
     assert os.path.exists(path), path
-    return proto(C.CDLL(path, mode=C.RTLD_GLOBAL))
+    return proto(C.CDLL(path))  # RTLD_LOCAL: a global load would interpose the reference library's own lazily-bound symbols
 
 
 def proto(L):
