@@ -298,6 +298,11 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
     int const lane = (int)threadIdx.x & 63;
     int const wave = (int)threadIdx.x >> 6;
     bool const solo = blockDim.x == 64; // one wavefront does both halves
+    // role 0 produces, role 1 consumes.  Workgroups alternate which wavefront takes which role, so that the two wavefronts
+    // that end up on one SIMD are one of each kind, and the consumer -- the serial critical path -- issues first.
+    int const role = solo ? 0 : (wave ^ ((p.flags & RUN_NO_ROLE_SWAP) ? 0 : (int)(blockIdx.x & 1u)));
+    if (!solo && role == 1 && !(p.flags & RUN_NO_PRIO))
+        __builtin_amdgcn_s_setprio(3);
     if (threadIdx.x == 0)
         s_pover = 0;
     uint32_t const s = blockIdx.x; // wavefront = one capture, or one segment of a split capture
@@ -415,7 +420,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
             pf[k] = v;
         }
     };
-    if (wave == 0)
+    if (role == 0)
         issue_loads(tile_first);
     int p_fail = 0, p_over = 0; // producer side of seg_fail / det.overflow
 
@@ -1162,6 +1167,11 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                     m_hi_ok = false;
                     tick(8, t_w);
                 };
+                // Windows outside, legs inside: the window registers change at one place only (a conditional reload in the
+                // middle of the leg loop costs a register copy per value and leg).
+                bool leave = false;
+                for (;;) {
+                load_window();
                 for (;;) {
                     CNT(13, 1); // engine legs
                     if (timing && lane == 0)
@@ -1169,8 +1179,9 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                     long long const t_leg = now();
                     // a pulse that begins in the last third of a window gets a window of its own
                     if (st == ST_PULSE && k - base > 40 && k < e && e < lim_u)
-                        load_window();
+                        break;
                     if (st == ST_PULSE) {
+                        CNT(23, 1); // engine: pulse legs
                         int const h0 = uni((int)hv[0]);
                         int const thr_ub = thr_of(max(h0, amax_ub) + 1);
                         int const tlo_ub = thr_ub - (thr_ub >> 3);
@@ -1185,6 +1196,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                             int const kk = k;
                             long long const t_ema = now();
                             while (j < kk) { // the averages over [j, kk): see the pulse leg below for the three forms
+                                CNT(16, 1); // engine: runs of the averages
                                 int const f1s = uni((int)hv[1]);
                                 bool const neg = f1s < 0;
                                 unsigned long long const bad = ~((neg ? okn : okp) >> (j - base));
@@ -1197,6 +1209,9 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                                     int const nb = len >> 3;
                                     v2s x = hv * sv;
                                     ema_groups(x, rot, nb);
+                                    CNT(17, nb * 8);         // engine: samples in groups of eight
+                                    CNT(18, len - nb * 8);   // engine: the rest of such runs
+                                    CNT(22, j != base);      // engine: runs that needed a rotation
                                     j += nb * 8;
                                     int const rem = len - nb * 8; // the rest of the run right away: same form, lane numbers computed
                                     for (int u = 0; u < rem; ++u) {
@@ -1216,6 +1231,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                                         x = x + (in - (x >> 6));
                                     }
                                     hv = x * sv;
+                                    CNT(19, len); // engine: samples of short runs
                                     j += len;
                                     continue;
                                 }
@@ -1225,6 +1241,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                                     v2s const q = (hv + ((hv >> 15) & m63)) >> 6; // hv / 64, truncating toward zero
                                     hv = pk_max(hv - q + in, floor_v);
                                 }
+                                CNT(20, cnt); // engine: samples through the general form
                                 j += cnt;
                             }
                             tick(10, t_ema);
@@ -1232,6 +1249,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                                 break;
                             long long const t_cand = now();
                             // candidate: decide with the exact level.  Not an edge -> it is one more pulse sample.
+                            CNT(21, 1); // engine: candidates checked
                             int const thr = thr_of(uni((int)hv[0]));
                             int const am_k = __builtin_amdgcn_readlane(am_l, k - base);
                             if (am_k < thr - (thr >> 3)) {
@@ -1251,6 +1269,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                         if (fall) {
                             if (run + 1 < 10) { // a spurious short pulse: the general step knows what that means
                                 need_general = true;
+                                leave = true;
                                 break;
                             }
                             cur = run + 1; // pulse_detect.c:340-357: the width is known, the debounce begins
@@ -1289,7 +1308,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                                 k = e;
                             }
                         }
-                        else { // ST_GAP, pulse_detect.c:422-470
+                        if (st == ST_GAP && k < e) { // pulse_detect.c:422-470; also right after the debounce above (ka is still the one)
                             int const togo = max(0, eop_lim - run);
                             int const ke = togo < e - k ? k + togo : e; // first sample whose count ends the package
                             if (ka <= ke && ka < e) {
@@ -1307,6 +1326,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                                 k = ke;
                                 if (ke < e) { // the package ends here: the general step emits it
                                     need_general = true;
+                                    leave = true;
                                     break;
                                 }
                             }
@@ -1316,7 +1336,8 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                     if (k < e)
                         continue;
                     long long const t_bu = now();
-                    // the block is used up
+                    // the window is used up
+                    leave = true;
                     if (k >= lim_u)
                         break;
                     if (st == ST_GAP) { // whole chunks without a sample above the level cannot end the gap
@@ -1338,7 +1359,11 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                     if (n_pairs + 70 >= R433_PD_MAX_PULSES) // the 1200-pulse cap is the general step's business
                         break;
                     tick(14, t_bu);
-                    load_window();
+                    leave = false;
+                    break;
+                }
+                if (leave)
+                    break;
                 }
                 det.state = st;
                 det.run = run;
@@ -1819,7 +1844,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
     }
     else {
         for (uint32_t it = tile_first; it <= tile_end; ++it) {
-            if (wave == 0) {
+            if (role == 0) {
                 if (it < tile_end)
                     produce(it, (int)(it & 1u));
             }
@@ -1829,7 +1854,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
             __syncthreads();
         }
     }
-    if (!solo && wave == 0)
+    if (!solo && role == 0)
         return; // the consumer wavefront reports
     if (s_pover)
         det.overflow = (uint32_t)s_pover;

@@ -184,6 +184,7 @@ static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long l
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 static inline unsigned __lane_id() { return emu::tid() & 63u; }
 static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 
 // IEEE single ops that must not be contracted (g++ -ffp-contract=off keeps them separate)
