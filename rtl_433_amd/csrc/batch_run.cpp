@@ -526,7 +526,8 @@ int run_slice_and_mirror(RunCtx &r)
     if ((rc = b->d_dir_stream.ensure(max_pkgs)) || (rc = b->d_dir_off.ensure(max_pkgs))
             || (rc = b->d_rec_bytes.ensure(max_pkgs)) || (rc = b->d_rec_off.ensure(max_pkgs))
             || (rc = b->d_pkg_bytes.ensure(max_pkgs)) || (rc = b->d_pkg_off.ensure(max_pkgs))
-            || (rc = b->d_sizes.ensure((size_t)max_pkgs * std::max<uint32_t>(n_devs, 1))))
+            || (rc = b->d_sizes.ensure((size_t)max_pkgs * std::max<uint32_t>(n_devs, 1)))
+            || (rc = b->d_dev_off.ensure((size_t)max_pkgs * std::max<uint32_t>(n_devs, 1))))
         return rc;
 
     launch_directory(b->d_arena.p, b->arena_stride, b->d_state.p, r.split ? b->d_order.p : nullptr, r.n_order, b->d_pkg_base.p,
@@ -547,16 +548,20 @@ int run_slice_and_mirror(RunCtx &r)
     lp.n_rows = (uint32_t)b->rows.size();
     lp.n_devs = n_devs;
     lp.sizes = b->d_sizes.p;
+    lp.dev_off = b->d_dev_off.p;
     lp.pkg_bytes = b->d_pkg_bytes.p;
     lp.pkg_off = b->d_pkg_off.p;
     lp.max_pkgs = max_pkgs;
     if (n_devs && r.total_pkgs) {
         // One slicing pass into staging slots when they fit.  A default device set yields ~135 B per
-        // (package, device) on average but the heavy PCM rows reach a few KB, and those are exactly the
-        // slow lanes, so the slot is made as large as the arena budget allows (up to 4 KB); below 512 B
-        // the classic count + write pair runs instead.
-        constexpr size_t kStageMax = (size_t)6 << 30;
-        uint32_t stage_cap = 4096;
+        // (package, device) on average, but the heavy PCM rows fill whole bitbuffers -- 50 rows x (4 + 128) B -- and
+        // those are exactly the slow lanes: a record that outgrows its slot is sliced a second time by the placing
+        // pass (with 4 KB slots that second slicing WAS the placing pass: 0.35 ms of 0.37).  8 KB holds every
+        // record there can be; the slots are written sparsely, so their size costs address space, not bandwidth
+        // (3.2 GB for the 1024 x 384 rows of the bench batch, of 288 GB).  Below 512 B the classic count + write
+        // pair runs instead.
+        constexpr size_t kStageMax = (size_t)32 << 30;
+        uint32_t stage_cap = 8192;
         while (stage_cap >= 512 && (size_t)r.total_pkgs * b->rows.size() * stage_cap > kStageMax)
             stage_cap >>= 1;
         if (stage_cap >= 512 && !(b->debug_flags & R433_DEBUG_TWO_PASS_SLICER)) {

@@ -248,6 +248,7 @@ void r433_batch_destroy(r433_batch *b)
     b->d_rec_bytes.release();
     b->d_rec_off.release();
     b->d_sizes.release();
+    b->d_dev_off.release();
     b->d_pkg_bytes.release();
     b->d_pkg_off.release();
     b->d_pkg_blob.release();

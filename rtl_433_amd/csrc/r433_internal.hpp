@@ -133,6 +133,7 @@ struct SliceParams {
     uint32_t n_rows;
     uint32_t n_devs;            // registered devices (width of `sizes`)
     uint32_t *sizes;            // [pkg][orig dev] bytes of event records
+    uint32_t *dev_off;          // [pkg][orig dev] exclusive prefix of sizes[pkg][.] (k_dev_prefix, before the placing pass)
     uint32_t *pkg_bytes;        // [pkg] total
     uint32_t const *pkg_off;    // [pkg] exclusive scan of pkg_bytes
     uint8_t *events;

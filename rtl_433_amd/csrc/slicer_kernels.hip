@@ -20,8 +20,6 @@ namespace r433 {
 
 namespace {
 
-constexpr uint32_t kMaxDevs = 2048;
-
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total)
 {
     uint32_t x = v;
@@ -48,7 +46,6 @@ template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
     constexpr bool PLACE = MODE == M_WRITE || MODE == M_COMPACT; // records go to their final offsets
     constexpr bool STORE = MODE != M_COUNT;                       // the sink stores bytes
     __shared__ int2 pairs[R433_PD_MAX_PULSES];
-    __shared__ uint32_t prefix[PLACE ? kMaxDevs : 1];
 
     uint32_t const n_pkgs = min(*p.n_pkgs, p.max_pkgs);
     uint32_t const chunks = p.n_rows / 64;
@@ -72,18 +69,6 @@ template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
         if (need_pulses)
             for (uint32_t i = lane; i < num; i += 64)
                 pairs[i] = src[i];
-        if (PLACE) { // exclusive prefix of this package's per-device sizes, in registration order
-            uint32_t carry = 0;
-            for (uint32_t b = 0; b < p.n_devs; b += 64) {
-                uint32_t i = b + lane;
-                uint32_t v = i < p.n_devs ? p.sizes[(uint64_t)pkg * p.n_devs + i] : 0u;
-                uint32_t tot;
-                uint32_t ex = wave_excl_scan(v, tot);
-                if (i < p.n_devs)
-                    prefix[i] = carry + ex;
-                carry += tot;
-            }
-        }
         __syncthreads();
 
         uint32_t my_bytes = 0;
@@ -98,7 +83,7 @@ template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
             bool fits = true;
             bool slice = run;
             if (PLACE) {
-                uint32_t base = p.pkg_off[pkg] + prefix[t.orig];
+                uint32_t base = p.pkg_off[pkg] + p.dev_off[(uint64_t)pkg * p.n_devs + t.orig]; // k_dev_prefix
                 limit = my_size;
                 fits = limit > 0 && (uint64_t)base + limit <= p.events_cap;
                 out = p.events + base;
@@ -122,17 +107,54 @@ template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
                 p.sizes[(uint64_t)pkg * p.n_devs + t.orig] = my_bytes;
         }
         if (MODE == M_COMPACT) {
-            // staged records -> event stream, one record at a time with the whole wavefront (a lane copying
-            // its own record word by word would pay a global-memory round trip per word)
-            unsigned long long todo = __ballot(copy_bytes > 0);
+            // Staged records -> event stream.  Most records are a header and a row or two: every lane copies its own with
+            // 16-byte loads from its (aligned) slot, four in flight, and dword stores (records are 4-byte aligned in the
+            // stream; stores do not wait).  One record at a time with the whole wavefront would pay a memory round trip
+            // per record, 64 in a row.  The rare long record is left to the whole wavefront below.
+            constexpr uint32_t kOwn = 512;
+            if (copy_bytes > 0 && copy_bytes <= kOwn) {
+                uint8_t const *src_r = p.stage + ((uint64_t)pkg * p.n_rows + di) * p.stage_cap;
+                uint32_t *dst = (uint32_t *)(p.events + copy_base);
+                uint32_t const words = copy_bytes / 4;
+                for (uint32_t w = 0; w < words; w += 16) {
+                    uint4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        v[u] = w + 4 * u < words ? *(uint4 const *)(src_r + (w + 4 * u) * 4) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        uint32_t const at = w + 4 * u;
+                        if (at < words) dst[at] = v[u].x;
+                        if (at + 1 < words) dst[at + 1] = v[u].y;
+                        if (at + 2 < words) dst[at + 2] = v[u].z;
+                        if (at + 3 < words) dst[at + 3] = v[u].w;
+                    }
+                }
+            }
+            unsigned long long todo = __ballot(copy_bytes > kOwn);
             while (todo) {
                 int const r = __ffsll(todo) - 1;
                 todo &= todo - 1;
                 uint32_t const nb = (uint32_t)__builtin_amdgcn_readlane((int)copy_bytes, r);
                 uint32_t const at = (uint32_t)__builtin_amdgcn_readlane((int)copy_base, r);
                 uint8_t const *src_r = p.stage + ((uint64_t)pkg * p.n_rows + chunk * 64 + (uint32_t)r) * p.stage_cap;
-                for (uint32_t w = lane * 4; w < nb; w += 256)
-                    *(uint32_t *)(p.events + at + w) = *(uint32_t const *)(src_r + w);
+                uint32_t *const dst = (uint32_t *)(p.events + at);
+                for (uint32_t w0 = 0; w0 < nb; w0 += 4096) { // 4 KB a round: four 16-byte loads per lane in flight, then the stores
+                    uint4 v[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        uint32_t const off = w0 + u * 1024 + lane * 16;
+                        v[u] = off < nb ? *(uint4 const *)(src_r + off) : make_uint4(0, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        uint32_t const off = w0 + u * 1024 + lane * 16;
+                        if (off < nb) dst[off / 4] = v[u].x;
+                        if (off + 4 < nb) dst[off / 4 + 1] = v[u].y;
+                        if (off + 8 < nb) dst[off / 4 + 2] = v[u].z;
+                        if (off + 12 < nb) dst[off / 4 + 3] = v[u].w;
+                    }
+                }
             }
         }
         if (!PLACE) {
@@ -140,6 +162,28 @@ template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
             wave_excl_scan(my_bytes, tot);
             if (lane == 0 && tot)
                 atomicAdd(&p.pkg_bytes[pkg], tot);
+        }
+    }
+}
+
+// Where each device's records of a package begin inside the package's stretch of the event stream: the exclusive prefix
+// of sizes[pkg][.] in registration order, once per package (every (package, 64 devices) item of the placing pass needs
+// one entry of it; computed inside that pass it was six dependent load + scan rounds per item, most of the pass).
+__global__ __launch_bounds__(64) void k_dev_prefix(uint32_t const *sizes, uint32_t *dev_off, uint32_t const *n_pkgs_ptr,
+        uint32_t max_pkgs, uint32_t n_devs)
+{
+    uint32_t const n_pkgs = min(*n_pkgs_ptr, max_pkgs);
+    uint32_t const lane = threadIdx.x;
+    for (uint32_t pkg = blockIdx.x; pkg < n_pkgs; pkg += gridDim.x) {
+        uint32_t carry = 0;
+        for (uint32_t b = 0; b < n_devs; b += 64) {
+            uint32_t const i = b + lane;
+            uint32_t const v = i < n_devs ? sizes[(uint64_t)pkg * n_devs + i] : 0u;
+            uint32_t tot;
+            uint32_t const ex = wave_excl_scan(v, tot);
+            if (i < n_devs)
+                dev_off[(uint64_t)pkg * n_devs + i] = carry + ex;
+            carry += tot;
         }
     }
 }
@@ -208,6 +252,8 @@ void launch_scan_u32(uint32_t const *in, uint32_t *out, uint32_t const *n_ptr, u
 
 void launch_slice_write(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st)
 {
+    hipLaunchKernelGGL(k_dev_prefix, dim3(grid_pkgs < 1 ? 1 : grid_pkgs < 16384 ? grid_pkgs : 16384), dim3(64), 0, st, p.sizes, p.dev_off,
+            p.n_pkgs, p.max_pkgs, p.n_devs);
     if (p.stage)
         hipLaunchKernelGGL(k_slice<M_COMPACT>, dim3(slice_grid(grid_pkgs, p.n_rows)), dim3(64), 0, st, p);
     else

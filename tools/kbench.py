@@ -16,6 +16,7 @@ ap.add_argument("--seed0", type=int, default=0)
 ap.add_argument("--rotate", type=int, default=1, help="distinct input batches taken in turn (no launch re-reads the batch before it)")
 ap.add_argument("--split", type=int, default=0)
 ap.add_argument("--debug", type=lambda x: int(x, 0), default=0)
+ap.add_argument("--lib", default=None, help="a development variant of the library to time instead of the product")
 ap.add_argument("--sigma-only", action="store_true", help="only the captures with noise (sigma > 0): no closed-form silence")
 ap.add_argument("--fsk-cu8", action="store_true", help="250 kS/s cu8 FSK bursts at 433.92 MHz: the classic FSK detector")
 ap.add_argument("--analyze", action="store_true", help="also time the pulse analyzer (-A) over the packages of the run")
@@ -45,7 +46,11 @@ d = torch.from_numpy(host).cuda()
 ds = [d] + [torch.from_numpy(np.roll(host, k + 1, axis=0).copy()).cuda() for k in range(a.rotate - 1)]
 devs = None if a.nodevs else load_device_table()[0]
 lib = None
-if a.debug & 1024:  # the per-phase clocks live in the development build of the library only
+if a.lib:
+    import ctypes
+    from rtl_433_amd import _lib
+    lib = _lib.bind(ctypes.CDLL(os.path.abspath(a.lib)))
+elif a.debug & 1024:  # the per-phase clocks live in the development build of the library only
     import ctypes
     from rtl_433_amd import _lib, build
     lib = _lib.bind(ctypes.CDLL(build.build(timing=True)))
