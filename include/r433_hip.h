@@ -152,6 +152,7 @@ int r433_batch_debug_state(r433_batch *b, void *host_buf, size_t bytes);
 #define R433_DEBUG_TIMING 1024u        /* per-phase shader clocks into the debug state (tools/kbench.py) */
 #define R433_DEBUG_NO_ROLE_SWAP 8192u /* wavefront 0 of every workgroup produces (A/B timing) */
 #define R433_DEBUG_NO_PRIO 16384u     /* the consumer wavefront keeps the default issue priority (A/B timing) */
+#define R433_DEBUG_PAIR 32768u        /* a producer / consumer pair per capture also in launches of more than 1280 captures */
 #define R433_DEBUG_ONE_WAVE 4096u /* one wavefront per capture instead of a producer / consumer pair: same results, for A/B timing */
 #define R433_DEBUG_NO_TRAIN_ENGINE 2048u /* in-package legs through the older per-leg code: same results, for A/B timing */
 int r433_batch_set_debug(r433_batch *b, uint32_t flags);

@@ -293,7 +293,7 @@ StreamParams stream_params(RunCtx const &r)
     sp.n_streams = r.n_planned;
     sp.frame_samples = b->cfg.frame_samples;
     sp.flags = 0;
-    sp.flags |= b->debug_flags & (RUN_DBG_SKIP_DETECT | RUN_DBG_SKIP_FILTERS | RUN_DBG_TIMING | RUN_NO_TRAIN_ENGINE | RUN_ONE_WAVE | RUN_NO_ROLE_SWAP | RUN_NO_PRIO); // r433_batch_set_debug
+    sp.flags |= b->debug_flags & (RUN_DBG_SKIP_DETECT | RUN_DBG_SKIP_FILTERS | RUN_DBG_TIMING | RUN_NO_TRAIN_ENGINE | RUN_ONE_WAVE | RUN_NO_ROLE_SWAP | RUN_NO_PRIO | RUN_PAIR); // r433_batch_set_debug
     sp.det = b->det;
     sp.use_mag = (int)b->cfg.use_mag_est;
     sp.enable_fm = (int)b->cfg.enable_fm;

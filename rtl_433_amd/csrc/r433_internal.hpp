@@ -67,6 +67,7 @@ enum : uint32_t {
     RUN_DBG_TIMING = 1024u, // per-phase shader-clock ticks into unused StreamState slots (r433_batch_debug_state)
     RUN_NO_ROLE_SWAP = 8192u, // development: wavefront 0 always produces
     RUN_NO_PRIO = 16384u,     // development: the consumer does not raise its issue priority
+    RUN_PAIR = 32768u,        // development: a producer / consumer pair per capture whatever the launch size
     RUN_ONE_WAVE = 4096u, // development: one wavefront per capture does phases A+B and C in turn (A/B timing, same results)
     RUN_NO_TRAIN_ENGINE = 2048u, // development: in-package legs through the older per-leg code (A/B timing, same results)
 };

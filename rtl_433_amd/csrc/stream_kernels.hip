@@ -289,8 +289,13 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
     // The two sit on different SIMDs of the CU (a workgroup's wavefronts are dealt out round-robin), each next to a
     // wavefront of another capture, so a SIMD issues for two wavefronts instead of one.  Launched with 64 threads the one
     // wavefront does both in turn (filters-only launches; R433_DEBUG_ONE_WAVE for A/B timing).
-    __shared__ __attribute__((aligned(16))) uint8_t s_am[2 * 64 * kPitchOut];
-    __shared__ __attribute__((aligned(16))) uint8_t s_fm[2 * 64 * kPitchOut];
+    // (the tile buffers are dynamic LDS: two of each for a pair, one for a single wavefront -- 8 KB that decide whether
+    // five or eight single-wavefront workgroups fit a CU)
+#ifdef R433_EMU
+    __shared__ __attribute__((aligned(16))) uint8_t s_tiles[4 * 64 * kPitchOut];
+#else
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_tiles[];
+#endif
     __shared__ int s_cmax[2 * 64], s_cmin[2 * 64];
     __shared__ int s_pflag[2]; // producer -> consumer, per buffer: the establishing tile could not be proven
     __shared__ int s_pover;    // producer -> consumer: a filter carry was refused (det.overflow codes 2, 3)
@@ -298,6 +303,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
     int const lane = (int)threadIdx.x & 63;
     int const wave = (int)threadIdx.x >> 6;
     bool const solo = blockDim.x == 64; // one wavefront does both halves
+    uint8_t *const s_am = s_tiles, *const s_fm = s_tiles + (solo ? 1 : 2) * (64 * kPitchOut);
     // role 0 produces, role 1 consumes.  Workgroups alternate which wavefront takes which role, so that the two wavefronts
     // that end up on one SIMD are one of each kind, and the consumer -- the serial critical path -- issues first.
     int const role = solo ? 0 : (wave ^ ((p.flags & RUN_NO_ROLE_SWAP) ? 0 : (int)(blockIdx.x & 1u)));
@@ -1983,8 +1989,13 @@ void launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st)
 {
     if (p.n_streams == 0)
         return;
-    // two wavefronts per capture (producer + consumer), or one doing both in turn (development: RUN_ONE_WAVE)
-    dim3 grid(p.n_streams), block((p.flags & RUN_ONE_WAVE) ? 64 : 128);
+    // Two wavefronts per capture (producer + consumer) while that is what fills the chip: 1024 SIMDs x 2 wavefront slots
+    // (amdgpu_waves_per_eu(2,2)).  Past 1024 captures single wavefronts begin to fill the second slots by themselves and the
+    // pair only adds its barriers and its second pair of tile buffers (per launch, single / pair: 1024 captures 1.65 / 1.35 ms,
+    // 1536: 1.90 / 1.97, 2048: 1.90 / 2.43, 8192: 5.74 / 7.43).  RUN_ONE_WAVE / RUN_PAIR force either form (A/B timing, tests).
+    bool const pair = (p.flags & RUN_PAIR) || (!(p.flags & RUN_ONE_WAVE) && p.n_streams <= 1280u);
+    dim3 grid(p.n_streams), block(pair ? 128 : 64);
+    uint32_t const lds = (pair ? 4u : 2u) * 64u * (uint32_t)kPitchOut; // the tile buffers (s_tiles)
     // FAST: no filter step can wrap and both feedback coefficients are non-negative (see Track16).
     // The AM filter always qualifies (13993 + 2*1195 <= 16384); the FM filter does for every cutoff
     // up to half the Nyquist rate, which includes the defaults.
@@ -1997,13 +2008,13 @@ void launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st)
 #define R433_LAUNCH_WAVE(SS)                                                                                           \
     do {                                                                                                               \
         if (fast && fm)                                                                                                \
-            hipLaunchKernelGGL((k_wave<SS, true, true>), grid, block, 0, st, p);                                       \
+            hipLaunchKernelGGL((k_wave<SS, true, true>), grid, block, lds, st, p);                                       \
         else if (fast)                                                                                                 \
-            hipLaunchKernelGGL((k_wave<SS, true, false>), grid, block, 0, st, p);                                      \
+            hipLaunchKernelGGL((k_wave<SS, true, false>), grid, block, lds, st, p);                                      \
         else if (fm)                                                                                                   \
-            hipLaunchKernelGGL((k_wave<SS, false, true>), grid, block, 0, st, p);                                      \
+            hipLaunchKernelGGL((k_wave<SS, false, true>), grid, block, lds, st, p);                                      \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_wave<SS, false, false>), grid, block, 0, st, p);                                     \
+            hipLaunchKernelGGL((k_wave<SS, false, false>), grid, block, lds, st, p);                                     \
     } while (0)
     if (sample_size == 2)
         R433_LAUNCH_WAVE(2);
@@ -2017,6 +2028,7 @@ void launch_filters(StreamParams const &p, uint32_t sample_size, hipStream_t st)
     if (p.n_streams == 0)
         return;
     dim3 grid(p.n_streams), block(64);
+    uint32_t const lds = 2u * 64u * (uint32_t)kPitchOut; // the tile buffers (s_tiles) of a single wavefront
     bool const fm = p.enable_fm != 0;
     bool fast;
     if (sample_size == 2)
@@ -2025,17 +2037,17 @@ void launch_filters(StreamParams const &p, uint32_t sample_size, hipStream_t st)
         fast = !fm || (p.a32 >= 0 && p.b32 >= 0 && p.a32 + 2 * p.b32 <= (1ll << 30));
     if (sample_size == 2) {
         if (!fm)
-            hipLaunchKernelGGL((k_wave<2, true, false, true>), grid, block, 0, st, p);
+            hipLaunchKernelGGL((k_wave<2, true, false, true>), grid, block, lds, st, p);
         else if (fast)
-            hipLaunchKernelGGL((k_wave<2, true, true, true>), grid, block, 0, st, p);
+            hipLaunchKernelGGL((k_wave<2, true, true, true>), grid, block, lds, st, p);
         else
-            hipLaunchKernelGGL((k_wave<2, false, true, true>), grid, block, 0, st, p);
+            hipLaunchKernelGGL((k_wave<2, false, true, true>), grid, block, lds, st, p);
     }
     else {
         if (fast)
-            hipLaunchKernelGGL((k_wave<4, true, true, true>), grid, block, 0, st, p);
+            hipLaunchKernelGGL((k_wave<4, true, true, true>), grid, block, lds, st, p);
         else
-            hipLaunchKernelGGL((k_wave<4, false, true, true>), grid, block, 0, st, p);
+            hipLaunchKernelGGL((k_wave<4, false, true, true>), grid, block, lds, st, p);
     }
 }
 

@@ -54,8 +54,10 @@ def test_case_vs_golden_and_oracle(name, default_devices):
     assert np.array_equal(env[0, :n], o["env"])
 
 
-def test_ragged_batch(default_devices):
-    """Captures of different lengths (including 0 and non-multiples of the tile) in one launch."""
+@pytest.mark.parametrize("form", ["pair", "one_wave"])
+def test_ragged_batch(form, default_devices):
+    """Captures of different lengths (including 0 and non-multiples of the tile) in one launch; as producer / consumer
+    wavefront pairs (what launches of up to 1280 captures use) and as single wavefronts (what larger launches use)."""
     from tests.emu import host
     devs = default_devices[0][:40]
     rng = np.random.default_rng(5)
@@ -70,7 +72,7 @@ def test_ragged_batch(default_devices):
         else:
             a = synth.ook_stream(1000 + s, max(n, 1))[0][: 2 * n]
         iqs.append(a)
-    g = host.emu_run(iqs, 2, 250000, devs)
+    g = host.emu_run(iqs, 2, 250000, devs, debug=4096 if form == "one_wave" else 32768)  # R433_DEBUG_ONE_WAVE / _PAIR
     pk, ev, base = _oracle_batch(iqs, devs, po.default_flow_cfg(2, 250000, fpdm=0))
     assert g["packages"][1] == base and g["packages"][0] == pk and g["events"][0] == ev
 

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 META = json.load(open(os.path.join(GOLD, "cases.json")))
 
 
-def _gpu_run(iq_list, ss, rate, freq, devs, taps=False, enable_fm=1, **kw):
+def _gpu_run(iq_list, ss, rate, freq, devs, taps=False, enable_fm=1, debug=0, **kw):
     import torch
     from rtl_433_amd.engine import BatchEngine, flow_cfg
     n = len(iq_list)
@@ -31,6 +31,8 @@ def _gpu_run(iq_list, ss, rate, freq, devs, taps=False, enable_fm=1, **kw):
     tp = None
     if taps:
         eng.enable_taps(n, max(1, stride // ss))
+    if debug:
+        eng.set_debug(debug)
     npk = eng.run(dev, lens)
     out = dict(n_packages=npk, packages=eng.packages(), events=eng.events(), sums=eng.frame_sums(n), timing=eng.timing())
     if taps:
@@ -70,8 +72,10 @@ def test_case_vs_golden_and_oracle(name, default_devices):
     assert np.array_equal(env[0, :n], o["env"])
 
 
-def test_ragged_batch_vs_oracle(default_devices):
-    """Many captures of different lengths in one launch; every capture must match the oracle run alone."""
+@pytest.mark.parametrize("form", ["pair", "one_wave"])
+def test_ragged_batch_vs_oracle(form, default_devices):
+    """Many captures of different lengths in one launch; every capture must match the oracle run alone.  Both forms of the
+    detection kernel: producer / consumer wavefront pairs (launches of up to 1280 captures) and single wavefronts (larger ones)."""
     from rtl_433_amd import synth
     devs = default_devices[0]
     rng = np.random.default_rng(5)
@@ -86,7 +90,7 @@ def test_ragged_batch_vs_oracle(default_devices):
         else:
             a = synth.ook_stream(1000 + s, max(n, 1))[0][: 2 * n]
         iqs.append(a)
-    g = _gpu_run(iqs, 2, 250000, 433920000, devs)
+    g = _gpu_run(iqs, 2, 250000, 433920000, devs, debug=4096 if form == "one_wave" else 32768)  # R433_DEBUG_ONE_WAVE / _PAIR
     cfg = po.default_flow_cfg(2, 250000, fpdm=0)
     pk_all, ev_all, base = b"", b"", 0
     for s, a in enumerate(iqs):

@@ -139,7 +139,8 @@ def one_case(seed, run=None):
         split = int(rng.choice([1, 1, 65536, 200000]))  # 1 = R433_SPLIT_AUTO
         kw.pop("frame_samples", None) if kw.get("frame_samples", 65536) < 2048 else None
     blind = 1 if split and rng.random() < 0.5 else 0  # R433_DEBUG_SPLIT_BLIND
-    g = run(caps, ss, rate, devs, fpdm=fpdm, taps=True, enable_fm=enable_fm, split=split, debug=blind, **kw)
+    form = (0, 4096, 32768)[seed % 3]  # the launch's own choice / R433_DEBUG_ONE_WAVE / R433_DEBUG_PAIR: both forms of the detection kernel
+    g = run(caps, ss, rate, devs, fpdm=fpdm, taps=True, enable_fm=enable_fm, split=split, debug=blind | form, **kw)
     cfg = po.default_flow_cfg(ss, rate, fpdm=fpdm, enable_fm=enable_fm, **kw)
     pk, ev, base = b"", b"", 0
     for s, a in enumerate(caps):
