@@ -265,6 +265,22 @@ int r433_filter_frame(uint32_t kind, void const *h_in, uint32_t n_samples, int16
 #define R433_ENV_TRUE_CS16 4u
 int r433_envelope_host(uint32_t kind, void const *h_iq, uint16_t *h_env, uint32_t n_samples, uint32_t *sum);
 
+/* pulse_detect_package() as a call of its own (reference include/pulse_detect.h:37-71, src/pulse_detect.c:199-483): the
+ * detector object with its levels, and one visit of a HOST buffer of filtered envelope / discriminator samples per call.
+ * Same contract: resumable across buffers, returns R433_PKG_OOK / R433_PKG_FSK at the first package that ends (the next call
+ * looks at the same sample again) or 0 at the end of the buffer, len == 0 flushes; `pulses` / `fsk_pulses` hold what the
+ * reference's structs hold after the same call (the detector's fields; both are cleared when a package begins).  The state
+ * machine runs on the device, one wavefront, sample by sample: this entry point exists for the function-level seam
+ * (librtl433seam.so exports it as pulse_detect_package), the fast path is r433_batch_run.  < 0: error. */
+typedef struct r433_detector r433_detector;
+r433_detector *r433_detector_create(void);
+void r433_detector_destroy(r433_detector *d);
+void r433_detector_reset(r433_detector *d);
+/* pulse_detect_set_levels (src/pulse_detect.c:86-105): dB values as the reference takes them */
+void r433_detector_set_levels(r433_detector *d, int use_mag_est, float fixed_high_level, float min_high_level, float high_low_ratio);
+int r433_detector_package(r433_detector *d, int16_t const *envelope, int16_t const *fm, int len, uint32_t samp_rate, uint64_t sample_offset,
+        r433_pulse_data *pulses, r433_pulse_data *fsk_pulses, unsigned fpdm);
+
 /* The file loop's input conversions (src/rtl_433.c:1811-1834) on device buffers: n = number of components
  * (2 per IQ sample).  cs8 -> cu8: +128.  cf32 -> cs16: (int)(f * 32767) clamped to +-32767, with C-on-x86
  * semantics for values no int can hold (they become -32767). */

@@ -123,6 +123,7 @@ EXPORTS = [
     "r433_pulse_vcd_header", "r433_pulse_vcd", "r433_batch_grab_plan",
     "r433_sigmf_prefix", "r433_sigmf_trailer", "r433_sigmf_probe",
     "r433_filter_frame", "r433_envelope_host", "r433_host_alloc", "r433_host_free", "r433_batch_run_host", "r433_batch_dispatch_hooks", "r433_batch_dispatch_ordered", "r433_batch_decoded",
+    "r433_detector_create", "r433_detector_destroy", "r433_detector_reset", "r433_detector_set_levels", "r433_detector_package",
 ]
 
 
@@ -225,6 +226,16 @@ def bind(L):
     L.r433_filter_frame.argtypes = [C.c_uint32, vp, C.c_uint32, vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int64]
     L.r433_envelope_host.restype = C.c_int
     L.r433_envelope_host.argtypes = [C.c_uint32, vp, vp, C.c_uint32, vp]
+    L.r433_detector_create.restype = vp
+    L.r433_detector_create.argtypes = []
+    L.r433_detector_destroy.restype = None
+    L.r433_detector_destroy.argtypes = [vp]
+    L.r433_detector_reset.restype = None
+    L.r433_detector_reset.argtypes = [vp]
+    L.r433_detector_set_levels.restype = None
+    L.r433_detector_set_levels.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float]
+    L.r433_detector_package.restype = C.c_int
+    L.r433_detector_package.argtypes = [vp, vp, vp, C.c_int, C.c_uint32, C.c_uint64, vp, vp, C.c_uint]
     L.r433_host_alloc.restype = vp
     L.r433_host_alloc.argtypes = [C.c_size_t]
     L.r433_host_free.restype = None

@@ -7,16 +7,18 @@
 //   include/pulse_slicer.h:38-184  the ten pulse_slicer_* and pulse_slicer_string
 //   include/pulse_detect.h:37-52   pulse_detect_create / _free / _reset / _set_levels (the object rtl_433 creates at
 //                                  start-up and configures from -Y options)
+//   include/pulse_detect.h:71      pulse_detect_package: the reference's resumable one-package-per-call contract over
+//                                  r433_detector_package (the exact state machine on the device, one wavefront, sample by
+//                                  sample: it completes the seam -- the reference's own src/r_flow.c links and decodes
+//                                  over it, `make -C dropin refflow` -- and is no fast path; that is push_sdr_flow)
 //
 // Every function is a thin host wrapper: host pointers in, the work on the GPU through librtl433hip.so's C ABI
 // (r433_envelope_host, r433_filter_frame, r433_batch_run_pulses + r433_batch_dispatch), host pointers out.  Nothing is
 // computed here.  A per-call round trip over PCIe makes these slower than the CPU code they replace -- they exist so the
 // seam is complete; the fast path is the batch entry (dropin/r_flow_hip.c).
 //
-// NOT exported: pulse_detect_package and pulse_detect_fsk_* (include/pulse_detect.h:71, pulse_detect_fsk.h:46-75).  Their
-// contract -- one package per call, resumable in the middle of a frame, partial pulse lists visible to the caller -- is
-// the serial state machine itself; on this hardware it only exists fused behind the filters (k_wave) and is reached
-// through push_sdr_flow / r433_batch_run.  With dropin/r_flow_hip.c in place nothing in rtl_433 calls them.
+// NOT exported: pulse_detect_fsk_classic / _minmax / _wrap_up (include/pulse_detect_fsk.h:46-75): only
+// pulse_detect_package calls them, and here they are part of its device code (csrc/detect_device.hpp).
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -186,12 +188,13 @@ void baseband_demod_FM_cs16(demodfm_state_t *state, int16_t const *x_buf, int16_
     state->yf = c.fm_y;
 }
 
-// ---- include/pulse_detect.h: the object rtl_433 creates and configures; detection itself is behind push_sdr_flow ----
+// ---- include/pulse_detect.h ----
 
 typedef struct pulse_detect {
     int use_mag_est;
     float fixed_high_level, min_high_level, high_low_ratio;
     int verbosity;
+    r433_detector *det; // made on the first pulse_detect_package call (the batch path never needs it)
 } pulse_detect_t;
 
 void pulse_detect_set_levels(pulse_detect_t *pulse_detect, int use_mag_est, float fixed_high_level, float min_high_level, float high_low_ratio, int verbosity)
@@ -201,6 +204,8 @@ void pulse_detect_set_levels(pulse_detect_t *pulse_detect, int use_mag_est, floa
     pulse_detect->min_high_level = min_high_level;
     pulse_detect->high_low_ratio = high_low_ratio;
     pulse_detect->verbosity = verbosity;
+    if (pulse_detect->det)
+        r433_detector_set_levels(pulse_detect->det, use_mag_est, fixed_high_level, min_high_level, high_low_ratio);
 }
 
 pulse_detect_t *pulse_detect_create(void)
@@ -216,12 +221,32 @@ pulse_detect_t *pulse_detect_create(void)
 
 void pulse_detect_free(pulse_detect_t *pulse_detect)
 {
+    if (pulse_detect)
+        r433_detector_destroy(pulse_detect->det);
     free(pulse_detect);
 }
 
 void pulse_detect_reset(pulse_detect_t *pulse_detect)
 {
-    (void)pulse_detect; // no detector state lives on the host: every capture starts clean on the device
+    if (pulse_detect->det)
+        r433_detector_reset(pulse_detect->det);
+}
+
+// include/pulse_detect.h:71.  pulse_data_t is r433_pulse_data byte for byte (include/r433_abi.h, tests/test_abi.py).
+int pulse_detect_package(pulse_detect_t *pulse_detect, int16_t const *envelope_data, int16_t const *fm_data, int len, uint32_t samp_rate,
+        uint64_t sample_offset, r433_pulse_data *pulses, r433_pulse_data *fsk_pulses, unsigned fpdm)
+{
+    if (!pulse_detect->det) {
+        pulse_detect->det = r433_detector_create();
+        if (!pulse_detect->det)
+            die("pulse_detect_package");
+        r433_detector_set_levels(pulse_detect->det, pulse_detect->use_mag_est, pulse_detect->fixed_high_level, pulse_detect->min_high_level,
+                pulse_detect->high_low_ratio);
+    }
+    int const r = r433_detector_package(pulse_detect->det, envelope_data, fm_data, len, samp_rate, sample_offset, pulses, fsk_pulses, fpdm);
+    if (r < 0)
+        die("pulse_detect_package");
+    return r;
 }
 
 // ---- include/pulse_slicer.h ----

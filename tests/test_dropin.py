@@ -26,6 +26,10 @@ HIP = os.path.join(ROOT, "dropin", "_build", "rtl_433_hip")
 # the same with src/baseband.c, src/pulse_detect*.c and src/pulse_slicer.c left out as well: librtl433seam.so stands in
 EMU_SEAM = os.path.join(ROOT, "dropin", "_build", "rtl_433_emu_seam")
 HIP_SEAM = os.path.join(ROOT, "dropin", "_build", "rtl_433_hip_seam")
+# the reference with its OWN src/r_flow.c and src/rtl_433.c, only the four DSP units replaced by librtl433seam.so: every
+# frame goes through envelope_detect / baseband_low_pass_filter / baseband_demod_FM / pulse_detect_package / pulse_slicer_*
+EMU_REFFLOW = os.path.join(ROOT, "dropin", "_build", "rtl_433_refflow_emu")
+HIP_REFFLOW = os.path.join(ROOT, "dropin", "_build", "rtl_433_refflow_hip")
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 FLEX = ["-X", "n=pwm,m=OOK_PWM,s=300,l=600,r=5000,g=2000,t=150",
@@ -42,9 +46,12 @@ def _ensure_built(binary):
         pytest.skip(f"{os.path.relpath(binary, ROOT)} not built and no reference tree to build it from")
     from oracle import pyoracle as po
     po.build_ref()
-    if binary in (EMU, EMU_SEAM):
+    if binary in (EMU, EMU_SEAM, EMU_REFFLOW):
         from tests.emu import build_emu
         build_emu.build()
+    if binary in (EMU_REFFLOW, HIP_REFFLOW):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "dropin"), "refflow"], stdout=subprocess.DEVNULL)
+        return
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "dropin"), "emu" if binary in (EMU, EMU_SEAM) else "hip"]
                           + (["SEAM=1"] if binary in (EMU_SEAM, HIP_SEAM) else []), stdout=subprocess.DEVNULL)
 
@@ -244,3 +251,26 @@ def test_emu_pulse_dumpers(tmp_path):
 def test_hip_pulse_dumpers(tmp_path):
     _ensure_built(HIP)
     check_pulse_dumpers(HIP, tmp_path)
+
+
+@pytest.mark.parametrize("binary", [pytest.param(EMU_REFFLOW, id="emu"), pytest.param(HIP_REFFLOW, id="hip", marks=pytest.mark.gpu)])
+def test_reference_flow_over_the_function_seam(binary, tmp_path):
+    """The reference's own r_flow.c (and everything above it) linked with librtl433seam.so instead of src/baseband.c,
+    src/pulse_detect.c, src/pulse_detect_fsk.c and src/pulse_slicer.c: envelope, both filters, pulse_detect_package -- called
+    again and again per frame, resumable -- and the slicers all come from the GPU library, call by call.  Same output as the
+    stock binary: the known answer with its levels, a flex decoder's rows, an FSK capture through both FSK detectors."""
+    _ensure_built(binary)
+    shutil.copy(os.path.join(GOLD, "nice_250k.cu8"), tmp_path / "g001_433.92M_250k.cu8")
+    args = ["-r", "g001_433.92M_250k.cu8", "-R", "169"] + FLEX[:2] + ["-F", "json", "-M", "level", "-M", "protocol"]
+    ref = run_cli(REF, args, tmp_path)
+    got = run_cli(binary, args, tmp_path)
+    assert ref.splitlines()[0].strip() == KAT_LINE
+    assert got == ref
+    synth.fsk_stream_cu8(4, 60000, n_bursts=2, nbits=120, gap=5000).tofile(tmp_path / "f_433.92M_250k.cu8")
+    synth.ook_stream(12, 40000)[0].tofile(tmp_path / "o_433.92M_250k.cu8")
+    for extra in ([], ["-Y", "minmax"]):
+        args = ["-r", "f_433.92M_250k.cu8", "-r", "o_433.92M_250k.cu8", "-X", "n=fpcm,m=FSK_PCM,s=100,l=100,r=2000"] + FLEX + extra \
+            + ["-F", "json", "-M", "level", "-K", "FILE"]
+        ref = run_cli(REF, args, tmp_path)
+        assert ref.count("\n") >= 2
+        assert run_cli(binary, args, tmp_path) == ref

@@ -220,3 +220,84 @@ def test_slicers_against_reference(fn, mod, backend):
     assert list(devs["a"].decode_fails) == list(devs["b"].decode_fails)
     if mod not in (10,):  # Oregon v1 needs its own preamble to say anything
         assert len(seen["a"]) > 0
+
+
+def _pd_proto(L):
+    from rtl_433_amd import _lib
+    vp = C.c_void_p
+    L.pulse_detect_create.restype = vp
+    L.pulse_detect_create.argtypes = []
+    L.pulse_detect_free.restype = None
+    L.pulse_detect_free.argtypes = [vp]
+    L.pulse_detect_reset.restype = None
+    L.pulse_detect_reset.argtypes = [vp]
+    L.pulse_detect_set_levels.restype = None
+    L.pulse_detect_set_levels.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int]
+    L.pulse_detect_package.restype = C.c_int
+    L.pulse_detect_package.argtypes = [vp, vp, vp, C.c_int, C.c_uint32, C.c_uint64, C.POINTER(_lib.PulseData), C.POINTER(_lib.PulseData), C.c_uint]
+    return L
+
+
+def _pd_view(p, partial):
+    """The detector's fields of a pulse_data_t.  `partial`: a list still being built (the slot after the last pair holds the
+    width of the pulse whose gap is running)."""
+    n = p.num_pulses
+    k = min(n + 1, 1200) if partial else n
+    return (p.offset, p.sample_rate, p.start_ago, p.end_ago, n, tuple(p.pulse[:k]), tuple(p.gap[:n]), p.ook_low_estimate, p.ook_high_estimate,
+            p.fsk_f1_est, p.fsk_f2_est)
+
+
+DETECT_CASES = [("ook", 250000, 0, [20000, 131072, 4097, 131072]), ("fsk_classic", 250000, 0, [131072, 50001]), ("fsk_minmax", 250000, 1, [70000, 131072]),
+                ("ook_levels", 250000, 0, [65536, 65536])]
+
+
+@pytest.mark.parametrize("name,rate,fpdm,frames", DETECT_CASES)
+def test_pulse_detect_package_against_reference(name, rate, fpdm, frames, backend):
+    """pulse_detect_package of the seam and of the reference, called the way src/r_flow.c:243 calls it -- again and again on
+    a buffer until it says 0, buffer after buffer, then the flush -- on the same filtered samples (the reference's own
+    filters make them): same return values, same structs after every call."""
+    from rtl_433_amd import _lib
+    S, R = _pd_proto(seam_lib(backend)), _pd_proto(ref_lib())
+    total = sum(frames)
+    if name.startswith("ook"):
+        iq = np.concatenate([synth.ook_stream(s, 65536, rate)[0] for s in (885, 3, 17, 40, 41, 42)])[: 2 * total]
+    else:
+        iq = np.concatenate([synth.fsk_stream_cu8(s, 100000, n_bursts=3, nbits=200, gap=4000) for s in (1, 2, 3, 4)])[: 2 * total]
+    iq = np.ascontiguousarray(iq)
+    assert iq.size == 2 * total
+    pa, pb = S.pulse_detect_create(), R.pulse_detect_create()
+    if name == "ook_levels":
+        for L, p in ((S, pa), (R, pb)):
+            L.pulse_detect_set_levels(p, 1, -10.0, -20.0, 6.0, 0)
+    fa, fb = FilterState(), FilterState()
+    ma, mb = FmState(), FmState()
+    sa, sb = (_lib.PulseData(), _lib.PulseData()), (_lib.PulseData(), _lib.PulseData())
+    at, offset, log = 0, 0, []
+    for n in frames + [0]:
+        chunk = np.ascontiguousarray(iq[2 * at: 2 * (at + n)])
+        env, am, fm = np.zeros(max(n, 1), dtype=np.uint16), np.zeros(max(n, 1), dtype=np.int16), np.zeros(max(n, 1), dtype=np.int16)
+        if n:
+            if name == "ook_levels":
+                R.magnitude_est_cu8(chunk.ctypes.data, env.ctypes.data, n)
+            else:
+                R.envelope_detect(chunk.ctypes.data, env.ctypes.data, n)
+            R.baseband_low_pass_filter(C.byref(fb), env.ctypes.data, am.ctypes.data, n)
+            R.baseband_demod_FM(C.byref(mb), chunk.ctypes.data, fm.ctypes.data, n, rate, 0.2 if fpdm else 0.1)
+        for guard in range(10000):
+            ra = S.pulse_detect_package(pa, am.ctypes.data, fm.ctypes.data, n, rate, offset, C.byref(sa[0]), C.byref(sa[1]), fpdm)
+            rb = R.pulse_detect_package(pb, am.ctypes.data, fm.ctypes.data, n, rate, offset, C.byref(sb[0]), C.byref(sb[1]), fpdm)
+            assert ra == rb, (name, at, guard, ra, rb)
+            # after EVERY call, returned package or not: the package list (with the slot of the pulse whose gap is running)
+            # and the FSK candidate next to it, ages, offsets, levels
+            assert _pd_view(sa[0], True) == _pd_view(sb[0], True), (name, at, guard, rb)
+            assert _pd_view(sa[1], False) == _pd_view(sb[1], False), (name, at, guard, rb)
+            log.append(rb)
+            if rb == 0 or n == 0:
+                break
+        at += n
+        offset += n
+    assert log.count(1) + log.count(2) >= 2, log  # the cases do contain packages
+    if "fsk" in name:
+        assert 2 in log, log
+    S.pulse_detect_free(pa)
+    R.pulse_detect_free(pb)
