@@ -256,13 +256,15 @@ int run_plan(RunCtx &r)
         r.cap_n[c] = (r.stream_bytes ? r.stream_bytes[c] : (uint32_t)r.stride_bytes) / r.ss;
     b->stream_samples = r.cap_n;
     // automatic: only where one wavefront per capture would leave the chip empty -- few, long captures.
-    // Aim at ~4096 segments, at least 32 Ki samples each.
+    // Aim at ~8192 segments, at least 24 Ki samples each (tools/splitsweep.py, tools/longbench.py: a piece that has to be run
+    // again across a cut that did not verify is one wavefront's serial time, so short pieces keep the later rounds short;
+    // 64 Mi-sample cs16 FSK stream 20.0 -> 15.5 ms, 256 Mi-sample 2 MS/s stream 27.0 -> 22.5 ms against 32 Ki / 4096).
     uint32_t split_samples = b->logic_on ? 0u : b->split_samples; // the logic dump is painted by whole-capture wavefronts
     if (split_samples == R433_SPLIT_AUTO) {
         uint64_t total = 0;
         for (uint32_t c = 0; c < r.n_streams; ++c)
             total += r.cap_n[c];
-        split_samples = (r.n_streams <= 64 && r.max_samples >= (1u << 20)) ? (uint32_t)std::max<uint64_t>(32768, total / 4096) : 0u;
+        split_samples = (r.n_streams <= 64 && r.max_samples >= (1u << 20)) ? (uint32_t)std::max<uint64_t>(24576, total / 8192) : 0u;
     }
     r.split = split_samples > 0;
     r.max_seg_samples = r.max_samples;
@@ -385,6 +387,9 @@ int run_stitch(RunCtx &r, StreamParams const &sp)
                 merged.push_back(pc);
                 continue;
             }
+            if (b->debug_flags & R433_DEBUG_SPLIT_TRACE)
+                fprintf(stderr, "r.split: capture %u cut at %u cannot be started from (reasons %d / %d)\n", c, pc.seg.start,
+                        b->h_state.p[pc.slot[0]].seg_fail, b->h_state.p[pc.slot[1]].seg_fail);
             Piece &m = merged.back();
             m.seg.end = pc.seg.end;
             m.seg.flags |= pc.seg.flags & SEG_LAST;

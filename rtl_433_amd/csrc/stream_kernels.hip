@@ -692,9 +692,21 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
             sa.start_known = sf.start_known = true;
             sa.end_known = sf.end_known = false;
         }
-        if (warm && lane < kWarmChunks) { // no history: take what the tracks say, proven or not, and never wait for it
-            sa.start_known = sf.start_known = true;
-            sa.ident = sf.ident = 0;
+        if (warm) {
+            // An establishing tile is wanted for two things only: proven carries at its end and proven samples in its last
+            // sixteen chunks (the floor walk).  Its first lanes have no history: take what the tracks say, proven or not, and
+            // never wait for it.  The same goes for any lane before those sixteen chunks whose warm-up did not collapse (two
+            // AM tracks one apart stay apart with probability 0.854 per step: 1-2 % of the lanes): its left neighbour may be
+            // one of the unproven first lanes, then nobody could ever settle it and the whole cut would be given up.
+            bool const early = lane < 64 - kFloorWindow / kChunk;
+            if (lane < kWarmChunks || (early && !sa.start_known)) {
+                sa.start_known = true;
+                sa.ident = 0;
+            }
+            if (lane < kWarmChunks || (early && !sf.start_known)) {
+                sf.start_known = true;
+                sf.ident = 0;
+            }
         }
         // the fixed-point argument needs a feedback coefficient in [0, 1]: monotone map, slope <= 1
         sa.ident &= ta.ok;
@@ -713,7 +725,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                     break;
                 if (round > 64) { // cannot happen in a regular tile (the first open lane settles every round)
                     if (warm)
-                        p_fail = 1; // a stall reaching back past the establishing tile: the carry is not provable here
+                        p_fail |= 8; // a stall reaching back past the establishing tile: the carry is not provable here
                     else
                         p_over = 2;
                     break;
@@ -828,7 +840,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
             // proven, and so must the last sixteen chunks (the floor is walked over their samples).
             bool const tail_ok = lane < 64 - kFloorWindow / kChunk || (sa.start_known && sa.end_known && sf.start_known && sf.end_known);
             if (__ballot(!tail_ok))
-                p_fail = 1;
+                p_fail |= 16;
             if (lane == 0)
                 s_pflag[buf] = p_fail;
             return; // the consumer walks the floor over this tile
@@ -875,8 +887,8 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
         if (p.flags & RUN_DBG_SKIP_FILTERS)
             return;
         if (warm) {
-            if (s_pflag[buf])
-                seg_fail = 1;
+            if (s_pflag[buf]) // (bits: 1 the filters -- 8 a carry that cannot be proven inside the tile, 16 an unproven chunk among
+                seg_fail |= 1 | s_pflag[buf]; // those the floor is walked over --, 2 floor range too wide, 4 the walks did not meet)
             // Noise floor at the segment's first sample: the detector is assumed idle over the last 512
             // samples with a floor of the assumed parity somewhere inside the tile's sample range; both
             // extremes of that parity are walked and must meet (see the lazy floor below).
@@ -888,7 +900,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
             int const par = (seg_flags & SEG_ODD) ? 1 : 0;
             int a = rmin - 1, b = rmax + 1;
             if (b - a >= 1000)
-                seg_fail = 1; // steps of more than one are possible: not the regime the cut assumes
+                seg_fail |= 2; // steps of more than one are possible: not the regime the cut assumes
             a += (a ^ par) & 1;
             b -= (b ^ par) & 1;
             for (int w = kTile - kFloorWindow; w < kTile; w += 64) { // chunks 48..63: proven above
@@ -901,7 +913,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                 }
             }
             if (a != b)
-                seg_fail = 1;
+                seg_fail |= 4;
             det.low = a;
             det.high = max(cfg.ratio * a, cfg.min_high);
             seg_init_low = a;
