@@ -20,6 +20,10 @@ WORKLOADS = {
                 "k_wave<2,true,true>, 1024 captures x 65536 cu8 samples (tools/kbench.py, all decoders), one launch"),
     "config3": ([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "3", "--quick", "--steps", "2", "--warmup", "1"], "k_wave<4", 4 * (64 << 20),
                 "k_wave<4,true,true> over the verified segments of one 64 Mi-sample cs16 stream (bench.py --config 3): all its launches of one pass"),
+    "config4": ([sys.executable, os.path.join(ROOT, "tools", "kbench.py"), "--reps", "2", "--nodevs", "--streams", "8192"], "k_wave<2", 2 * 8192 * 65536,
+                "k_wave<2,true,true>, one launch of 8192 captures x 65536 cu8 samples (what bench.py --config 4 launches eight times per step)"),
+    "config5": ([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "5", "--quick", "--steps", "2", "--warmup", "1"], "k_wave<2", 2 * (256 << 20),
+                "k_wave<2,..> over the verified segments of one 256 Mi-sample 2 MS/s cu8 stream (bench.py --config 5): all its launches of one pass"),
 }
 
 
@@ -54,10 +58,10 @@ def main():
         if not got:
             continue
         n_disp = len(got["FETCH_SIZE"])
-        if key == "config2":
+        if key in ("config2", "config4"):
             per = n_disp  # every dispatch is one launch of the workload
         else:
-            per = 3  # bench.py --config 3 --steps 2 --warmup 1: three passes over the stream
+            per = 3  # bench.py --config 3 / 5 --steps 2 --warmup 1: three passes over the stream
         fetch_kb = sum(v for _, _, v in got["FETCH_SIZE"]) / per
         write_kb = sum(v for _, _, v in got["WRITE_SIZE"]) / per
         res[key] = dict(kernel=what, dispatches_seen=n_disp, launches_or_passes=per,
