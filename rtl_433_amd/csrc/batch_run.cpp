@@ -569,11 +569,15 @@ int run_slice_and_mirror(RunCtx &r)
         uint32_t stage_cap = 8192;
         while (stage_cap >= 512 && (size_t)r.total_pkgs * b->rows.size() * stage_cap > kStageMax)
             stage_cap >>= 1;
-        if (stage_cap >= 512 && !(b->debug_flags & R433_DEBUG_TWO_PASS_SLICER)) {
-            if ((rc = b->d_stage.ensure((size_t)r.total_pkgs * b->rows.size() * stage_cap)))
-                return rc;
-            lp.stage = b->d_stage.p;
-            lp.stage_cap = stage_cap;
+        if (!(b->debug_flags & R433_DEBUG_TWO_PASS_SLICER)) {
+            // (a device with less free memory than that: smaller slots -- a record that outgrows its slot is sliced a second
+            // time -- and in the end the count + write pair, never a failed run)
+            for (; stage_cap >= 512; stage_cap >>= 1)
+                if (b->d_stage.ensure((size_t)r.total_pkgs * b->rows.size() * stage_cap) == 0) {
+                    lp.stage = b->d_stage.p;
+                    lp.stage_cap = stage_cap;
+                    break;
+                }
         }
         HIP_TRY(hipMemsetAsync(b->d_pkg_bytes.p, 0, (size_t)max_pkgs * sizeof(uint32_t), r.st));
         launch_slice_count(lp, r.total_pkgs, r.st);
