@@ -1603,12 +1603,24 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                                         int fx = fstate == 1 ? det.f_f2 : det.f_f1;
                                         v2s fv = {(short)f1, (short)fx};
                                         v2s const m63 = {63, 63};
-                                        for (int u = 0; u < run; ++u) {
-                                            h = max(h - (h >> 6) + __builtin_amdgcn_readlane(a64_l, j - base + u), cfg.min_high);
-                                            v2s const in = as_v2s(__builtin_amdgcn_readlane(ff_pk_l, j - base + u));
+                                        // scalar lane numbers, four samples per trip: a lane number that sits in a vector register
+                                        // costs a v_readfirstlane and its wait states per sample (19 -> 13 instructions per sample)
+                                        int const idx0 = uni(j - base);
+                                        auto step = [&](int at) {
+                                            h = max(h - (h >> 6) + __builtin_amdgcn_readlane(a64_l, at), cfg.min_high);
+                                            v2s const in = as_v2s(__builtin_amdgcn_readlane(ff_pk_l, at));
                                             v2s const q = (fv + ((fv >> 15) & m63)) >> 6; // v / 64, truncating toward zero
                                             fv = fv - q + in;
+                                        };
+                                        int u = 0;
+                                        for (; u + 4 <= run; u += 4) {
+                                            step(idx0 + u);
+                                            step(idx0 + u + 1);
+                                            step(idx0 + u + 2);
+                                            step(idx0 + u + 3);
                                         }
+                                        for (; u < run; ++u)
+                                            step(idx0 + u);
                                         f1 = fv[0];
                                         fx = fv[1];
                                         if (fstate == 1)
@@ -1664,16 +1676,25 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                                         // wavefront more than the few instructions it would skip
                                         auto advance = [&](auto mode_tag) {
                                             constexpr int MODE = decltype(mode_tag)::value; // the detector's state
-                                            for (int u = 0; u < run; ++u) {
-                                                int const x = __builtin_amdgcn_readlane(fm_l, idx0 + u);
-                                                int const x64 = __builtin_amdgcn_readlane(f64_l, idx0 + u);
+                                            auto step = [&](int at) {
+                                                int const x = __builtin_amdgcn_readlane(fm_l, at);
+                                                int const x64 = __builtin_amdgcn_readlane(f64_l, at);
                                                 int const x16 = (x + ((x >> 31) & 15)) >> 4; // x / 16, C division
-                                                h = max(h - (h >> 6) + __builtin_amdgcn_readlane(a64_l, idx0 + u), cfg.min_high);
+                                                h = max(h - (h >> 6) + __builtin_amdgcn_readlane(a64_l, at), cfg.min_high);
                                                 f1 += x64 - div64(f1);
                                                 bool const fast = MODE == 0 || (MODE == 1 ? x > F : x < F); // towards the outside: 1/16 steps
                                                 int const sh = fast ? 4 : 6, bias = fast ? 15 : 63;
                                                 F += (fast ? x16 : x64) - ((F + ((F >> 31) & bias)) >> sh); // v/16 - F/16 or v/64 - F/64, C division
+                                            };
+                                            int u = 0;
+                                            for (; u + 4 <= run; u += 4) { // four samples per trip: the loop bookkeeping is a fifth of a sample's work
+                                                step(idx0 + u);
+                                                step(idx0 + u + 1);
+                                                step(idx0 + u + 2);
+                                                step(idx0 + u + 3);
                                             }
+                                            for (; u < run; ++u)
+                                                step(idx0 + u);
                                         };
                                         if (fstate == 0)
                                             advance(std::integral_constant<int, 0>{});
