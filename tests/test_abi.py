@@ -60,6 +60,15 @@ def test_no_cpu_fallback_without_a_device():
     assert not L.r433_batch_create(C.byref(cfg), None, 0)
     assert L.r433_envelope_detect(None, None, 0, None, None) == -2
     assert b"HIP" in L.r433_last_error() or b"device" in L.r433_last_error()
+    # the stand-alone detector: the object is host state, a call is device work
+    import numpy as np
+    det = L.r433_detector_create()
+    assert det
+    am, fm = np.zeros(64, dtype=np.int16), np.zeros(64, dtype=np.int16)
+    pa, pb = _lib.PulseData(), _lib.PulseData()
+    assert L.r433_detector_package(det, am.ctypes.data, fm.ctypes.data, 64, 250000, 0, C.byref(pa), C.byref(pb), 0) == -2
+    assert L.r433_detector_package(det, None, None, 64, 250000, 0, C.byref(pa), C.byref(pb), 0) == -1  # R433_EINVAL before anything else
+    L.r433_detector_destroy(det)
 
 
 def test_missing_library_is_a_hard_error(monkeypatch):
