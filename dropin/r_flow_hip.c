@@ -21,7 +21,9 @@
     So `rtl_433 -r a.cu8 -r b.cu8 ... -F json` prints the same lines in the same order.
 
     A drain happens
-      - at every flush                      when batching is off (RTL433_HIP_BATCH=1, or no end hook compiled in);
+      - at every flush                      when batching is off (RTL433_HIP_BATCH=1, no end hook compiled in, or an output that
+                                            also prints log messages -- -F kv, -F log -- so that the file loop's messages and the
+                                            events of each file come out in the reference's order);
       - when RTL433_HIP_BATCH captures (default 4096) or 1 GiB of samples are waiting;
       - at hip_sdr_flow_drain(cfg), which the host calls once after its file loop and before close_dumpers()
         (one added line in src/rtl_433.c:1860; builds of the unmodified rtl_433.c get the same effect from
@@ -97,6 +99,7 @@ static struct {
     size_t n_caps, caps_cap;
     int open; /* the last capture is still being pushed to */
     int warned_grab, warned_dump;
+    uint32_t fm_note_rate; /* the rate the "FM low pass filter" notice was last printed for (src/baseband.c:217,310) */
     /* replay context */
     r_cfg_t *cfg;
     hip_capture *group;
@@ -106,12 +109,19 @@ static struct {
     uint32_t cur_frames_done;
 } H = {.cur_stream = UINT32_MAX};
 
-static size_t batch_limit(void)
+static size_t batch_limit(r_cfg_t *cfg)
 {
     char const *e = getenv("RTL433_HIP_BATCH");
     if (e && *e) {
         long v = atol(e);
         return v < 1 ? 1 : (size_t)v;
+    }
+    /* An output that also takes log messages (-F kv, -F log, -F json:v...) interleaves the file loop's own messages
+       ("Test mode active. Reading samples from file: ...") with the events of each file: keep that order, one pass per file. */
+    for (size_t i = 0; i < cfg->output_handler.len; ++i) {
+        data_output_t *o = cfg->output_handler.elems[i];
+        if (o && o->log_level > 0)
+            return 1;
     }
 #ifdef R433_HIP_HAVE_DRAIN
     return 4096;
@@ -623,6 +633,7 @@ void reset_sdr_flow(r_cfg_t *cfg)
 
     /* filter, discriminator and detector state live on the device, per capture: a new capture starts clean */
     H.open = 0;
+    H.fm_note_rate = 0; /* baseband_demod_FM_reset zeroes the rate the notice is keyed on */
 }
 
 int push_sdr_flow(r_cfg_t *cfg, unsigned char *iq_buf, uint32_t len)
@@ -636,7 +647,7 @@ int push_sdr_flow(r_cfg_t *cfg, unsigned char *iq_buf, uint32_t len)
     if (!len) {
         /* flush: the capture is complete */
         H.open = 0;
-        if (H.n_caps >= batch_limit() || H.stage_len >= ((size_t)1 << 30))
+        if (H.n_caps >= batch_limit(cfg) || H.stage_len >= ((size_t)1 << 30))
             return hip_sdr_flow_drain(cfg);
         return 0;
     }
@@ -661,6 +672,19 @@ int push_sdr_flow(r_cfg_t *cfg, unsigned char *iq_buf, uint32_t len)
     if (demod->load_info.format == S16_AM || demod->load_info.format == S16_FM) {
         print_log(LOG_ERROR, "HIP", "AM / FM sample files are not served by the HIP flow");
         return -1;
+    }
+
+    /* what baseband_demod_FM(_cs16) tells a -vv user when it derives its filter: on the first frame after a reset and on
+       every change of the sample rate (src/baseband.c:217-223,310-316; same float arithmetic, same wording) */
+    if (demod->enable_FM_demod && H.fm_note_rate != demod->samp_rate) {
+        float low_pass = demod->fm_low_pass != 0.0f ? demod->fm_low_pass : demod->fsk_pulse_detect_mode ? 0.2f : 0.1f; /* src/r_flow.c:204 */
+        if (low_pass > 1e4f)
+            low_pass = low_pass / demod->samp_rate;
+        else if (low_pass >= 1.0f)
+            low_pass = 1e6f / low_pass / demod->samp_rate;
+        print_logf(LOG_NOTICE, "Baseband", demod->sample_size == 2 ? "FM low pass filter for %u Hz at cutoff %.0f Hz, %.1f us" : "low pass filter for %u Hz at cutoff %.0f Hz, %.1f us",
+                demod->samp_rate, demod->samp_rate * (double)low_pass, 1e6 / (demod->samp_rate * (double)low_pass));
+        H.fm_note_rate = demod->samp_rate;
     }
 
     hip_capture *c = H.open && H.n_caps ? &H.caps[H.n_caps - 1] : capture_open(cfg);

@@ -50,6 +50,7 @@ typedef r433_bitbuffer bitbuffer_t;   // include/bitbuffer.h:34-40
 // reference functions this library calls back when the host program has them (weak: tests/baseband-test.c has neither)
 void decoder_log_bitbuffer(r_device *decoder, int level, char const *func, const bitbuffer_t *bitbuffer, char const *msg) __attribute__((weak));
 void bitbuffer_parse(bitbuffer_t *bits, const char *code) __attribute__((weak));
+void print_logf(int level, char const *src, char const *fmt, ...) __attribute__((weak)); // include/logger.h:66 (log_level_t is an int-sized enum)
 
 static void die(char const *what)
 {
@@ -133,6 +134,9 @@ void baseband_demod_FM(demodfm_state_t *state, uint8_t const *x_buf, int16_t *y_
             low_pass = low_pass / samp_rate;
         else if (low_pass >= 1.0f)
             low_pass = 1e6f / low_pass / samp_rate;
+        if (print_logf) // what a -vv user is told at this point (src/baseband.c:222-223), LOG_NOTICE = 5
+            print_logf(5, "Baseband", "FM low pass filter for %u Hz at cutoff %.0f Hz, %.1f us", samp_rate, samp_rate * (double)low_pass,
+                    1e6 / (samp_rate * (double)low_pass));
         double ita = 1.0 / tan(M_PI_2 * low_pass);
         double gain = 1.0 / (1.0 + ita) / 2;
         state->alp_16[0] = (int)(1.0 * 32768);
@@ -164,6 +168,9 @@ void baseband_demod_FM_cs16(demodfm_state_t *state, int16_t const *x_buf, int16_
             low_pass = low_pass / samp_rate;
         else if (low_pass >= 1.0f)
             low_pass = 1e6f / low_pass / samp_rate;
+        if (print_logf) // src/baseband.c:315-316
+            print_logf(5, "Baseband", "low pass filter for %u Hz at cutoff %.0f Hz, %.1f us", samp_rate, samp_rate * (double)low_pass,
+                    1e6 / (samp_rate * (double)low_pass));
         double ita = 1.0 / tan(M_PI_2 * low_pass);
         double gain = 1.0 / (1.0 + ita);
         state->alp_32[0] = (int)(1.0 * 1073741824);

@@ -274,3 +274,60 @@ def test_reference_flow_over_the_function_seam(binary, tmp_path):
         ref = run_cli(REF, args, tmp_path)
         assert ref.count("\n") >= 2
         assert run_cli(binary, args, tmp_path) == ref
+
+
+OPTION_SETS = [
+    ["-F", "json", "-M", "level", "-M", "stats:2:1"],
+    ["-F", "json", "-M", "level", "-Y", "autolevel", "-Y", "magest"],
+    ["-F", "json", "-M", "level", "-Y", "level=-5", "-Y", "minlevel=-20", "-Y", "minsnr=6"],
+    ["-F", "csv", "-M", "level"],
+    ["-F", "json", "-M", "level", "-s", "1000k"],
+    ["-F", "json", "-M", "level", "-Y", "classic"],
+    ["-F", "json", "-M", "level", "-Y", "minmax", "-Y", "ampest"],
+    ["-F", "json", "-M", "level", "-Y", "filter=0.3", "-M", "noise:1"],
+    ["-F", "log", "-F", "json", "-M", "level", "-vv"],
+]
+
+
+def _strip_banner(text):
+    return "\n".join(l for l in text.splitlines() if not l.startswith("rtl_433 version") and "Use \"-F log\"" not in l)
+
+
+@pytest.mark.parametrize("binary", [pytest.param(EMU, id="emu"), pytest.param(HIP, id="hip", marks=pytest.mark.gpu)])
+def test_cli_option_matrix(binary, tmp_path):
+    """The flow options a user can reach from the command line -- levels, estimators, FSK detector choice, filters, sample rate
+    override, statistics, verbosity, output formats -- on an OOK, an FSK and the known-answer capture: stdout AND stderr equal the
+    stock binary's (stderr carries the -vv messages of the flow, e.g. the per-package levels)."""
+    _ensure_built(binary)
+    shutil.copy(os.path.join(GOLD, "nice_250k.cu8"), tmp_path / "g001_433.92M_250k.cu8")
+    synth.ook_stream(12, 40000)[0].tofile(tmp_path / "o_433.92M_250k.cu8")
+    synth.fsk_stream_cu8(4, 60000, n_bursts=2, nbits=120, gap=5000).tofile(tmp_path / "f_433.92M_250k.cu8")
+    base = ["-r", "g001_433.92M_250k.cu8", "-r", "o_433.92M_250k.cu8", "-r", "f_433.92M_250k.cu8", "-R", "169", "-X", FLEX[1],
+            "-X", "n=fpcm,m=FSK_PCM,s=100,l=100,r=2000"]
+    for opts in OPTION_SETS:
+        outs = []
+        for b in (REF, binary):
+            p = subprocess.run([b] + base + opts, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+            assert p.returncode == 0, (opts, p.stderr.decode(errors="replace")[-1000:])
+            outs.append((p.stdout.decode(), _strip_banner(p.stderr.decode(errors="replace"))))
+        assert outs[0][0] == outs[1][0], opts
+        assert outs[0][1] == outs[1][1], opts
+        assert outs[0][0].count("\n") >= 4, opts
+
+
+@pytest.mark.parametrize("binary", [pytest.param(EMU, id="emu"), pytest.param(HIP, id="hip", marks=pytest.mark.gpu)])
+def test_log_printing_outputs_keep_the_file_order(binary, tmp_path):
+    """-F kv prints the file loop's own messages ("Test mode active. Reading samples from file: ...") in the same stream as
+    the events: the flow then runs one pass per file so that both come out in the reference's order.  (The separator line
+    of -F kv is as wide as an ioctl on a non-terminal says -- uninitialised in the reference -- and is left out.)"""
+    _ensure_built(binary)
+    shutil.copy(os.path.join(GOLD, "nice_250k.cu8"), tmp_path / "g001_433.92M_250k.cu8")
+    synth.ook_stream(12, 40000)[0].tofile(tmp_path / "o_433.92M_250k.cu8")
+    args = ["-r", "g001_433.92M_250k.cu8", "-r", "o_433.92M_250k.cu8", "-r", "g001_433.92M_250k.cu8", "-R", "169", "-X", FLEX[1], "-F", "kv", "-M", "level"]
+
+    def lines(b):
+        out = run_cli(b, args, tmp_path)
+        return [l for l in out.splitlines() if l.strip() and not l.startswith("_ _")]
+    ref = lines(REF)
+    assert sum("Reading samples from file" in l for l in ref) == 3
+    assert lines(binary) == ref
