@@ -31,9 +31,12 @@
     Deferred work means push_sdr_flow returns 0 and the flush (or the drain) returns the events; "-E quit" style
     options that look at the per-frame event count therefore act at file granularity.
 
-    Not served by this flow (reported once, then ignored): the sample grabber (-S), the raw rtl_tcp output's
-    per-frame pacing is kept, S16_AM / S16_FM pseudo-IQ input files, and sample dumpers other than the input's own
-    format (-w/-W .ook, .vcd and .u8 are served).
+    Not served by this flow (reported once, then ignored): the sample grabber (-S) and S16_AM / S16_FM pseudo-IQ input
+    files; the raw rtl_tcp output's per-frame pacing is kept.  Every -w / -W dumper is served: the input's own format is a
+    copy, the other IQ formats are the library's dump kernel on each frame, am / fm dumps come from the detection pass's
+    taps, .u8 is painted by the detection kernel, .ook / .vcd are written during the replay.  (One quirk of the reference
+    is NOT reproduced: its IQ conversions write into a buffer that is a union with buf.fm, so an IQ dumper listed before
+    an fm.s16 dumper clobbers what that one writes; here fm.s16 is always the discriminator.)
  */
 
 #include <stdio.h>
@@ -99,6 +102,10 @@ static struct {
     size_t n_caps, caps_cap;
     int open; /* the last capture is still being pushed to */
     int warned_grab, warned_dump;
+    uint8_t *conv;      /* a converted frame / capture for the sample dumpers */
+    size_t conv_cap;
+    int16_t *taps[3];   /* pinned: raw envelope, filtered envelope, filtered discriminator of the captures of a pass (am / fm dumpers) */
+    size_t taps_cap;
     uint32_t fm_note_rate; /* the rate the "FM low pass filter" notice was last printed for (src/baseband.c:217,310) */
     /* replay context */
     r_cfg_t *cfg;
@@ -121,6 +128,12 @@ static size_t batch_limit(r_cfg_t *cfg)
     for (size_t i = 0; i < cfg->output_handler.len; ++i) {
         data_output_t *o = cfg->output_handler.elems[i];
         if (o && o->log_level > 0)
+            return 1;
+    }
+    /* the am / fm sample dumpers are fed from per-sample taps of the detection pass (6 bytes per sample, pinned): per file */
+    for (void **iter = cfg->demod->dumper.elems; iter && *iter; ++iter) {
+        file_info_t const *dumper = *iter;
+        if (dumper->file && (dumper->format == S16_AM || dumper->format == S16_FM || dumper->format == F32_AM || dumper->format == F32_FM))
             return 1;
     }
 #ifdef R433_HIP_HAVE_DRAIN
@@ -449,6 +462,33 @@ static void engine_ensure(r_cfg_t *cfg, r433_flow_cfg const *fc)
     H.eng_first_dev = first;
 }
 
+static uint8_t *conv_reserve(size_t need)
+{
+    if (need > H.conv_cap) {
+        free(H.conv);
+        H.conv = malloc(need);
+        if (!H.conv)
+            FATAL_MALLOC("hip dump conversion buffer");
+        H.conv_cap = need;
+    }
+    return H.conv;
+}
+
+/* the library's name of a dump format that is a conversion of the IQ frame (src/r_flow.c:396-432,456-479); 0 = not one */
+static int iq_dump_format(file_info_t const *dumper, unsigned sample_size, int *values_per_sample, int *out_width)
+{
+    *values_per_sample = 2;
+    switch (dumper->format) {
+    case CU8_IQ: *out_width = 1; return sample_size == 4 ? R433_DUMP_CU8_IQ : 0;
+    case CS16_IQ: *out_width = 2; return sample_size == 2 ? R433_DUMP_CS16_IQ : 0;
+    case CS8_IQ: *out_width = 1; return R433_DUMP_CS8_IQ;
+    case CF32_IQ: *out_width = 4; return R433_DUMP_CF32_IQ;
+    case F32_I: *values_per_sample = 1; *out_width = 4; return R433_DUMP_F32_I;
+    case F32_Q: *values_per_sample = 1; *out_width = 4; return R433_DUMP_F32_Q;
+    default: return 0;
+    }
+}
+
 static int run_group(r_cfg_t *cfg, hip_capture *group, size_t n)
 {
     struct dm_state *demod = cfg->demod;
@@ -472,7 +512,62 @@ static int run_group(r_cfg_t *cfg, hip_capture *group, size_t n)
             want_logic = 1;
     }
     r433_batch_enable_logic_dump(H.eng, want_logic);
+    /* `-w file.am.s16 / .fm.s16 / .am.f32 / .fm.f32`: the filtered envelope and discriminator of every sample, left behind by
+       the detection kernel in (pinned) tap buffers (src/r_flow.c:436-453 writes demod->am_buf / buf.fm of each frame) */
+    int want_taps = 0;
+    for (void **iter = demod->dumper.elems; iter && *iter; ++iter) {
+        file_info_t const *dumper = *iter;
+        if (dumper->file && (dumper->format == S16_AM || dumper->format == S16_FM || dumper->format == F32_AM || dumper->format == F32_FM))
+            want_taps = 1;
+    }
+    size_t tap_stride = 0;
+    if (want_taps) {
+        for (size_t i = 0; i < n; ++i) {
+            size_t ns = group[i].bytes / group[i].sample_size;
+            tap_stride = ns > tap_stride ? ns : tap_stride;
+        }
+        tap_stride = (tap_stride + 63) & ~(size_t)63;
+        if (n * tap_stride > H.taps_cap) {
+            for (int k = 0; k < 3; ++k) {
+                r433_host_free(H.taps[k]);
+                H.taps[k] = r433_host_alloc(n * tap_stride * sizeof(int16_t) + 64);
+                if (!H.taps[k])
+                    hip_fatal("pinned tap buffers");
+            }
+            H.taps_cap = n * tap_stride;
+        }
+        if (r433_batch_set_taps(H.eng, H.taps[0], H.taps[1], H.taps[2], tap_stride) < 0)
+            hip_fatal("r433_batch_set_taps");
+    }
+    else {
+        r433_batch_set_taps(H.eng, NULL, NULL, NULL, 0);
+    }
     int n_pkgs = r433_batch_run_host(H.eng, ptrs, bytes, (uint32_t)n);
+    if (n_pkgs >= 0 && want_taps) {
+        for (void **iter = demod->dumper.elems; iter && *iter; ++iter) {
+            file_info_t const *dumper = *iter;
+            if (!dumper->file)
+                continue;
+            int const is_am = dumper->format == S16_AM || dumper->format == F32_AM;
+            int const is_f32 = dumper->format == F32_AM || dumper->format == F32_FM;
+            if (!is_am && dumper->format != S16_FM && dumper->format != F32_FM)
+                continue;
+            for (size_t i = 0; i < n; ++i) {
+                size_t n_samples   = group[i].bytes / group[i].sample_size;
+                int16_t const *tap = H.taps[is_am ? 1 : 2] + i * tap_stride;
+                void const *out    = tap;
+                size_t out_len     = n_samples * sizeof(int16_t);
+                if (is_f32 && n_samples) { /* scale from Q0.15, src/r_flow.c:444-453 */
+                    out = conv_reserve(n_samples * sizeof(float));
+                    if (r433_dump_convert_host(is_am ? R433_DUMP_F32_AM : R433_DUMP_F32_FM, 2, tap, H.conv, n_samples) < 0)
+                        hip_fatal("r433_dump_convert_host");
+                    out_len = n_samples * sizeof(float);
+                }
+                if (fwrite(out, 1, out_len, dumper->file) != out_len)
+                    print_log(LOG_ERROR, __func__, "Short write, samples lost, exiting!");
+            }
+        }
+    }
     if (n_pkgs >= 0 && want_logic) {
         uint8_t const *logic = NULL;
         uint64_t stride      = 0;
@@ -734,9 +829,27 @@ int push_sdr_flow(r_cfg_t *cfg, unsigned char *iq_buf, uint32_t len)
                 d_events = -1;
             }
         }
-        else if (!H.warned_dump) {
-            H.warned_dump = 1;
-            print_logf(LOG_WARNING, "HIP", "sample dumper \"%s\" is not served by the HIP flow", dumper->spec);
+        else if (dumper->format == S16_AM || dumper->format == S16_FM || dumper->format == F32_AM || dumper->format == F32_FM) {
+            continue; /* written when the capture has been through the detection kernel (taps) */
+        }
+        else {
+            int per_sample = 2, width = 1;
+            int fmt = iq_dump_format(dumper, demod->sample_size, &per_sample, &width);
+            if (fmt) { /* a conversion of the IQ frame: the library's dump kernel on this frame */
+                size_t n_out   = n_samples * (size_t)per_sample;
+                size_t out_len = n_out * (size_t)width;
+                conv_reserve(out_len + 16);
+                if (n_out && r433_dump_convert_host(fmt, demod->sample_size, iq_buf, H.conv, n_out) < 0)
+                    hip_fatal("r433_dump_convert_host");
+                if (fwrite(H.conv, 1, out_len, dumper->file) != out_len) {
+                    print_log(LOG_ERROR, __func__, "Short write, samples lost, exiting!");
+                    d_events = -1;
+                }
+            }
+            else if (!H.warned_dump) {
+                H.warned_dump = 1;
+                print_logf(LOG_WARNING, "HIP", "sample dumper \"%s\" is not served by the HIP flow", dumper->spec);
+            }
         }
     }
 

@@ -362,6 +362,9 @@ int r433_analysis_text(r433_batch *b, uint32_t pkg, r433_analysis const *a, char
 #define R433_DUMP_F32_I 9   /* cu8: (I - 128) * (1.0f / 0x80), cs16: I * (1.0f / 0x8000) */
 #define R433_DUMP_F32_Q 10
 int r433_dump_convert(int format, uint32_t sample_size, void const *d_in, void *d_out, uint64_t n_out, void *stream);
+/* The same for a frame in HOST memory (the file loop's -w / -W dumpers, dropin/r_flow_hip.c): staged through device buffers of
+ * the library's own, synchronous.  No alignment requirement. */
+int r433_dump_convert_host(int format, uint32_t sample_size, void const *h_in, void *h_out, uint64_t n_out);
 /* AMP_TO_DB / MAG_TO_DB of a frame sum (include/baseband.h:36-37, src/baseband.c:44,78) */
 float r433_level_db(uint32_t sum, uint32_t n, int is_magnitude);
 

@@ -15,6 +15,7 @@ struct SeamCtx {
     DevBuf<StreamState> d_state;
     DevBuf<int> d_init;
     DevBuf<uint32_t> d_sum;
+    DevBuf<uint8_t> d_out;
     hipStream_t st = nullptr;
     int ensure_stream()
     {
@@ -126,6 +127,40 @@ int r433_envelope_host(uint32_t kind, void const *h_iq, uint16_t *h_env, uint32_
     HIP_TRY(hipStreamSynchronize(c.st));
     if (sum)
         *sum = s;
+    return 0;
+}
+
+// r433_dump_convert for a caller whose frame sits in HOST memory (dropin/r_flow_hip.c: the -w / -W sample dumpers of the file
+// loop, one frame per call): staged through device buffers of the library's own, converted by the same kernel.
+int r433_dump_convert_host(int format, uint32_t sample_size, void const *h_in, void *h_out, uint64_t n_out)
+{
+    if (format < R433_DUMP_CU8_IQ || format > R433_DUMP_F32_Q)
+        return fail(R433_EINVAL, "unknown dump format %d", format);
+    if (sample_size != 2 && sample_size != 4)
+        return fail(R433_EINVAL, "sample_size must be 2 (cu8) or 4 (cs16)");
+    if (n_out == 0)
+        return 0;
+    if (!h_in || !h_out)
+        return fail(R433_EINVAL, "null argument");
+    if (r433_device_count() < 0)
+        return R433_ENODEV;
+    // bytes in: IQ formats and the I / Q picks read IQ components of the input's own width; the AM / FM formats read an s16 stream
+    bool const from_taps = format == R433_DUMP_S16_AM || format == R433_DUMP_S16_FM || format == R433_DUMP_F32_AM || format == R433_DUMP_F32_FM;
+    bool const pick = format == R433_DUMP_F32_I || format == R433_DUMP_F32_Q;
+    uint64_t const in_bytes = from_taps ? n_out * 2 : pick ? n_out * sample_size : n_out * (sample_size / 2);
+    uint64_t const out_width = (format == R433_DUMP_CU8_IQ || format == R433_DUMP_CS8_IQ) ? 1 : (format == R433_DUMP_CS16_IQ || format == R433_DUMP_S16_AM || format == R433_DUMP_S16_FM) ? 2 : 4;
+    uint64_t const out_bytes = n_out * out_width;
+    if (in_bytes > 0xfffffff0ull || out_bytes > 0xfffffff0ull)
+        return fail(R433_EINVAL, "frames are limited to 4 GiB");
+    SeamCtx &c = g_seam;
+    int rc;
+    if ((rc = c.ensure_stream()) || (rc = c.d_in.ensure(in_bytes + 64)) || (rc = c.d_out.ensure(out_bytes + 64)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(c.d_in.p, h_in, in_bytes, hipMemcpyHostToDevice, c.st));
+    if ((rc = r433_dump_convert(format, sample_size, c.d_in.p, c.d_out.p, n_out, c.st)) < 0)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(h_out, c.d_out.p, out_bytes, hipMemcpyDeviceToHost, c.st));
+    HIP_TRY(hipStreamSynchronize(c.st));
     return 0;
 }
 

@@ -122,3 +122,34 @@ def test_gpu_dump_of_engine_taps_matches_reference():
             torch.cuda.synchronize()
             data = d_out.cpu().numpy()[: 4 * n].tobytes()
             assert hashlib.sha256(data).hexdigest() == GOLD[name][fmt]["sha256"], (name, fmt)
+
+
+def _host_variant(L, name):
+    """r433_dump_convert_host (what the drop-in's -w / -W dumpers call per frame): unaligned host buffers, odd lengths."""
+    src = _sources(name)
+    for fmt in po.DUMP_FORMATS:
+        arr, ss = src[fmt]
+        want = po.dump_convert(fmt, ss, arr)
+        n_all = len(arr) // 2 if fmt in ("i.f32", "q.f32") else len(arr)
+        for n_out in (n_all, 2 * 4097, 6):
+            n_out = min(n_out, n_all)
+            raw = np.zeros(arr.nbytes + 3, dtype=np.uint8)
+            raw[1:1 + arr.nbytes] = arr.view(np.uint8)  # deliberately misaligned
+            out = np.full(_out_bytes(fmt, n_out) + 8, 0xA5, dtype=np.uint8)
+            rc = L.r433_dump_convert_host(_lib.DUMP_FORMATS[fmt], ss, C.c_void_p(raw.ctypes.data + 1), C.c_void_p(out.ctypes.data), n_out)
+            assert rc == 0, (fmt, _lib.last_error(L))
+            nb = _out_bytes(fmt, n_out)
+            assert out[:nb].tobytes() == want[:nb], (name, fmt, n_out)
+            assert (out[nb:] == 0xA5).all(), (name, fmt, n_out)
+
+
+@pytest.mark.parametrize("name", ["cu8", "cs16"])
+def test_emulator_host_variant(name):
+    from tests.emu.host import emu_lib
+    _host_variant(emu_lib(), name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cu8", "cs16"])
+def test_gpu_host_variant(name):
+    _host_variant(_lib.lib(), name)
