@@ -31,8 +31,9 @@
     Deferred work means push_sdr_flow returns 0 and the flush (or the drain) returns the events; "-E quit" style
     options that look at the per-frame event count therefore act at file granularity.
 
-    Not served by this flow (reported once, then ignored): the sample grabber (-S) and S16_AM / S16_FM pseudo-IQ input
-    files; the raw rtl_tcp output's per-frame pacing is kept.  Every -w / -W dumper is served: the input's own format is a
+    Not served by this flow (reported once, then ignored): S16_AM / S16_FM pseudo-IQ input files and the sample grabber's
+    "undecoded" mode (it needs the analyzer's frame quality); the raw rtl_tcp output's per-frame pacing is kept.  The sample
+    grabber (-S all | unknown | known, raw or SigMF) writes its files after the replay of a pass (write_grabs below).  Every -w / -W dumper is served: the input's own format is a
     copy, the other IQ formats are the library's dump kernel on each frame, am / fm dumps come from the detection pass's
     taps, .u8 is painted by the detection kernel, .ook / .vcd are written during the replay.  (One quirk of the reference
     is NOT reproduced: its IQ conversions write into a buffer that is a union with buf.fm, so an IQ dumper listed before
@@ -60,6 +61,8 @@
 #include "r_util.h"
 #include "logger.h"
 #include "fatal.h"
+
+#include "samp_grab.h"
 
 #include "r433_hip.h"
 
@@ -106,6 +109,10 @@ static struct {
     size_t conv_cap;
     int16_t *taps[3];   /* pinned: raw envelope, filtered envelope, filtered discriminator of the captures of a pass (am / fm dumpers) */
     size_t taps_cap;
+    uint8_t *hist;      /* the sample grabber's view of the past: the last 3 MiB pushed before the captures now queued */
+    size_t hist_len;
+    uint64_t pushed_before_queue; /* bytes pushed, ever, before the first capture of the queue */
+    int warned_grab_mode;
     uint32_t fm_note_rate; /* the rate the "FM low pass filter" notice was last printed for (src/baseband.c:217,310) */
     /* replay context */
     r_cfg_t *cfg;
@@ -489,6 +496,121 @@ static int iq_dump_format(file_info_t const *dumper, unsigned sample_size, int *
     }
 }
 
+/* ---- the sample grabber (-S all | unknown | known; src/r_flow.c:136-147,342-362, src/samp_grab.c:97-233) ----
+   The reference keeps the last 3 MiB of everything pushed in a ring and, when a frame with signal is over, saves the padded
+   stretch around it to g<counter>_<freq>M_<rate>k.<type> (or a SigMF container).  Here the captures of a pass are still in the
+   staging buffer after the replay: r433_batch_grab_plan says which byte range of which capture each file holds (from the
+   package records and the decode results), and what the ring would have held from before a capture's first byte -- the
+   tails of the captures pushed before it, zeros before the first -- comes from the queue and a 3 MiB history of earlier passes. */
+#define GRAB_RING (12u * 262144u)  /* SIGNAL_GRABBER_BUFFER, include/rtl_433.h:22 */
+#define GRAB_BLOCK (128u * 1024u)  /* src/samp_grab.c:95 */
+
+/* the `need` bytes pushed right before capture `idx` of the queue, oldest first */
+static void grab_write_before(size_t idx, size_t need, FILE *fp)
+{
+    size_t from_caps = 0, k = idx;
+    while (k > 0 && from_caps < need) { /* how far back into the queue */
+        --k;
+        from_caps += H.caps[k].bytes;
+    }
+    size_t from_hist  = from_caps < need ? need - from_caps : 0;
+    size_t zeros      = 0;
+    if (from_hist > H.hist_len) {
+        zeros     = from_hist - H.hist_len;
+        from_hist = H.hist_len;
+    }
+    static uint8_t const zero[4096];
+    for (size_t z = zeros; z > 0;) {
+        size_t w = z < sizeof(zero) ? z : sizeof(zero);
+        fwrite(zero, 1, w, fp);
+        z -= w;
+    }
+    if (from_hist)
+        fwrite(H.hist + H.hist_len - from_hist, 1, from_hist, fp);
+    size_t skip = from_caps > need ? from_caps - need : 0; /* of the oldest capture reached */
+    for (; k < idx; ++k) {
+        fwrite(H.stage + H.caps[k].offset + skip, 1, H.caps[k].bytes - skip, fp);
+        skip = 0;
+    }
+}
+
+static void write_grabs(r_cfg_t *cfg, hip_capture *group, size_t n)
+{
+    struct dm_state *demod = cfg->demod;
+    samp_grab_t *g         = demod->samp_grab;
+    if (!g || !demod->grab_mode)
+        return;
+    if (demod->grab_mode < 1 || demod->grab_mode > 3) {
+        if (!H.warned_grab_mode) {
+            H.warned_grab_mode = 1;
+            print_log(LOG_WARNING, "HIP", "sample grabber mode \"undecoded\" (-S undecoded) is not served by the HIP flow");
+        }
+        return;
+    }
+    int count = r433_batch_grab_plan(H.eng, demod->grab_mode, NULL, 0);
+    if (count < 0)
+        hip_fatal("r433_batch_grab_plan");
+    if (count == 0)
+        return;
+    r433_grab *plan = calloc((size_t)count, sizeof(*plan));
+    if (!plan)
+        FATAL_CALLOC("hip grab plan");
+    if (r433_batch_grab_plan(H.eng, demod->grab_mode, plan, (uint32_t)count) < 0)
+        hip_fatal("r433_batch_grab_plan");
+    for (int k = 0; k < count; ++k) {
+        hip_capture const *c = &group[plan[k].stream];
+        (void)n;
+        unsigned ss           = (unsigned)c->sample_size;
+        unsigned signal_bsize = ss * plan[k].n_samples;
+        signal_bsize += GRAB_BLOCK - (signal_bsize % GRAB_BLOCK);
+        /* the ring's fill when the reference writes this file: everything pushed so far, at most the ring (src/samp_grab.c:84-87) */
+        uint64_t fill = H.pushed_before_queue + plan[k].pushed;
+        for (hip_capture const *q = H.caps; q < c; ++q)
+            fill += q->bytes;
+        unsigned sg_len = fill > GRAB_RING ? GRAB_RING : (unsigned)fill;
+        if (signal_bsize > sg_len) {
+            fprintf(stderr, "Signal bigger than buffer, signal = %u > buffer %u !!\n", signal_bsize, sg_len);
+            signal_bsize = sg_len;
+        }
+        double freq_mhz = c->center_frequency / 1000000.0;
+        double rate_khz = c->samp_rate / 1000.0;
+        char f_name[64] = {0};
+        while (1) {
+            snprintf(f_name, sizeof(f_name), "g%03u_%gM_%gk.%s", g->sg_counter, freq_mhz, rate_khz,
+                    g->sg_fileformat ? "sigmf" : ss == 2 ? "cu8" : "cs16");
+            g->sg_counter++;
+            if (access(f_name, F_OK) == -1)
+                break;
+        }
+        fprintf(stderr, "*** Saving signal to file %s (%u samples, %u bytes)\n", f_name, plan[k].n_samples, signal_bsize);
+        FILE *fp = fopen(f_name, "wb");
+        if (!fp) {
+            fprintf(stderr, "Failed to open %s\n", f_name);
+            continue;
+        }
+        char wrap[4096];
+        if (g->sg_fileformat) { /* the reference's SigMF container around the same bytes (src/sigmf.c, microtar) */
+            int w = r433_sigmf_prefix(ss, c->samp_rate, c->center_frequency, signal_bsize, wrap, sizeof(wrap));
+            if (w < 0)
+                hip_fatal("r433_sigmf_prefix");
+            fwrite(wrap, 1, (size_t)w, fp);
+        }
+        uint64_t end_byte = plan[k].byte_offset + plan[k].byte_len; /* where the stretch ends inside the capture */
+        size_t inside     = end_byte < signal_bsize ? (size_t)end_byte : signal_bsize;
+        if (inside < signal_bsize)
+            grab_write_before((size_t)(c - H.caps), signal_bsize - inside, fp);
+        fwrite(H.stage + c->offset + (end_byte - inside), 1, inside, fp);
+        if (g->sg_fileformat) {
+            int w = r433_sigmf_trailer(signal_bsize, wrap, sizeof(wrap));
+            if (w < 0)
+                hip_fatal("r433_sigmf_trailer");
+            fwrite(wrap, 1, (size_t)w, fp);
+        }
+        fclose(fp);
+    }
+    free(plan);
+}
+
 static int run_group(r_cfg_t *cfg, hip_capture *group, size_t n)
 {
     struct dm_state *demod = cfg->demod;
@@ -620,6 +742,7 @@ static int run_group(r_cfg_t *cfg, hip_capture *group, size_t n)
     }
     if (events < 0)
         hip_fatal("r433_batch_dispatch_hooks");
+    write_grabs(cfg, group, n);
     /* captures without packages (and the frames after the last package) still count their frames */
     enter_capture((uint32_t)n - 1);
     account_frames(&group[n - 1], (uint32_t)n - 1, UINT32_MAX);
@@ -666,6 +789,30 @@ int hip_sdr_flow_drain(struct r_cfg *cfg)
         i = j;
     }
 
+    /* the sample grabber's history: what was pushed last, for signals near the start of the captures of the next pass */
+    if (demod->samp_grab && n_run) {
+        uint8_t *h = malloc(GRAB_RING);
+        if (!h)
+            FATAL_MALLOC("hip grab history");
+        size_t have = 0, k = n_run;
+        while (k > 0 && have < GRAB_RING) { /* newest first, filled from the end */
+            --k;
+            size_t take = H.caps[k].bytes < GRAB_RING - have ? H.caps[k].bytes : GRAB_RING - have;
+            memcpy(h + GRAB_RING - have - take, H.stage + H.caps[k].offset + (H.caps[k].bytes - take), take);
+            have += take;
+        }
+        if (have < GRAB_RING && H.hist_len) {
+            size_t take = H.hist_len < GRAB_RING - have ? H.hist_len : GRAB_RING - have;
+            memcpy(h + GRAB_RING - have - take, H.hist + H.hist_len - take, take);
+            have += take;
+        }
+        memmove(h, h + GRAB_RING - have, have);
+        free(H.hist);
+        H.hist     = h;
+        H.hist_len = have;
+    }
+    for (size_t i = 0; i < n_run; ++i)
+        H.pushed_before_queue += H.caps[i].bytes;
     /* keep a capture that is still open at the front of the queue */
     for (size_t i = 0; i < n_run; ++i)
         capture_free(&H.caps[i]);
@@ -760,10 +907,6 @@ int push_sdr_flow(r_cfg_t *cfg, unsigned char *iq_buf, uint32_t len)
 
     get_time_now(&demod->now);
 
-    if (demod->samp_grab && !H.warned_grab) {
-        H.warned_grab = 1;
-        print_log(LOG_WARNING, "HIP", "the sample grabber (-S) is not served by the HIP flow");
-    }
     if (demod->load_info.format == S16_AM || demod->load_info.format == S16_FM) {
         print_log(LOG_ERROR, "HIP", "AM / FM sample files are not served by the HIP flow");
         return -1;

@@ -309,6 +309,8 @@ typedef struct r433_grab {
     uint64_t byte_len;    /* multiple of 128 KiB unless cut by the start of the capture or the 3 MiB ring */
     uint32_t n_samples;   /* the padded signal length the reference reports */
     uint32_t clipped;     /* 1: the reference would have read ring memory older than the capture here */
+    uint64_t pushed;      /* bytes of the capture pushed when the reference writes the file (its ring holds that much of this capture,
+                             plus what came before it: the file is as long as the ring's fill allows, src/samp_grab.c:110-113) */
 } r433_grab;
 int r433_batch_grab_plan(r433_batch *b, int grab_mode, r433_grab *out, uint32_t max_grabs);
 /* The SigMF container the grabber writes with `-S sigmf:...` (src/samp_grab.c:166-232, src/sigmf.c, microtar): the

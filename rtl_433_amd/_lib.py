@@ -68,7 +68,7 @@ class Analysis(C.Structure):
 class Grab(C.Structure):
     """r433_grab (include/r433_hip.h)."""
     _fields_ = [("stream", C.c_uint32), ("counter", C.c_uint32), ("byte_offset", C.c_uint64), ("byte_len", C.c_uint64),
-                ("n_samples", C.c_uint32), ("clipped", C.c_uint32)]
+                ("n_samples", C.c_uint32), ("clipped", C.c_uint32), ("pushed", C.c_uint64)]
 
 
 class SigmfInfo(C.Structure):

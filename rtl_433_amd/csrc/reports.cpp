@@ -280,6 +280,7 @@ int r433_batch_grab_plan(r433_batch *b, int grab_mode, r433_grab *out, uint32_t 
                         g.byte_len = end_byte - want_start;
                         g.n_samples = len_padded;
                         g.clipped = end_byte < bsize ? 1u : 0u;
+                        g.pushed = pushed;
                     }
                     n_out += 1;
                     counter += 1;

@@ -358,3 +358,39 @@ def test_every_sample_dumper(binary, tmp_path):
             for x in dumpers:
                 assert len(got["ref"][1][x]) > 0, (inputs, x)
                 assert got["ref"][1][x] == got["new"][1][x], (inputs, x)
+
+
+@pytest.mark.parametrize("binary", [pytest.param(EMU, id="emu"), pytest.param(HIP, id="hip", marks=pytest.mark.gpu)])
+def test_sample_grabber(binary, tmp_path):
+    """-S all | unknown | known and the SigMF variant over a list of files: the same g###_<freq>M_<rate>k files with the same
+    bytes (the first grab reaches back across a file boundary: the ring's history), the same messages; also with one GPU pass
+    per file, where the history comes from the pass before."""
+    _ensure_built(binary)
+    shutil.copy(os.path.join(GOLD, "nice_250k.cu8"), tmp_path / "g001_433.92M_250k.cu8")
+    synth.ook_stream(12, 40000)[0].tofile(tmp_path / "o_433.92M_250k.cu8")
+    synth.ook_stream(21, 400000)[0].tofile(tmp_path / "big_433.92M_250k.cu8")
+    files = ["g001_433.92M_250k.cu8", "o_433.92M_250k.cu8", "big_433.92M_250k.cu8", "g001_433.92M_250k.cu8"]
+
+    def run(b, mode, env=None):
+        d = tmp_path / "work"
+        shutil.rmtree(d, ignore_errors=True)
+        d.mkdir()
+        e = dict(os.environ)
+        e.update(env or {})
+        p = subprocess.run([b] + sum((["-r", "../" + f] for f in files), []) + ["-R", "169", "-S", mode, "-F", "json"], cwd=d, env=e,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+        assert p.returncode == 0, p.stderr.decode(errors="replace")[-1000:]
+        notes = [l for l in p.stderr.decode(errors="replace").splitlines() if l.startswith("***") or l.startswith("Signal bigger")]
+        return p.stdout.decode(), notes, {f: (d / f).read_bytes() for f in sorted(os.listdir(d))}
+
+    for mode in ("all", "unknown", "known", "sigmf:all"):
+        ref = run(REF, mode)
+        if mode in ("all", "sigmf:all"):
+            assert len(ref[2]) >= 2 and len(ref[1]) >= 2
+        for env in (None, {"RTL433_HIP_BATCH": "1"}):
+            got = run(binary, mode, env)
+            assert got[0] == ref[0], (mode, env)
+            assert got[1] == ref[1], (mode, env)
+            assert sorted(got[2]) == sorted(ref[2]), (mode, env)
+            for f in ref[2]:
+                assert got[2][f] == ref[2][f], (mode, env, f)
