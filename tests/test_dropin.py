@@ -277,7 +277,7 @@ def test_reference_flow_over_the_function_seam(binary, tmp_path):
 
 
 OPTION_SETS = [
-    ["-F", "json", "-M", "level", "-M", "stats:2:1"],
+    ["-F", "json", "-M", "level", "-M", "stats:2:3600"],  # (a short report interval is a wall-clock event: not comparable)
     ["-F", "json", "-M", "level", "-Y", "autolevel", "-Y", "magest"],
     ["-F", "json", "-M", "level", "-Y", "level=-5", "-Y", "minlevel=-20", "-Y", "minsnr=6"],
     ["-F", "csv", "-M", "level"],
