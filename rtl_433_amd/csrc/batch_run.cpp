@@ -11,6 +11,7 @@ namespace {
 
 // What one r433_batch_run call carries from stage to stage.
 struct RunCtx {
+    std::unique_lock<std::mutex> turn{g_detect_turn, std::defer_lock}; // exclusive_detect: this pass's turn on the detection kernel
     r433_batch *b;
     hipStream_t st;
     uint32_t ss;                  // bytes per sample: 2 = cu8, 4 = cs16
@@ -471,7 +472,7 @@ int run_detect(RunCtx &r)
     int rc;
     // the calling thread waits for the detection kernel below anyway (it needs the package count): holding the turn until
     // then keeps two engines' detection kernels from running side by side
-    std::unique_lock<std::mutex> turn(g_detect_turn, std::defer_lock);
+    std::unique_lock<std::mutex> &turn = r.turn;
     if (b->exclusive_detect) {
         turn.lock();
         if (b->profiling) // the time spent waiting for the turn is not the kernel's
@@ -514,6 +515,8 @@ int run_detect(RunCtx &r)
         b->arena_growth *= 4;
         b->arena_stride = (uint32_t)std::min<uint64_t>((uint64_t)b->arena_stride * 4, 1u << 30);
     }
+    if (turn.owns_lock() && b->exclusive_detect < 2)
+        turn.unlock(); // level 2 keeps the turn through the slicer kernels (run_slice_and_mirror)
     return 0;
 }
 
@@ -621,6 +624,10 @@ int run_slice_and_mirror(RunCtx &r)
     }
     if (b->profiling)
         HIP_TRY(hipEventRecord(b->ev[5], r.st));
+    if (r.turn.owns_lock()) { // exclusive level 2: the kernels of this pass are done before the next engine's begin
+        HIP_TRY(stream_wait(b, r.st));
+        r.turn.unlock();
+    }
     if (pkg_bytes)
         HIP_TRY(hipMemcpyAsync(b->h_pkg_blob.p, b->d_pkg_blob.p, pkg_bytes, hipMemcpyDeviceToHost, r.st));
     if (evt_bytes)

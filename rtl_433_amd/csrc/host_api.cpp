@@ -326,7 +326,7 @@ int r433_batch_set_exclusive_detect(r433_batch *b, int on)
 {
     if (!b)
         return fail(R433_EINVAL, "null batch");
-    b->exclusive_detect = on != 0;
+    b->exclusive_detect = on < 0 ? 0 : on > 2 ? 2 : on;
     return 0;
 }
 

@@ -194,7 +194,7 @@ struct r433_batch {
     // split captures (r433_batch_set_split)
     uint32_t split_samples = R433_SPLIT_AUTO;
     uint32_t debug_flags = 0; // r433_batch_set_debug
-    bool exclusive_detect = false; // r433_batch_set_exclusive_detect
+    int exclusive_detect = 0; // r433_batch_set_exclusive_detect: 1 the detection kernel, 2 the slicer kernels as well
     bool logic_on = false;         // r433_batch_enable_logic_dump
     DevBuf<uint8_t> d_logic;
     PinBuf<uint8_t> h_logic;
