@@ -123,7 +123,9 @@ int r433_batch_set_split(r433_batch *b, uint32_t segment_samples);
 /* Several engines of one process, each on its own stream (a software pipeline over batches): with this set, their
  * detection kernels take turns instead of sharing the compute units -- a launch fills every SIMD by itself, two of them
  * side by side only stretch each other -- while everything after detection (slicers, record copies) still overlaps the
- * next engine's detection.  Off by default: a lone engine has nobody to wait for. */
+ * next engine's detection.  on = 2: the turn lasts until the slicer kernels of the pass are done as well (they, too, fill
+ * the chip by themselves; record copies and the host replay still overlap the next engine's kernels).  Off by default: a
+ * lone engine has nobody to wait for. */
 int r433_batch_set_exclusive_detect(r433_batch *b, int on);
 /* of the last run: wavefront slots planned (segments incl. parity variants), pieces run again after a dropped cut */
 int r433_batch_split_stats(r433_batch *b, uint32_t *segments, uint32_t *pieces_rerun);

@@ -139,7 +139,8 @@ class BatchEngine:
         return out
 
     def set_exclusive_detect(self, on=True):
-        """Engines of a software pipeline take turns on the detection kernel (r433_batch_set_exclusive_detect)."""
+        """Engines of a software pipeline take turns on the detection kernel (1 / True), or on all kernels of a pass (2)
+        (r433_batch_set_exclusive_detect)."""
         _lib.check(self.L.r433_batch_set_exclusive_detect(self.h, int(on)), "r433_batch_set_exclusive_detect", self.L)
 
     def set_debug(self, flags):
