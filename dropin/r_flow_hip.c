@@ -28,8 +28,10 @@
       - at hip_sdr_flow_drain(cfg), which the host calls once after its file loop and before close_dumpers()
         (one added line in src/rtl_433.c:1860; builds of the unmodified rtl_433.c get the same effect from
         -Dclose_dumpers=hip_sdr_flow_close_dumpers on that one file, see dropin/Makefile).
-    Deferred work means push_sdr_flow returns 0 and the flush (or the drain) returns the events; "-E quit" style
-    options that look at the per-frame event count therefore act at file granularity.
+    Deferred work means push_sdr_flow returns 0 and the flush (or the drain) returns the events.  With -E quit / -E hop the
+    file loop acts on the event count of every push (src/rtl_433.c:1136-1143): then nothing is deferred -- every push runs
+    the capture as far as it has come and replays its newest packages (sync_step below), and the loop quits where the
+    reference's does.
 
     Not served by this flow (reported once, then ignored): S16_AM / S16_FM pseudo-IQ input files and the sample grabber's
     "undecoded" mode (it needs the analyzer's frame quality); the raw rtl_tcp output's per-frame pacing is kept.  The sample
@@ -113,6 +115,10 @@ static struct {
     size_t hist_len;
     uint64_t pushed_before_queue; /* bytes pushed, ever, before the first capture of the queue */
     int warned_grab_mode;
+    /* answering every push at once (-E: the file loop acts on the event count of a push) */
+    int sync_active, sync_flush, warned_sync_grab;
+    uint32_t sync_frame;            /* the frame just pushed */
+    unsigned sync_count, sync_squelch; /* frames / noise-only frames the run before this one counted for the same capture */
     uint32_t fm_note_rate; /* the rate the "FM low pass filter" notice was last printed for (src/baseband.c:217,310) */
     /* replay context */
     r_cfg_t *cfg;
@@ -243,8 +249,9 @@ static void account_frames(hip_capture *c, uint32_t stream, uint32_t upto)
             if (demod->auto_level > 0 && demod->noise_level < demod->min_level - 3.0f
                     && fabsf(demod->min_level_auto - demod->noise_level - 3.0f) > 1.0f) {
                 demod->min_level_auto = demod->noise_level + 3.0f;
-                print_logf(LOG_WARNING, "Auto Level", "Estimated noise level is %.1f dB, adjusting minimum detection level to %.1f dB",
-                        demod->noise_level, demod->min_level_auto);
+                if (!H.sync_active || (!H.sync_flush && f >= H.sync_frame)) /* (a frame replayed again for -E has said it already) */
+                    print_logf(LOG_WARNING, "Auto Level", "Estimated noise level is %.1f dB, adjusting minimum detection level to %.1f dB",
+                            demod->noise_level, demod->min_level_auto);
             }
         }
         else {
@@ -469,6 +476,29 @@ static void engine_ensure(r_cfg_t *cfg, r433_flow_cfg const *fc)
     H.eng_first_dev = first;
 }
 
+/* -E quit / -E hop: src/rtl_433.c:1136-1143 acts on the events of each push, so a push cannot be left for later.  The capture as
+   far as it has been pushed is run again from its first sample (the detector is causal: the packages of the earlier frames
+   come out as before) and only the packages the reference would have returned from THIS call go through the decoders. */
+static int sync_filter(void *user, r433_pkg_rec const *rec)
+{
+    (void)user;
+    int const from_flush = rec->ret_pos == R433_RET_FLUSH;
+    if (H.sync_flush)
+        return from_flush;
+    return !from_flush && rec->frame == H.sync_frame;
+}
+
+/* the first sample of a capture whose dump bytes have not been written yet (everything, unless frames are replayed again for -E) */
+static size_t sync_first_sample(hip_capture const *c, size_t n_samples)
+{
+    if (!H.sync_active)
+        return 0;
+    if (H.sync_flush)
+        return n_samples;
+    size_t from = (size_t)H.sync_frame * (c->frame_bytes / (unsigned)c->sample_size);
+    return from < n_samples ? from : n_samples;
+}
+
 static uint8_t *conv_reserve(size_t need)
 {
     if (need > H.conv_cap) {
@@ -540,6 +570,13 @@ static void write_grabs(r_cfg_t *cfg, hip_capture *group, size_t n)
     samp_grab_t *g         = demod->samp_grab;
     if (!g || !demod->grab_mode)
         return;
+    if (H.sync_active) {
+        if (!H.warned_sync_grab) {
+            H.warned_sync_grab = 1;
+            print_log(LOG_WARNING, "HIP", "the sample grabber (-S) is not served together with -E");
+        }
+        return;
+    }
     if (demod->grab_mode < 1 || demod->grab_mode > 3) {
         if (!H.warned_grab_mode) {
             H.warned_grab_mode = 1;
@@ -675,8 +712,10 @@ static int run_group(r_cfg_t *cfg, hip_capture *group, size_t n)
             if (!is_am && dumper->format != S16_FM && dumper->format != F32_FM)
                 continue;
             for (size_t i = 0; i < n; ++i) {
-                size_t n_samples   = group[i].bytes / group[i].sample_size;
-                int16_t const *tap = H.taps[is_am ? 1 : 2] + i * tap_stride;
+                size_t all_samples = group[i].bytes / group[i].sample_size;
+                size_t from        = sync_first_sample(&group[i], all_samples);
+                size_t n_samples   = all_samples - from;
+                int16_t const *tap = H.taps[is_am ? 1 : 2] + i * tap_stride + from;
                 void const *out    = tap;
                 size_t out_len     = n_samples * sizeof(int16_t);
                 if (is_f32 && n_samples) { /* scale from Q0.15, src/r_flow.c:444-453 */
@@ -701,7 +740,8 @@ static int run_group(r_cfg_t *cfg, hip_capture *group, size_t n)
                 continue;
             for (size_t i = 0; i < n; ++i) {
                 size_t n_samples = group[i].bytes / group[i].sample_size;
-                if (fwrite(logic + i * stride, 1, n_samples, dumper->file) != n_samples)
+                size_t from      = sync_first_sample(&group[i], n_samples);
+                if (fwrite(logic + i * stride + from, 1, n_samples - from, dumper->file) != n_samples - from)
                     print_log(LOG_ERROR, __func__, "Short write, samples lost, exiting!");
             }
         }
@@ -728,11 +768,11 @@ static int run_group(r_cfg_t *cfg, hip_capture *group, size_t n)
     int n_threads = replay_threads();
     int events;
     if (chatty || n_threads <= 1) {
-        r433_dispatch_hooks hooks = {NULL, on_package_begin, on_event_done, on_package_end};
+        r433_dispatch_hooks hooks = {NULL, on_package_begin, on_event_done, on_package_end, H.sync_active ? sync_filter : NULL};
         events = r433_batch_dispatch_hooks(H.eng, (r433_r_device *const *)demod->r_devs.elems, (uint32_t)demod->r_devs.len, &hooks);
     }
     else {
-        r433_dispatch_hooks hooks = {NULL, on_package_begin, NULL, on_package_end};
+        r433_dispatch_hooks hooks = {NULL, on_package_begin, NULL, on_package_end, H.sync_active ? sync_filter : NULL};
         events = r433_batch_dispatch_ordered(H.eng, (r433_r_device *const *)demod->r_devs.elems, (uint32_t)demod->r_devs.len, &hooks, (uint32_t)n_threads);
     }
     if (events == R433_EDECODER) {
@@ -878,6 +918,52 @@ void reset_sdr_flow(r_cfg_t *cfg)
     H.fm_note_rate = 0; /* baseband_demod_FM_reset zeroes the rate the notice is keyed on */
 }
 
+/* one push (or the flush) of the open capture, answered now: the capture so far through the GPU, its newest packages replayed */
+static int sync_step(r_cfg_t *cfg, int flush)
+{
+    struct dm_state *demod = cfg->demod;
+    if (!H.n_caps)
+        return 0;
+    hip_capture *c = &H.caps[H.n_caps - 1];
+    if (!c->n_frames || !c->bytes)
+        return 0;
+    if (c->irregular || (c->n_frames > 1 && c->frame_bytes / c->sample_size % 64 != 0)) {
+        if (flush)
+            print_logf(LOG_ERROR, "HIP", "\"%s\": frames of unequal or odd length are not served by the HIP flow, capture skipped",
+                    c->in_filename ? c->in_filename : "?");
+        return 0;
+    }
+    /* what the host has set for this file is what the replay wants: nothing to restore but the clocks of the push */
+    float keep_pos = demod->sample_file_pos, keep_noise = demod->noise_level, keep_auto = demod->min_level_auto;
+    struct timeval keep_now = demod->now;
+    unsigned base_count = demod->total_frames_count, base_squelch = demod->total_frames_squelch;
+
+    H.sync_active = 1;
+    H.sync_flush  = flush;
+    H.sync_frame  = c->n_frames - 1;
+    int events    = run_group(cfg, c, 1);
+    H.sync_active = 0;
+
+    /* the frames of the capture were counted from its first one again: keep what this push adds */
+    unsigned made_count = demod->total_frames_count - base_count, made_squelch = demod->total_frames_squelch - base_squelch;
+    demod->total_frames_count   = base_count + (made_count - H.sync_count);
+    demod->total_frames_squelch = base_squelch + (made_squelch - H.sync_squelch);
+    H.sync_count                = made_count;
+    H.sync_squelch              = made_squelch;
+    (void)keep_noise;
+    (void)keep_auto; /* noise_level / min_level_auto: as the replay of all frames so far leaves them, like the reference's */
+    demod->sample_file_pos = keep_pos;
+    demod->now             = keep_now;
+    if (flush) { /* the capture is done: nothing of it is left for a drain */
+        H.pushed_before_queue += c->bytes;
+        H.stage_len = c->offset;
+        capture_free(c);
+        H.n_caps -= 1;
+        H.sync_count = H.sync_squelch = 0;
+    }
+    return events;
+}
+
 int push_sdr_flow(r_cfg_t *cfg, unsigned char *iq_buf, uint32_t len)
 {
     struct dm_state *demod = cfg->demod;
@@ -888,6 +974,11 @@ int push_sdr_flow(r_cfg_t *cfg, unsigned char *iq_buf, uint32_t len)
 
     if (!len) {
         /* flush: the capture is complete */
+        if (cfg->after_successful_events_flag && H.open) {
+            int ev = sync_step(cfg, 1);
+            H.open = 0;
+            return ev;
+        }
         H.open = 0;
         if (H.n_caps >= batch_limit(cfg) || H.stage_len >= ((size_t)1 << 30))
             return hip_sdr_flow_drain(cfg);
@@ -998,5 +1089,7 @@ int push_sdr_flow(r_cfg_t *cfg, unsigned char *iq_buf, uint32_t len)
 
     demod->input_pos += n_samples;
 
+    if (cfg->after_successful_events_flag && d_events >= 0)
+        return sync_step(cfg, 0);
     return d_events;
 }

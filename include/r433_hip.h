@@ -192,6 +192,10 @@ typedef struct r433_dispatch_hooks {
     void (*package_begin)(void *user, r433_pkg_rec const *rec, r433_pulse_data const *pulses);
     void (*event_done)(void *user, r433_r_device *device, int ret, r433_bitbuffer const *bits);
     void (*package_end)(void *user, r433_pkg_rec const *rec, int p_events);
+    /* optional: return 0 to leave a package out of the replay altogether (no decoder sees it, no other hook is called for it).
+     * dropin/r_flow_hip.c uses it when it has to answer every push at once (-E quit): it then replays a growing prefix of the
+     * capture and only lets the packages of the newest frame through. */
+    int (*package_filter)(void *user, r433_pkg_rec const *rec);
 } r433_dispatch_hooks;
 int r433_batch_dispatch_hooks(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices,
         r433_dispatch_hooks const *hooks);

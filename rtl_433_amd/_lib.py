@@ -100,10 +100,13 @@ HOOK_EVENT_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(RDevice), C.c_int, C.c_v
 HOOK_END_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(PkgRec), C.c_int)
 
 
+HOOK_FILTER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(PkgRec))
+
+
 class DispatchHooks(C.Structure):
     """r433_dispatch_hooks (include/r433_hip.h)."""
     _fields_ = [("user", C.c_void_p), ("package_begin", HOOK_BEGIN_FN), ("event_done", HOOK_EVENT_FN),
-                ("package_end", HOOK_END_FN)]
+                ("package_end", HOOK_END_FN), ("package_filter", HOOK_FILTER_FN)]
 
 _lib = None
 

@@ -85,6 +85,8 @@ int dispatch_range(r433_batch *b, r433_r_device *const *devices, uint32_t n_devi
     for (uint32_t pkg = p0; pkg < p1 && rc == 0; ++pkg) {
         r433_pkg_rec ph;
         memcpy(&ph, pk + b->h_rec_off.p[pkg], sizeof(ph));
+        if (hooks && hooks->package_filter && !hooks->package_filter(hooks->user, &ph))
+            continue; // not this caller's business (e.g. a frame it has replayed before): no decoder sees it
         if (want_pd) {
             memset(pd, 0, sizeof(*pd));
             pd->offset = ph.offset;
@@ -396,12 +398,15 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
         at += eh.total_bytes;
     }
     std::vector<uint32_t> pkg_stream(np), pkg_type(np), pkg_start_ago(np);
+    std::vector<uint8_t> skipped(np, 0); // hooks->package_filter said no: no decoder sees the package, no hook is called for it
     for (uint32_t p = 0; p < np; ++p) {
         r433_pkg_rec ph;
         memcpy(&ph, pk + b->h_rec_off.p[p], sizeof(ph));
         pkg_stream[p] = ph.stream;
         pkg_type[p] = ph.type;
         pkg_start_ago[p] = ph.start_ago;
+        if (hooks && hooks->package_filter && !hooks->package_filter(hooks->user, &ph))
+            skipped[p] = 1;
     }
 
     // outputs go to the capture while the threads run
@@ -436,7 +441,7 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
         // a package whose lower levels produced an event is closed for this level (src/r_api.c:442)
         std::vector<uint8_t> open(np);
         for (uint32_t p = 0; p < np; ++p)
-            open[p] = p_events[p].load(std::memory_order_relaxed) == 0;
+            open[p] = !skipped[p] && p_events[p].load(std::memory_order_relaxed) == 0;
         std::atomic<uint32_t> cursor{0};
         uint32_t const nt = std::max<uint32_t>(1, std::min<uint32_t>(n_threads, (uint32_t)devs_of_level.size()));
         b->pool.run(nt, [&](unsigned w) {
@@ -531,7 +536,7 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
         b->pkg_decoded[p] = pe;
         decoded += pe;
         bool const has_out = ci < all.size() && all[ci].pkg == p;
-        if (!want_pkgs && !has_out)
+        if (skipped[p] || (!want_pkgs && !has_out))
             continue;
         r433_pkg_rec ph;
         memcpy(&ph, pk + b->h_rec_off.p[p], sizeof(ph));

@@ -337,3 +337,50 @@ def test_dispatch_ordered_equals_single_thread(threads, backend):
     assert a[5] and b[5]           # output_fn / log_fn restored
     assert any(t[0] == "out" for t in a[1]) and any(t[0] == "log" for t in a[1])
     eng.close()
+
+
+@pytest.mark.parametrize("ordered", [False, True])
+def test_package_filter_leaves_packages_out(ordered, backend):
+    """hooks.package_filter: a package it turns down reaches no decoder and no other hook, in the single-threaded and in the
+    ordered replay alike; the others are replayed as if it were not there."""
+    devs = _devices()
+    iqs = [synth.ook_stream(950 + k, 30000)[0] for k in range(5)]
+    eng, keep = _setup(devs, iqs, backend)
+    L = eng.L
+    n_pkgs = eng.packages()[1]
+    assert n_pkgs >= 4
+    calls, begun, ended, asked = [], [], [], []
+
+    @_lib.DECODE_FN
+    def decode(rdev, bits_p):
+        info = _lib.DispatchInfo()
+        L.r433_dispatch_current(C.byref(info))
+        calls.append(info.package)
+        return 1 if info.device == 2 else 0
+
+    @_lib.HOOK_BEGIN_FN
+    def begin(user, rec, pd):
+        begun.append(rec.contents.stream)
+
+    @_lib.HOOK_END_FN
+    def end(user, rec, p_events):
+        ended.append((rec.contents.stream, p_events))
+
+    @_lib.HOOK_FILTER_FN
+    def keep_even_captures(user, rec):
+        asked.append(rec.contents.stream)
+        return 1 if rec.contents.stream % 2 == 0 else 0
+
+    rdevs, objs = make_rdevices(devs, C.cast(decode, C.c_void_p).value, None)
+    hooks = _lib.DispatchHooks(None, begin, C.cast(None, _lib.HOOK_EVENT_FN), end, keep_even_captures)
+    n = eng.dispatch_ordered(rdevs, hooks, 3) if ordered else eng.dispatch_hooks(rdevs, hooks)
+    pkgs = po.parse_packages(eng.packages()[0])
+    kept = [k for k, p in enumerate(pkgs) if p["stream"] % 2 == 0]
+    assert sorted(set(asked)) == sorted(set(p["stream"] for p in pkgs))      # every package was offered once
+    assert len(asked) == len(pkgs)
+    assert sorted(set(calls)) == kept                                          # decoders saw the kept packages only
+    assert begun == [pkgs[k]["stream"] for k in kept]
+    assert [s for s, _ in ended] == begun and sum(e for _, e in ended) == n
+    dec = list(eng.decoded())
+    assert all(dec[k] == 0 for k in range(len(pkgs)) if k not in kept) and n == sum(dec) > 0
+    eng.close()

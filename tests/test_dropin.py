@@ -394,3 +394,35 @@ def test_sample_grabber(binary, tmp_path):
             assert sorted(got[2]) == sorted(ref[2]), (mode, env)
             for f in ref[2]:
                 assert got[2][f] == ref[2][f], (mode, env, f)
+
+
+@pytest.mark.parametrize("binary", [pytest.param(EMU, id="emu"), pytest.param(HIP, id="hip", marks=pytest.mark.gpu)])
+def test_stop_after_successful_events(binary, tmp_path):
+    """-E quit / -E hop: the file loop acts on the event count of every push (src/rtl_433.c:1136-1143), so the flow answers
+    every push at once (the capture so far is run again, its newest packages replayed): the process stops where the stock
+    binary stops -- after the first frame with an event, then one frame of every further file -- and sample dumps written
+    along the way are the same bytes."""
+    _ensure_built(binary)
+    a, b, c = synth.ook_stream(12, 131072)[0], synth.noise_cu8(5, 131072, 2.0), synth.ook_stream(21, 131072)[0]
+    np.concatenate([a, b, c, a]).tofile(tmp_path / "multi_433.92M_250k.cu8")  # events in frames 0, 2 and 3
+    synth.ook_stream(12, 40000)[0].tofile(tmp_path / "o_433.92M_250k.cu8")
+    shutil.copy(os.path.join(GOLD, "nice_250k.cu8"), tmp_path / "g001_433.92M_250k.cu8")
+    lists = [["multi_433.92M_250k.cu8", "o_433.92M_250k.cu8"], ["o_433.92M_250k.cu8", "multi_433.92M_250k.cu8", "g001_433.92M_250k.cu8"]]
+    all_events = run_cli(REF, file_args(lists[0]) + ["-R", "169"] + FLEX + ["-F", "json", "-M", "level"], tmp_path)
+    for files in lists:
+        for opts in (["-E", "quit"], ["-E", "hop"], ["-E", "quit", "-Y", "autolevel", "-M", "stats:2:3600"]):
+            args = file_args(files) + ["-R", "169"] + FLEX + ["-F", "json", "-M", "level"] + opts
+            ref = run_cli(REF, args, tmp_path)
+            assert run_cli(binary, args, tmp_path) == ref, (files, opts)
+            if files is lists[0] and opts == ["-E", "quit"]:
+                assert 0 < ref.count("\n") < all_events.count("\n")  # it did stop early
+    # dumpers fed frame by frame while frames are replayed again
+    got = {}
+    for who, bin_ in (("ref", REF), ("new", binary)):
+        d = tmp_path / who
+        d.mkdir()
+        dumps = ["x.logic.u8", "x.am.s16", "x.fm.f32", "x.cs16"]
+        out = run_cli(bin_, ["-r", "../multi_433.92M_250k.cu8", "-r", "../o_433.92M_250k.cu8", "-R", "169"] + FLEX + ["-F", "json", "-E", "hop"]
+                      + sum((["-W", x] for x in dumps), []), d)
+        got[who] = (out, {x: (d / x).read_bytes() for x in dumps})
+    assert got["ref"] == got["new"]
