@@ -33,9 +33,9 @@
     the capture as far as it has come and replays its newest packages (sync_step below), and the loop quits where the
     reference's does.
 
-    Not served by this flow (reported once, then ignored): S16_AM / S16_FM pseudo-IQ input files and the sample grabber's
-    "undecoded" mode (it needs the analyzer's frame quality); the raw rtl_tcp output's per-frame pacing is kept.  The sample
-    grabber (-S all | unknown | known, raw or SigMF) writes its files after the replay of a pass (write_grabs below).  Every -w / -W dumper is served: the input's own format is a
+    Not served by this flow (reported once, then ignored): S16_AM / S16_FM pseudo-IQ input files; the raw rtl_tcp output's
+    per-frame pacing is kept.  The sample grabber (-S all | unknown | known | undecoded, raw or SigMF) writes its files after
+    the replay of a pass (write_grabs below).  Every -w / -W dumper is served: the input's own format is a
     copy, the other IQ formats are the library's dump kernel on each frame, am / fm dumps come from the detection pass's
     taps, .u8 is painted by the detection kernel, .ook / .vcd are written during the replay.  (One quirk of the reference
     is NOT reproduced: its IQ conversions write into a buffer that is a union with buf.fm, so an IQ dumper listed before
@@ -115,6 +115,8 @@ static struct {
     size_t hist_len;
     uint64_t pushed_before_queue; /* bytes pushed, ever, before the first capture of the queue */
     int warned_grab_mode;
+    int32_t *quality;   /* -S undecoded: pulse_analyzer_check's verdict on every package of the pass nobody decoded */
+    size_t quality_cap, quality_n;
     /* answering every push at once (-E: the file loop acts on the event count of a push) */
     int sync_active, sync_flush, warned_sync_grab;
     uint32_t sync_frame;            /* the frame just pushed */
@@ -395,6 +397,14 @@ static void on_package_end(void *user, r433_pkg_rec const *rec, int p_events)
     }
     demod->total_frames_events += p_events > 0;
     demod->frames_events += p_events > 0;
+    if (demod->grab_mode == 4 && H.quality_n < H.quality_cap) { /* src/r_flow.c:290-294,308-312 */
+        int q = 0;
+        if (p_events == 0) {
+            r_device device = {.log_fn = log_device_handler, .output_ctx = cfg};
+            q               = pulse_analyzer_check(pd, is_ook ? PULSE_DATA_OOK : PULSE_DATA_FSK, &device);
+        }
+        H.quality[H.quality_n++] = q;
+    }
 
     for (void **iter = demod->dumper.elems; iter && *iter; ++iter) {
         file_info_t const *dumper = *iter;
@@ -577,13 +587,10 @@ static void write_grabs(r_cfg_t *cfg, hip_capture *group, size_t n)
         }
         return;
     }
-    if (demod->grab_mode < 1 || demod->grab_mode > 3) {
-        if (!H.warned_grab_mode) {
-            H.warned_grab_mode = 1;
-            print_log(LOG_WARNING, "HIP", "sample grabber mode \"undecoded\" (-S undecoded) is not served by the HIP flow");
-        }
+    if (demod->grab_mode < 1 || demod->grab_mode > 4)
         return;
-    }
+    if (demod->grab_mode == 4 && r433_batch_set_package_quality(H.eng, H.quality, (uint32_t)H.quality_n) < 0)
+        hip_fatal("r433_batch_set_package_quality");
     int count = r433_batch_grab_plan(H.eng, demod->grab_mode, NULL, 0);
     if (count < 0)
         hip_fatal("r433_batch_grab_plan");
@@ -754,6 +761,14 @@ static int run_group(r_cfg_t *cfg, hip_capture *group, size_t n)
     H.cfg        = cfg;
     H.group      = group;
     H.cur_stream = UINT32_MAX;
+    H.quality_n  = 0;
+    if (demod->grab_mode == 4 && (size_t)n_pkgs > H.quality_cap) {
+        free(H.quality);
+        H.quality = calloc((size_t)n_pkgs, sizeof(*H.quality));
+        if (!H.quality)
+            FATAL_CALLOC("hip package verdicts");
+        H.quality_cap = (size_t)n_pkgs;
+    }
     r433_batch_frame_sums(H.eng, &H.frame_sums, &H.sums_cap);
     /* The replay.  account_event's debug printout (a decoder without decode_fn, -vv) needs every bitbuffer after its
        decoder ran: then everything stays on this thread.  Otherwise the decoders are spread over host threads -- each

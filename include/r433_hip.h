@@ -307,7 +307,7 @@ int r433_pulse_text_load(char const *text, size_t len, uint32_t sample_rate, r43
  * plan: which byte range of which capture the reference would have saved to its g<counter>_<freq>M_<rate>k files, from
  * the package records of the last r433_batch_run (and, for modes 2 and 3, the decode results of the last dispatch).
  * The ranges point into the caller's own IQ buffers -- copying them out is a memcpy.  grab_mode: 1 all, 2 unknown
- * (no decoder reported an event during the frame), 3 known.  Returns the number of grabs (may exceed max_grabs). */
+ * (no decoder reported an event during the frame), 3 known, 4 undecoded (below).  Returns the number of grabs (may exceed max_grabs). */
 typedef struct r433_grab {
     uint32_t stream;      /* capture index */
     uint32_t counter;     /* the ### of the file name, counted through the batch */
@@ -319,6 +319,10 @@ typedef struct r433_grab {
                              plus what came before it: the file is as long as the ring's fill allows, src/samp_grab.c:110-113) */
 } r433_grab;
 int r433_batch_grab_plan(r433_batch *b, int grab_mode, r433_grab *out, uint32_t max_grabs);
+/* grab_mode 4 ("undecoded", src/r_flow.c:290-294,351): a frame nobody decoded is saved if the pulse analyzer thinks one of its
+ * packages looks like a transmission.  The analyzer's verdict (pulse_analyzer_check's return value, > 0 = plausible) is the
+ * caller's: one value per package of the last run, before r433_batch_grab_plan(b, 4, ...). */
+int r433_batch_set_package_quality(r433_batch *b, int32_t const *quality, uint32_t n_packages);
 /* The SigMF container the grabber writes with `-S sigmf:...` (src/samp_grab.c:166-232, src/sigmf.c, microtar): the
  * bytes before the data of a grab (meta member + header of the data member) and the bytes after it (record padding +
  * two null records).  Both return the number of bytes needed and write them if cap suffices. */

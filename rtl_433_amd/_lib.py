@@ -126,7 +126,7 @@ EXPORTS = [
     "r433_pulse_vcd_header", "r433_pulse_vcd", "r433_batch_grab_plan",
     "r433_sigmf_prefix", "r433_sigmf_trailer", "r433_sigmf_probe",
     "r433_filter_frame", "r433_envelope_host", "r433_host_alloc", "r433_host_free", "r433_batch_run_host", "r433_batch_dispatch_hooks", "r433_batch_dispatch_ordered", "r433_batch_decoded",
-    "r433_dump_convert_host",
+    "r433_dump_convert_host", "r433_batch_set_package_quality",
     "r433_detector_create", "r433_detector_destroy", "r433_detector_reset", "r433_detector_set_levels", "r433_detector_package",
 ]
 
@@ -230,6 +230,8 @@ def bind(L):
     L.r433_filter_frame.argtypes = [C.c_uint32, vp, C.c_uint32, vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int64]
     L.r433_envelope_host.restype = C.c_int
     L.r433_envelope_host.argtypes = [C.c_uint32, vp, vp, C.c_uint32, vp]
+    L.r433_batch_set_package_quality.restype = C.c_int
+    L.r433_batch_set_package_quality.argtypes = [vp, vp, C.c_uint32]
     L.r433_dump_convert_host.restype = C.c_int
     L.r433_dump_convert_host.argtypes = [C.c_int, C.c_uint32, vp, vp, C.c_uint64]
     L.r433_detector_create.restype = vp

@@ -648,6 +648,7 @@ int run_slice_and_mirror(RunCtx &r)
     b->evt_bytes = evt_bytes;
     b->events_counted = false;
     b->dispatched = false;
+    b->pkg_quality.clear();
     b->pkg_decoded.clear();
     b->h_rec_off.p[r.total_pkgs] = (uint32_t)pkg_bytes;
     b->h_pkg_off.p[r.total_pkgs] = (uint32_t)evt_bytes;

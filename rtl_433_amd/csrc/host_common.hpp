@@ -221,6 +221,7 @@ struct r433_batch {
     bool events_counted = false;
     std::vector<uint32_t> stream_samples; // per capture of the last run (as the detector saw them)
     std::vector<int> pkg_decoded; // per package: events its decoders reported in the last dispatch
+    std::vector<int32_t> pkg_quality; // per package: the caller's analyzer verdict (r433_batch_set_package_quality; grab mode 4)
     bool dispatched = false;
 
     void *tap_env = nullptr, *tap_am = nullptr, *tap_fm = nullptr;

@@ -227,8 +227,10 @@ int r433_batch_grab_plan(r433_batch *b, int grab_mode, r433_grab *out, uint32_t 
 {
     if (!b || (!out && max_grabs))
         return fail(R433_EINVAL, "null argument");
-    if (grab_mode < 1 || grab_mode > 3)
-        return fail(R433_EINVAL, "grab mode must be 1 (all), 2 (unknown) or 3 (known)");
+    if (grab_mode < 1 || grab_mode > 4)
+        return fail(R433_EINVAL, "grab mode must be 1 (all), 2 (unknown), 3 (known) or 4 (undecoded)");
+    if (grab_mode == 4 && b->pkg_quality.size() != b->n_pkgs)
+        return fail(R433_EINVAL, "grab mode 4 needs the analyzer's verdict on every package: r433_batch_set_package_quality first");
     if (grab_mode != 1 && !b->dispatched)
         return fail(R433_EINVAL, "grab modes 2 and 3 need the decode results: dispatch first");
     if (b->stream_samples.size() != b->n_streams)
@@ -242,6 +244,7 @@ int r433_batch_grab_plan(r433_batch *b, int grab_mode, r433_grab *out, uint32_t 
         uint64_t const n_total = b->stream_samples.size() > c ? b->stream_samples[c] : 0;
         uint32_t const data_calls = (uint32_t)((n_total + F - 1) / F);
         unsigned start_ago = 0, end_ago = 0, event_count = 0;
+        int quality = 0; // demod->frame_quality: the best analyzer verdict among the frame's packages nobody decoded
         uint64_t pushed = 0; // bytes
         for (uint32_t call = 0; call <= data_calls; ++call) { // the last one is the flush (len 0)
             uint32_t const n = call < data_calls ? (uint32_t)std::min<uint64_t>(F, n_total - (uint64_t)call * F) : 0u;
@@ -261,9 +264,12 @@ int r433_batch_grab_plan(r433_batch *b, int grab_mode, r433_grab *out, uint32_t 
                 end_ago = ph.end_ago;
                 if (pkg < b->pkg_decoded.size())
                     event_count += (unsigned)b->pkg_decoded[pkg];
+                if (grab_mode == 4 && b->pkg_decoded[pkg] == 0) // src/r_flow.c:290-294,308-312
+                    quality = std::max(quality, (int)b->pkg_quality[pkg]);
             }
             if (start_ago && end_ago > n) { // the frame is older than a whole buffer: it is over
-                if (grab_mode == 1 || (grab_mode == 2 && event_count == 0) || (grab_mode == 3 && event_count > 0)) {
+                if (grab_mode == 1 || (grab_mode == 2 && event_count == 0) || (grab_mode == 3 && event_count > 0)
+                        || (grab_mode == 4 && event_count == 0 && quality > 0)) {
                     unsigned const pad = n / 8;
                     unsigned const start_padded = start_ago + pad, end_padded = end_ago - pad;
                     unsigned const len_padded = start_padded - end_padded;
@@ -287,10 +293,21 @@ int r433_batch_grab_plan(r433_batch *b, int grab_mode, r433_grab *out, uint32_t 
                 }
                 start_ago = 0;
                 event_count = 0;
+                quality = 0;
             }
         }
     }
     return (int)n_out;
+}
+
+int r433_batch_set_package_quality(r433_batch *b, int32_t const *quality, uint32_t n_packages)
+{
+    if (!b || (!quality && n_packages))
+        return fail(R433_EINVAL, "null argument");
+    if (n_packages != b->n_pkgs)
+        return fail(R433_EINVAL, "one verdict per package of the last run (%u given, %u packages)", n_packages, b->n_pkgs);
+    b->pkg_quality.assign(quality, quality + n_packages);
+    return 0;
 }
 
 namespace {

@@ -362,7 +362,7 @@ def test_every_sample_dumper(binary, tmp_path):
 
 @pytest.mark.parametrize("binary", [pytest.param(EMU, id="emu"), pytest.param(HIP, id="hip", marks=pytest.mark.gpu)])
 def test_sample_grabber(binary, tmp_path):
-    """-S all | unknown | known and the SigMF variant over a list of files: the same g###_<freq>M_<rate>k files with the same
+    """-S all | unknown | known | undecoded and the SigMF variant over a list of files: the same g###_<freq>M_<rate>k files with the same
     bytes (the first grab reaches back across a file boundary: the ring's history), the same messages; also with one GPU pass
     per file, where the history comes from the pass before."""
     _ensure_built(binary)
@@ -383,9 +383,9 @@ def test_sample_grabber(binary, tmp_path):
         notes = [l for l in p.stderr.decode(errors="replace").splitlines() if l.startswith("***") or l.startswith("Signal bigger")]
         return p.stdout.decode(), notes, {f: (d / f).read_bytes() for f in sorted(os.listdir(d))}
 
-    for mode in ("all", "unknown", "known", "sigmf:all"):
+    for mode in ("all", "unknown", "known", "undecoded", "sigmf:all"):
         ref = run(REF, mode)
-        if mode in ("all", "sigmf:all"):
+        if mode in ("all", "undecoded", "sigmf:all"):
             assert len(ref[2]) >= 2 and len(ref[1]) >= 2
         for env in (None, {"RTL433_HIP_BATCH": "1"}):
             got = run(binary, mode, env)
