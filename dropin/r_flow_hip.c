@@ -106,7 +106,7 @@ static struct {
     hip_capture *caps;
     size_t n_caps, caps_cap;
     int open; /* the last capture is still being pushed to */
-    int warned_grab, warned_dump;
+    int warned_dump;
     uint8_t *conv;      /* a converted frame / capture for the sample dumpers */
     size_t conv_cap;
     int16_t *taps[3];   /* pinned: raw envelope, filtered envelope, filtered discriminator of the captures of a pass (am / fm dumpers) */
@@ -274,7 +274,7 @@ static void switch_to(uint32_t stream)
     /* what reset_sdr_flow leaves behind (src/r_flow.c:79-97) and the file loop sets (src/rtl_433.c:1706-1711) */
     demod->min_level_auto        = 0.0f;
     demod->noise_level           = 0.0f;
-    cfg->in_filename             = (char *)c->in_filename;
+    cfg->in_filename             = c->in_filename;
     demod->load_info             = c->load_info;
     cfg->samp_rate               = c->samp_rate;
     cfg->center_frequency        = c->center_frequency;
@@ -632,7 +632,7 @@ static void write_grabs(r_cfg_t *cfg, hip_capture *group, size_t n)
             fprintf(stderr, "Failed to open %s\n", f_name);
             continue;
         }
-        char wrap[4096];
+        uint8_t wrap[4096];
         if (g->sg_fileformat) { /* the reference's SigMF container around the same bytes (src/sigmf.c, microtar) */
             int w = r433_sigmf_prefix(ss, c->samp_rate, c->center_frequency, signal_bsize, wrap, sizeof(wrap));
             if (w < 0)
@@ -818,7 +818,7 @@ int hip_sdr_flow_drain(struct r_cfg *cfg)
     if (!demod || H.n_caps == 0)
         return 0;
     /* what the host set for the file it is working on right now: restored after the replay */
-    char *keep_filename        = cfg->in_filename;
+    char const *keep_filename  = cfg->in_filename;
     file_info_t keep_load_info = demod->load_info;
     uint32_t keep_rate = cfg->samp_rate, keep_freq = cfg->center_frequency;
     uint32_t keep_drate = demod->samp_rate, keep_dfreq = demod->center_frequency;
