@@ -575,12 +575,20 @@ int run_slice_and_mirror(RunCtx &r)
         if (!(b->debug_flags & R433_DEBUG_TWO_PASS_SLICER)) {
             // (a device with less free memory than that: smaller slots -- a record that outgrows its slot is sliced a second
             // time -- and in the end the count + write pair, never a failed run)
-            for (; stage_cap >= 512; stage_cap >>= 1)
+            // do not even ask for more than the device has free: ensure() rounds up by a quarter
+            size_t mem_free = 0, mem_total = 0;
+            if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess)
+                while (stage_cap >= 512 && b->d_stage.cap < (size_t)r.total_pkgs * b->rows.size() * stage_cap
+                        && (size_t)r.total_pkgs * b->rows.size() * stage_cap / 4 * 5 > mem_free + b->d_stage.cap)
+                    stage_cap >>= 1;
+            for (; stage_cap >= 512; stage_cap >>= 1) {
                 if (b->d_stage.ensure((size_t)r.total_pkgs * b->rows.size() * stage_cap) == 0) {
                     lp.stage = b->d_stage.p;
                     lp.stage_cap = stage_cap;
                     break;
                 }
+                (void)hipGetLastError(); // a refused allocation must not fail the launch checks below (sticky on some ROCm releases)
+            }
         }
         HIP_TRY(hipMemsetAsync(b->d_pkg_bytes.p, 0, (size_t)max_pkgs * sizeof(uint32_t), r.st));
         launch_slice_count(lp, r.total_pkgs, r.st);
@@ -738,6 +746,8 @@ int r433_batch_run_host(r433_batch *b, void const *const *h_captures, uint32_t c
                 || (uint8_t const *)h_captures[i] != (uint8_t const *)h_captures[0] + (size_t)i * capture_bytes[0])
             packed = false;
     }
+    if (max_bytes == 0)
+        packed = false; // nothing to copy: the pointers may all be null (an empty file is a valid capture)
     uint64_t const stride = std::max<uint64_t>(16, (max_bytes + 15) & ~15ull);
     if (stride > 0xfffffff0ull)
         return fail(R433_EINVAL, "captures are limited to 4 GiB each");

@@ -417,8 +417,12 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
             continue;
         keep_out[d] = devices[d]->output_fn;
         keep_log[d] = devices[d]->log_fn;
-        devices[d]->output_fn = capture_output;
-        devices[d]->log_fn = capture_log;
+        // only where the caller listens: a decoder checks these pointers before it builds a payload, and a payload
+        // nobody takes at commit time would have no owner (data_t belongs to whoever output_fn hands it to)
+        if (keep_out[d])
+            devices[d]->output_fn = capture_output;
+        if (keep_log[d])
+            devices[d]->log_fn = capture_log;
     }
     std::vector<std::vector<Captured>> captured(n_threads);
     std::vector<std::atomic<int>> p_events(np);

@@ -55,6 +55,8 @@ template <typename T> struct DevBuf {
         size_t want = n + n / 4 + 16;
         hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
         if (e != hipSuccess)
+            (void)hipGetLastError(); // reported here; must not turn up again in a later launch check
+        if (e != hipSuccess)
             return fail(R433_ENOMEM, "hipMalloc(%zu bytes): %s", want * sizeof(T), hipGetErrorString(e));
         cap = want;
         return 0;

@@ -1,5 +1,5 @@
 // reports.cpp -- host-side text and report formats around the path: the pulse analyzer's report (`-A`) over the
-// device-computed analysis, and the `.ook` pulse-data reader / writer.
+// device-computed analysis, and the `.ook` pulse-data writer (the reader is pulse_text.cpp).
 #include "host_common.hpp"
 
 using namespace r433;
@@ -448,208 +448,6 @@ int r433_sigmf_probe(uint8_t const *buf, size_t len, r433_sigmf_info *info)
     if (!found_data)
         return fail(R433_EINVAL, "SigMF input with no stream data");
     return 0;
-}
-
-namespace {
-
-// ---- RfRaw lines inside pulse files, reference src/rfraw.c ----
-int hex_nibble(char const **p) // :16-36
-{
-    if (!p || !*p || !**p)
-        return -1;
-    while (**p == ' ' || **p == '\t' || **p == '-' || **p == ':')
-        ++*p;
-    int const c = **p;
-    if (c >= '0' && c <= '9') {
-        ++*p;
-        return c - '0';
-    }
-    if (c >= 'A' && c <= 'F') {
-        ++*p;
-        return c - 'A' + 10;
-    }
-    if (c >= 'a' && c <= 'f') {
-        ++*p;
-        return c - 'a' + 10;
-    }
-    return -1;
-}
-
-int hex_byte(char const **p) // :38-45
-{
-    int const h = hex_nibble(p);
-    int const l = hex_nibble(p);
-    return h >= 0 && l >= 0 ? (h << 4) | l : -1;
-}
-
-int hex_word(char const **p) // :47-54
-{
-    int const h = hex_byte(p);
-    int const l = hex_byte(p);
-    return h >= 0 && l >= 0 ? (h << 8) | l : -1;
-}
-
-int hex_peek_byte(char const *p) // :56-63
-{
-    return hex_byte(&p);
-}
-
-bool rfraw_check(char const *p) // :65-72: 0xaa 0xb0 or 0xaa 0xb1
-{
-    return hex_nibble(&p) == 0xa && hex_nibble(&p) == 0xa && hex_nibble(&p) == 0xb && (hex_nibble(&p) | 1) == 0x1;
-}
-
-bool parse_rfraw(r433_pulse_data *data, char const **p) // :94-178
-{
-    if (!p || !*p || !**p)
-        return false;
-    if (hex_byte(p) != 0xaa)
-        return false;
-    int const fmt = hex_byte(p);
-    if (fmt != 0xb0 && fmt != 0xb1)
-        return false;
-    if (fmt == 0xb0)
-        hex_byte(p); // len, ignored
-    int const bins_len = hex_byte(p);
-    if (bins_len > 8)
-        return false;
-    int repeats = 1;
-    if (fmt == 0xb0)
-        repeats = hex_byte(p);
-    int bins[8] = {0};
-    for (int i = 0; i < bins_len; ++i)
-        bins[i] = hex_word(p);
-    bool oldfmt = true; // old or new format?
-    for (char const *t = *p; *t;) {
-        int const b = hex_byte(&t);
-        if (b < 0 || b == 0x55)
-            break;
-        if (b & 0x88) {
-            oldfmt = false;
-            break;
-        }
-    }
-    unsigned const prev_pulses = data->num_pulses;
-    // The reference stores first and checks after (src/rfraw.c:141-163): a further segment on a line whose package is
-    // already full writes past pulse[] / gap[].  This reader takes untrusted text, so a full package takes nothing more.
-    if (prev_pulses >= R433_MAX_PULSES)
-        return false;
-    bool pulse_needed = true, aligned = true;
-    while (**p) {
-        if (aligned && hex_peek_byte(*p) == 0x55) {
-            hex_byte(p);
-            break;
-        }
-        int const w = hex_nibble(p);
-        aligned = !aligned;
-        if (w < 0)
-            return false;
-        if (w >= 8 || (oldfmt && !aligned)) { // pulse
-            if (!pulse_needed) {
-                data->gap[data->num_pulses] = 0;
-                data->num_pulses++;
-                if (data->num_pulses >= R433_MAX_PULSES)
-                    break;
-            }
-            data->pulse[data->num_pulses] = bins[w & 7];
-            pulse_needed = false;
-        }
-        else { // gap
-            if (pulse_needed)
-                data->pulse[data->num_pulses] = 0;
-            data->gap[data->num_pulses] = bins[w];
-            data->num_pulses++;
-            pulse_needed = true;
-        }
-        if (data->num_pulses >= R433_MAX_PULSES)
-            break;
-    }
-    unsigned const pkt_pulses = data->num_pulses - prev_pulses; // expand the repeats while there is room
-    for (int i = 1; i < repeats && data->num_pulses + pkt_pulses <= R433_MAX_PULSES; ++i) {
-        memcpy(&data->pulse[data->num_pulses], &data->pulse[prev_pulses], pkt_pulses * sizeof(*data->pulse));
-        memcpy(&data->gap[data->num_pulses], &data->gap[prev_pulses], pkt_pulses * sizeof(*data->pulse));
-        data->num_pulses += pkt_pulses;
-    }
-    data->sample_rate = 1000000; // the widths are microseconds
-    return true;
-}
-
-void rfraw_parse(r433_pulse_data *data, char const *p) // :180-200, appends to the package
-{
-    if (!p || !*p)
-        return;
-    while (*p) {
-        while (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n' || *p == '+' || *p == '-')
-            ++p;
-        if (data->num_pulses >= R433_MAX_PULSES || !parse_rfraw(data, &p))
-            break;
-    }
-}
-
-} // namespace
-
-// pulse_data_load, reference src/pulse_data.c:122-176, over a text in memory: one call of the reference reads one
-// package; the file loop calls it until a package comes back empty (src/rtl_433.c:1757-1761).
-int r433_pulse_text_load(char const *text, size_t len, uint32_t sample_rate, r433_pulse_data *out, uint32_t max_packages)
-{
-    if ((!text && len) || (!out && max_packages))
-        return fail(R433_EINVAL, "null argument");
-    size_t at = 0;
-    uint32_t n_out = 0;
-    double const to_sample = sample_rate / 1e6;
-    // fgets(s, 1024, file): at most 1023 characters, up to and including the newline
-    auto next_line = [&](char *s) -> bool {
-        if (at >= len)
-            return false;
-        size_t k = 0;
-        while (k < 1023 && at < len) {
-            char const c = text[at++];
-            s[k++] = c;
-            if (c == '\n')
-                break;
-        }
-        s[k] = '\0';
-        return true;
-    };
-    for (;;) {
-        r433_pulse_data *data = n_out < max_packages ? &out[n_out] : nullptr;
-        if (!data)
-            break;
-        memset(data, 0, sizeof(*data)); // pulse_data_clear
-        data->sample_rate = sample_rate;
-        char s[1024];
-        int i = 0;
-        while (i < R433_MAX_PULSES && next_line(s)) {
-            if (!strncmp(s, ";freq1", 6))
-                data->freq1_hz = (float)strtol(s + 6, nullptr, 10);
-            if (!strncmp(s, ";freq2", 6))
-                data->freq2_hz = (float)strtol(s + 6, nullptr, 10);
-            if (*s == ';') {
-                if (i)
-                    break; // end or next header found
-                continue;  // still reading a header
-            }
-            if (rfraw_check(s)) { // src/pulse_data.c:155-159
-                rfraw_parse(data, s);
-                i = (int)data->num_pulses;
-                continue;
-            }
-            char const *p = s;
-            char *endptr;
-            long const mark = strtol(p, &endptr, 10);
-            p = endptr + 1;
-            long const space = strtol(p, &endptr, 10);
-            if (mark < 0 || space < 0)
-                continue; // the reference warns and skips the line
-            data->pulse[i] = (int)(to_sample * mark);
-            data->gap[i++] = (int)(to_sample * space);
-        }
-        data->num_pulses = (unsigned)i;
-        if (i == 0)
-            break; // the file loop stops at the first empty package
-        n_out += 1;
-    }
-    return (int)n_out;
 }
 
 // pulse_data_print_vcd_header, reference src/pulse_data.c:77-100 (nice_freq: src/r_util.c:290-307)

@@ -202,6 +202,7 @@ hipError_t hipMemcpy(void *d, void const *s, size_t n, hipMemcpyKind) { memcpy(d
 hipError_t hipMemcpyAsync(void *d, void const *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = (size_t)64 << 30; *t = (size_t)64 << 30; return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t *st, unsigned) { *st = (hipStream_t)(uintptr_t)1; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }

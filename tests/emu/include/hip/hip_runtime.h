@@ -238,6 +238,7 @@ hipError_t hipMemcpy(void *d, void const *s, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void *d, void const *s, size_t n, hipMemcpyKind k, hipStream_t st);
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t st);
 hipError_t hipMemset(void *d, int v, size_t n);
+hipError_t hipMemGetInfo(size_t *free_bytes, size_t *total_bytes);
 enum { hipStreamNonBlocking = 1 };
 hipError_t hipStreamCreateWithFlags(hipStream_t *st, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t st);

@@ -270,6 +270,23 @@ def test_run_host_equals_run(backend):
     eng.close()
 
 
+def test_run_host_all_empty(backend):
+    """Every capture empty (pointers may be null): no copy, no package, no crash (the packed path read
+    n * 16 bytes from a null pointer)."""
+    devs = _devices()
+    if backend == "gpu":
+        eng = BatchEngine(flow_cfg(2, 250000), devs)
+    else:
+        from tests.emu import host as emu_host
+        eng = BatchEngine(flow_cfg(2, 250000), devs, library=emu_host.emu_lib())
+    ptrs = (C.c_void_p * 2)(None, None)
+    lens = (C.c_uint32 * 2)(0, 0)
+    rc = eng.L.r433_batch_run_host(eng.h, C.cast(ptrs, C.c_void_p), C.cast(lens, C.c_void_p), 2)
+    assert rc == 0
+    assert eng.packages()[1] == 0 and eng.events()[1] == 0
+    eng.close()
+
+
 @pytest.mark.parametrize("threads", [1, 4])
 def test_dispatch_ordered_equals_single_thread(threads, backend):
     """r433_batch_dispatch_ordered: decoders spread over threads, each decoder's calls in reference order, the priority
