@@ -119,6 +119,7 @@ static struct {
     size_t quality_cap, quality_n;
     /* answering every push at once (-E: the file loop acts on the event count of a push) */
     int sync_active, sync_flush, warned_sync_grab;
+    int eng_probed, eng_tables; /* the decoder pre-filter of H.eng: asked for, decoders with a table */
     uint32_t sync_frame;            /* the frame just pushed */
     unsigned sync_count, sync_squelch; /* frames / noise-only frames the run before this one counted for the same capture */
     uint32_t fm_note_rate; /* the rate the "FM low pass filter" notice was last printed for (src/baseband.c:217,310) */
@@ -484,6 +485,37 @@ static void engine_ensure(r_cfg_t *cfg, r433_flow_cfg const *fc)
     H.eng_cfg       = *fc;
     H.eng_devs      = n;
     H.eng_first_dev = first;
+    H.eng_probed    = 0;
+    H.eng_tables    = 0;
+}
+
+/* The replay is quiet and spread over threads (see the dispatch below): then no hook looks at single decoder calls, and the
+   bitbuffers a decoder refuses on their head alone can stay on the device (r433_batch_probe_prefilter; the statistics of
+   -M stats come out the same).  RTL433_HIP_PREFILTER=0 in the environment keeps every record coming. */
+static int replay_is_chatty(struct dm_state *demod)
+{
+    for (void **iter = demod->r_devs.elems; iter && *iter; ++iter) {
+        r_device const *d = *iter;
+        if (!d->decode_fn || d->verbose)
+            return 1;
+    }
+    return 0;
+}
+
+static void engine_prefilter(r_cfg_t *cfg)
+{
+    struct dm_state *demod = cfg->demod;
+    char const *env        = getenv("RTL433_HIP_PREFILTER");
+    int const want         = !(env && env[0] == '0') && !H.sync_active && replay_threads() > 1 && !replay_is_chatty(demod) && demod->r_devs.len;
+    if (want && !H.eng_probed) {
+        H.eng_probed = 1;
+        int const t  = r433_batch_probe_prefilter(H.eng, (r433_r_device *const *)demod->r_devs.elems, (uint32_t)demod->r_devs.len);
+        if (t < 0)
+            hip_fatal("r433_batch_probe_prefilter");
+        H.eng_tables = t;
+    }
+    if (H.eng_tables > 0 && r433_batch_set_prefilter(H.eng, want) < 0)
+        hip_fatal("r433_batch_set_prefilter");
 }
 
 /* -E quit / -E hop: src/rtl_433.c:1136-1143 acts on the events of each push, so a push cannot be left for later.  The capture as
@@ -708,6 +740,7 @@ static int run_group(r_cfg_t *cfg, hip_capture *group, size_t n)
     else {
         r433_batch_set_taps(H.eng, NULL, NULL, NULL, 0);
     }
+    engine_prefilter(cfg);
     int n_pkgs = r433_batch_run_host(H.eng, ptrs, bytes, (uint32_t)n);
     if (n_pkgs >= 0 && want_taps) {
         for (void **iter = demod->dumper.elems; iter && *iter; ++iter) {
@@ -774,12 +807,7 @@ static int run_group(r_cfg_t *cfg, hip_capture *group, size_t n)
        decoder ran: then everything stays on this thread.  Otherwise the decoders are spread over host threads -- each
        decoder on one thread, its calls in reference order -- and what they hand to output_fn is committed here in
        reference order (r433_batch_dispatch_ordered). */
-    int chatty = 0;
-    for (void **iter = demod->r_devs.elems; iter && *iter; ++iter) {
-        r_device const *d = *iter;
-        if (!d->decode_fn || d->verbose)
-            chatty = 1;
-    }
+    int chatty    = replay_is_chatty(demod);
     int n_threads = replay_threads();
     int events;
     if (chatty || n_threads <= 1) {

@@ -215,6 +215,26 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
 /* per package of the last dispatch: the events its decoders reported (p_events) */
 int r433_batch_decoded(r433_batch *b, int const **per_package, uint32_t *count);
 
+/* Device-side decoder pre-filter (reference src/pulse_slicer.c:26-66, the first-line length tests of
+ * the decoders under src/devices such as nice_flor_s.c:84).  Most bitbuffers a slicer builds are refused by their decoder on a look at
+ * num_rows / bits_per_row[0] alone.  r433_batch_probe_prefilter learns, per registered decoder, for which
+ * (num_rows, bits_per_row[0]) that is PROVABLY so: it calls decode_fn on a bitbuffer_t of which only num_rows, free_row and
+ * bits_per_row[0] are readable -- everything behind them lies on an inaccessible page -- and keeps a verdict only where the
+ * call came back with a failure code (0, DECODE_ABORT_LENGTH .. DECODE_FAIL_SANITY) WITHOUT touching anything else: a
+ * decoder that is a function of its arguments then returns that code for every bitbuffer with that head.  From the next run
+ * on the slicer kernel drops such records where it builds them (they are neither staged, copied to the host nor replayed)
+ * and counts them per decoder and code; the dispatch functions add the counts to decode_events / decode_fails exactly as
+ * account_event would have, so `-M stats` is unchanged.  Only decoders of the lowest priority level are filtered (the others
+ * are not called for every package, src/r_api.c:442-451), only with verbose == 0 (account_event prints refused bitbuffers at
+ * -vv), and never together with an event_done hook or a package_filter.  decode_fn is called n times per decoder here
+ * (~50 000, outside account_event: no statistics move); a decoder that keeps state between calls must not let that state
+ * decide its length test.  Returns the number of decoders with at least one provable refusal. */
+int r433_batch_probe_prefilter(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices);
+/* on = 0 turns the learned tables off again (records flow as without a probe), 1 back on */
+int r433_batch_set_prefilter(r433_batch *b, int on);
+/* of the last run: records dropped on the device, counts[device * 5 + code] with code = -(decode_fn return) in 0..4 */
+int r433_batch_prefilter_counts(r433_batch *b, uint32_t const **counts, uint32_t *n_devices);
+
 /* What the dispatcher is handing to decode_fn right now, for plugins that want to tag their output
  * (the reference's `output_tag FILE` needs the capture; time stamps need start_ago).  Thread-local. */
 typedef struct r433_dispatch_info {

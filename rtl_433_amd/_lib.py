@@ -127,6 +127,7 @@ EXPORTS = [
     "r433_sigmf_prefix", "r433_sigmf_trailer", "r433_sigmf_probe",
     "r433_filter_frame", "r433_envelope_host", "r433_host_alloc", "r433_host_free", "r433_batch_run_host", "r433_batch_dispatch_hooks", "r433_batch_dispatch_ordered", "r433_batch_decoded",
     "r433_dump_convert_host", "r433_batch_set_package_quality",
+    "r433_batch_probe_prefilter", "r433_batch_set_prefilter", "r433_batch_prefilter_counts",
     "r433_detector_create", "r433_detector_destroy", "r433_detector_reset", "r433_detector_set_levels", "r433_detector_package",
 ]
 
@@ -256,6 +257,12 @@ def bind(L):
     L.r433_batch_dispatch_ordered.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
     L.r433_batch_decoded.restype = C.c_int
     L.r433_batch_decoded.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint32)]
+    L.r433_batch_probe_prefilter.restype = C.c_int
+    L.r433_batch_probe_prefilter.argtypes = [vp, vp, C.c_uint32]
+    L.r433_batch_set_prefilter.restype = C.c_int
+    L.r433_batch_set_prefilter.argtypes = [vp, C.c_int]
+    L.r433_batch_prefilter_counts.restype = C.c_int
+    L.r433_batch_prefilter_counts.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint32)]
     for f in (L.r433_envelope_detect, L.r433_magnitude_est_cu8, L.r433_magnitude_est_cs16):
         f.restype = C.c_int
         f.argtypes = [vp, vp, C.c_uint32, vp, vp]

@@ -19,7 +19,7 @@ OUT = os.path.join(OUT_DIR, "librtl433hip.so")
 SEAM_OUT = os.path.join(OUT_DIR, "librtl433seam.so")  # the reference's own function names over the C ABI (csrc/ref_seam.cpp)
 
 SOURCES = ["stream_kernels.hip", "slicer_kernels.hip", "baseband_kernels.hip", "analyzer_kernels.hip", "host_api.cpp", "batch_run.cpp",
-           "dispatch.cpp", "reports.cpp", "pulse_text.cpp", "filter_frame.cpp", "detect_seam.hip"]
+           "dispatch.cpp", "reports.cpp", "pulse_text.cpp", "prefilter.cpp", "filter_frame.cpp", "detect_seam.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function", "-x", "hip"]
 

@@ -560,6 +560,12 @@ int run_slice_and_mirror(RunCtx &r)
     lp.pkg_bytes = b->d_pkg_bytes.p;
     lp.pkg_off = b->d_pkg_off.p;
     lp.max_pkgs = max_pkgs;
+    b->pf_ran = b->pf_accounted = false;
+    if (b->pf_on && n_devs && r.total_pkgs) { // decoder pre-filter (prefilter.cpp): records their decoder provably refuses stay here
+        lp.pf_tables = b->d_pf_tables.p;
+        lp.pf_counts = b->d_pf_counts.p;
+        HIP_TRY(hipMemsetAsync(b->d_pf_counts.p, 0, (size_t)n_devs * 5 * sizeof(uint32_t), r.st));
+    }
     if (n_devs && r.total_pkgs) {
         // One slicing pass into staging slots when they fit.  A default device set yields ~135 B per
         // (package, device) on average, but the heavy PCM rows fill whole bitbuffers -- 50 rows x (4 + 128) B -- and
@@ -647,6 +653,10 @@ int run_slice_and_mirror(RunCtx &r)
     }
     HIP_TRY(hipMemcpyAsync(b->h_frame_sums.p, b->d_frame_sums.p, (size_t)r.n_streams * r.frames_cap * sizeof(uint32_t),
             hipMemcpyDeviceToHost, r.st));
+    if (lp.pf_counts)
+        HIP_TRY(hipMemcpyAsync(b->h_pf_counts.p, b->d_pf_counts.p, (size_t)n_devs * 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, r.st));
+    if (lp.pf_counts)
+        HIP_TRY(hipMemcpyAsync(b->h_pf_counts.p, b->d_pf_counts.p, (size_t)n_devs * 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, r.st));
     if (b->logic_on && r.d_iq)
         HIP_TRY(hipMemcpyAsync(b->h_logic.p, b->d_logic.p, (size_t)r.n_streams * b->logic_stride, hipMemcpyDeviceToHost, r.st));
     if (b->profiling)
@@ -654,6 +664,7 @@ int run_slice_and_mirror(RunCtx &r)
     HIP_TRY(stream_wait(b, r.st));
     b->pkg_bytes = pkg_bytes;
     b->evt_bytes = evt_bytes;
+    b->pf_ran = lp.pf_counts != nullptr;
     b->events_counted = false;
     b->dispatched = false;
     b->pkg_quality.clear();

@@ -288,6 +288,7 @@ int r433_batch_dispatch_mt(r433_batch *b, r433_r_device *const *devices, uint32_
                 rd->decode_fails[k] += ds.fails[k];
         }
     }
+    apply_prefilter_counts(b, devices, n_devices);
     return decoded;
 }
 
@@ -300,6 +301,8 @@ int r433_batch_dispatch_hooks(r433_batch *b, r433_r_device *const *devices, uint
     b->dispatched = true;
     if (n_devices != b->timing.size())
         return fail(R433_EINVAL, "dispatch needs the %zu devices the engine was created with", b->timing.size());
+    if (b->pf_ran && hooks && (hooks->event_done || hooks->package_filter))
+        return fail(R433_EINVAL, "the last run dropped records on the device (r433_batch_probe_prefilter): no event_done hook or package_filter can see them");
     std::vector<DevStats> stats(n_devices);
     std::string err;
     static r433_dispatch_hooks const none = {nullptr, nullptr, nullptr, nullptr};
@@ -307,6 +310,7 @@ int r433_batch_dispatch_hooks(r433_batch *b, r433_r_device *const *devices, uint
     digest_publish();
     if (decoded < 0)
         return fail(decoded, "%s", err.c_str());
+    apply_prefilter_counts(b, devices, n_devices);
     return decoded;
 }
 
@@ -367,6 +371,8 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
         return fail(R433_EINVAL, "the ordered replay has no event_done hook: use r433_batch_dispatch_hooks");
     if (n_devices != b->timing.size())
         return fail(R433_EINVAL, "dispatch needs the %zu devices the engine was created with", b->timing.size());
+    if (b->pf_ran && hooks && hooks->package_filter)
+        return fail(R433_EINVAL, "the last run dropped records on the device (r433_batch_probe_prefilter): a package_filter cannot take their counts back");
     uint32_t const np = b->n_pkgs;
     b->pkg_decoded.assign(np, 0);
     b->dispatched = true;
@@ -586,6 +592,7 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
     free(pd);
     if (failed.load())
         return fail(R433_EDECODER, "%s", err.c_str());
+    apply_prefilter_counts(b, devices, n_devices);
     return decoded;
 }
 

@@ -66,6 +66,7 @@ DevRow resolve_timing(r433_dev_timing const &d, uint32_t rate, int orig)
     volatile float us = rate / 1.0e6f;
     r.modulation = (int)d.modulation;
     r.orig = orig;
+    r.pf = -1;
     r.is_fsk = d.modulation >= 16;
     volatile float v;
     v = d.short_width * us;
@@ -195,6 +196,7 @@ r433_batch *r433_batch_create(r433_flow_cfg const *cfg, r433_dev_timing const *d
         DevRow pad;
         memset(&pad, 0, sizeof(pad));
         pad.orig = -1;
+        pad.pf = -1;
         for (size_t i = 0; i < b->rows.size(); ++i) {
             if (i > 0 && (b->rows[i].is_fsk != b->rows[i - 1].is_fsk || b->rows[i].modulation != b->rows[i - 1].modulation))
                 while (padded.size() % 64)

@@ -40,6 +40,11 @@ namespace r433 {
 void levels_from_db(DetCfg &c, int use_mag, float fixed_db, float min_db, float ratio_db);
 // calc_rssi_snr, reference src/r_flow.c:35-64 (dispatch.cpp)
 void fill_levels(r433_flow_cfg const &cfg, r433_pulse_data &p);
+} // namespace r433
+struct r433_batch;
+namespace r433 {
+// records the device-side pre-filter dropped in the last run -> decode_events / decode_fails, once per run (prefilter.cpp)
+void apply_prefilter_counts(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices);
 
 template <typename T> struct DevBuf {
     T *p = nullptr;
@@ -239,6 +244,16 @@ struct r433_batch {
     hipEvent_t ev[8] = {};
     bool ev_made = false;
     r433_batch_timing last_timing = {};
+
+    // decoder pre-filter (prefilter.cpp)
+    std::vector<uint8_t> pf_tables;   // kPfTable bytes per filtered decoder
+    std::vector<int> pf_index;        // per registered device: its table, or -1
+    DevBuf<uint8_t> d_pf_tables;
+    DevBuf<uint32_t> d_pf_counts;
+    PinBuf<uint32_t> h_pf_counts;     // [device][5] of the last run
+    bool pf_on = false;               // tables are in use
+    bool pf_ran = false;              // the last run filtered (h_pf_counts is valid)
+    bool pf_accounted = false;        // its counts have been added to the decoders' statistics
 
     // dispatch scratch
     r433_bitbuffer *bits = nullptr;

@@ -1,0 +1,256 @@
+// prefilter.cpp -- the decoder pre-filter: which bitbuffers does a decoder refuse on a look at their
+// head alone?  Learned by running the decoder itself under a memory fence, so every verdict is the decoder's own answer,
+// given without having seen anything the verdict does not name.
+//
+// A reference bitbuffer_t (include/bitbuffer.h:34-40) starts { u16 num_rows, free_row, bits_per_row[50], ... }.  The probe
+// bitbuffer is laid across a page boundary so that exactly num_rows, free_row and bits_per_row[0] sit on a readable page
+// and bits_per_row[1] onwards (the other lengths, the sync counts, every data byte) on pages without access.  decode_fn
+// either returns -- then it decided on those three values -- or faults, is caught and counts as "needs the record".
+// Verdicts with a failure code become bytes of a (num_rows x bits_per_row[0]) table per decoder that the slicer kernel
+// consults where it finishes a bitbuffer (BitSink::fire, slicer_device.hpp).
+//
+// Reference: account_event (src/pulse_slicer.c:26-66) is what a dropped record would have gone through; the dispatch
+// functions add the kernel's per-decoder, per-code counts to the same statistics (dispatch.cpp, apply_prefilter_counts).
+#include <climits>
+#include <csetjmp>
+#include <csignal>
+
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include "host_common.hpp"
+
+using namespace r433;
+
+namespace {
+
+thread_local sigjmp_buf t_jump;
+thread_local volatile sig_atomic_t t_armed = 0;
+struct sigaction g_prev_segv, g_prev_bus;
+
+void on_fault(int sig, siginfo_t *info, void *uctx)
+{
+    if (t_armed) {
+        t_armed = 0;
+        siglongjmp(t_jump, 1);
+    }
+    // not ours: hand over to whoever was there before
+    struct sigaction const &prev = sig == SIGSEGV ? g_prev_segv : g_prev_bus;
+    if (prev.sa_flags & SA_SIGINFO) {
+        if (prev.sa_sigaction) {
+            prev.sa_sigaction(sig, info, uctx);
+            return;
+        }
+    }
+    else if (prev.sa_handler != SIG_DFL && prev.sa_handler != SIG_IGN) {
+        prev.sa_handler(sig);
+        return;
+    }
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
+struct Fence {
+    uint8_t *region = nullptr;
+    size_t page = 0;
+    r433_bitbuffer *bits = nullptr; // its first six bytes end the readable page
+    bool ok = false;
+
+    Fence()
+    {
+        long const ps = sysconf(_SC_PAGESIZE);
+        page = ps > 0 ? (size_t)ps : 4096;
+        size_t const tail = (sizeof(r433_bitbuffer) + page - 1) / page * page + page;
+        region = (uint8_t *)mmap(nullptr, page + tail, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (region == MAP_FAILED) {
+            region = nullptr;
+            return;
+        }
+        total = page + tail;
+        if (mprotect(region + page, tail, PROT_NONE) != 0)
+            return;
+        bits = (r433_bitbuffer *)(region + page - 6);
+        struct sigaction sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.sa_sigaction = on_fault;
+        sa.sa_flags = SA_SIGINFO | SA_NODEFER;
+        sigemptyset(&sa.sa_mask);
+        if (sigaction(SIGSEGV, &sa, &g_prev_segv) != 0)
+            return;
+        if (sigaction(SIGBUS, &sa, &g_prev_bus) != 0) {
+            sigaction(SIGSEGV, &g_prev_segv, nullptr);
+            return;
+        }
+        ok = true;
+    }
+    ~Fence()
+    {
+        if (ok) {
+            sigaction(SIGSEGV, &g_prev_segv, nullptr);
+            sigaction(SIGBUS, &g_prev_bus, nullptr);
+        }
+        if (region)
+            munmap(region, total);
+    }
+    size_t total = 0;
+
+    // the decoder's answer for this head: its return value, or INT_MIN when it reached for more
+    int ask(r433_r_device *dev, unsigned rows, unsigned bits0)
+    {
+        uint16_t *head = (uint16_t *)bits;
+        head[0] = (uint16_t)rows;
+        head[1] = (uint16_t)rows;
+        head[2] = (uint16_t)bits0;
+        int ret = INT_MIN;
+        if (sigsetjmp(t_jump, 1) == 0) {
+            t_armed = 1;
+            ret = dev->decode_fn(dev, bits);
+            t_armed = 0;
+        }
+        return ret;
+    }
+};
+
+std::mutex g_probe_lock; // signal dispositions are the process's
+
+// While a decoder is being asked, whatever it hands out goes nowhere.  (A decoder that SUCCEEDS on a head alone -- a flex
+// decoder without a minimum length does -- builds a message for it; the library cannot free a data_t, so the probe drops
+// such a decoder at its first success and at most a handful of small messages are lost per engine.)
+void swallow_output(r433_r_device *, struct data *) {}
+void swallow_log(r433_r_device *, int, struct data *) {}
+
+uint8_t verdict_of(int ret) // INT_MIN (the decoder wanted more), a success and an invalid code all mean: the host decides
+{
+    return ret <= 0 && ret >= R433_DECODE_FAIL_SANITY ? (uint8_t)(-ret) : (uint8_t)kPfKeep;
+}
+
+} // namespace
+
+namespace r433 {
+
+// what the last run's filter dropped goes into the decoders' statistics, once (the three dispatch functions call this)
+void apply_prefilter_counts(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices)
+{
+    if (!b->pf_ran || b->pf_accounted)
+        return;
+    b->pf_accounted = true;
+    for (uint32_t d = 0; d < n_devices && d < b->pf_index.size(); ++d) {
+        if (!devices[d] || b->pf_index[d] < 0)
+            continue;
+        uint32_t const *c = b->h_pf_counts.p + (size_t)d * 5;
+        for (int k = 0; k < 5; ++k) {
+            devices[d]->decode_events += c[k];
+            devices[d]->decode_fails[k] += c[k];
+        }
+    }
+}
+
+} // namespace r433
+
+extern "C" {
+
+int r433_batch_probe_prefilter(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices)
+{
+    if (!b || (!devices && n_devices))
+        return fail(R433_EINVAL, "null argument");
+    if (n_devices != b->timing.size())
+        return fail(R433_EINVAL, "the probe needs the %zu devices the engine was created with", b->timing.size());
+    std::lock_guard<std::mutex> guard(g_probe_lock);
+    Fence fence;
+    if (!fence.ok)
+        return fail(R433_ENOMEM, "pre-filter probe: no fenced page (mmap / mprotect / sigaction)");
+    uint32_t const lowest = b->prio_levels.empty() ? 0u : b->prio_levels.front();
+    b->pf_tables.clear();
+    b->pf_index.assign(n_devices, -1);
+    std::vector<uint8_t> tab(kPfTable);
+    int filtered = 0;
+    for (uint32_t d = 0; d < n_devices; ++d) {
+        r433_r_device *dev = devices[d];
+        // only decoders that are called for every package, and quietly (account_event prints refused bitbuffers at -vv)
+        if (!dev || !dev->decode_fn || dev->verbose || b->timing[d].priority != lowest)
+            continue;
+        struct Quiet { // outputs off for the time of the questions
+            r433_r_device *d;
+            decltype(d->output_fn) out;
+            decltype(d->log_fn) log;
+            explicit Quiet(r433_r_device *dev) : d(dev), out(dev->output_fn), log(dev->log_fn)
+            {
+                d->output_fn = swallow_output;
+                d->log_fn = swallow_log;
+            }
+            ~Quiet()
+            {
+                d->output_fn = out;
+                d->log_fn = log;
+            }
+        } quiet(dev);
+        // a decoder that reaches past the head whatever the head says is not worth 50 000 faults, and one that accepts a
+        // bare head is nothing to filter
+        static unsigned const sample[8][2] = {{1, 0}, {1, 1}, {1, 7}, {2, 5}, {3, 200}, {1, 1000}, {5, 33}, {12, 12}};
+        bool any = false, accepts = false;
+        for (auto const &s : sample) {
+            int const ret = fence.ask(dev, s[0], s[1]);
+            any |= ret != INT_MIN;
+            accepts |= ret != INT_MIN && ret > 0;
+        }
+        if (!any || accepts)
+            continue;
+        bool useful = false;
+        for (unsigned rows = 0; rows < kPfRows && !accepts; ++rows)
+            for (unsigned bits0 = 0; bits0 < kPfBits && !accepts; ++bits0) {
+                // (an empty bitbuffer has no row: bits_per_row[0] is 0 there)
+                int const ret = rows == 0 && bits0 != 0 ? INT_MIN : fence.ask(dev, rows, bits0);
+                accepts = ret != INT_MIN && ret > 0;
+                uint8_t const v = verdict_of(ret);
+                tab[rows * kPfBits + bits0] = v;
+                useful |= v != kPfKeep;
+            }
+        if (!useful || accepts)
+            continue;
+        // the same questions again: a decoder whose answers move between calls keeps state that its length test looks at
+        bool steady = true;
+        for (unsigned rows = 0; rows < kPfRows && steady; ++rows)
+            for (unsigned bits0 = 0; bits0 < (rows ? kPfBits : 1u) && steady; bits0 += 7)
+                steady = tab[rows * kPfBits + bits0] == verdict_of(fence.ask(dev, rows, bits0));
+        if (!steady)
+            continue;
+        b->pf_index[d] = (int)(b->pf_tables.size() / kPfTable);
+        b->pf_tables.insert(b->pf_tables.end(), tab.begin(), tab.end());
+        filtered += 1;
+    }
+    for (DevRow &r : b->rows)
+        r.pf = r.orig >= 0 ? b->pf_index[(size_t)r.orig] : -1;
+    int rc;
+    if ((rc = b->d_pf_tables.ensure(std::max<size_t>(b->pf_tables.size(), 16))) || (rc = b->d_pf_counts.ensure((size_t)n_devices * 5 + 16))
+            || (rc = b->h_pf_counts.ensure((size_t)n_devices * 5 + 16)))
+        return rc;
+    if (!b->pf_tables.empty())
+        HIP_TRY(hipMemcpy(b->d_pf_tables.p, b->pf_tables.data(), b->pf_tables.size(), hipMemcpyHostToDevice));
+    if (!b->rows.empty())
+        HIP_TRY(hipMemcpy(b->d_rows.p, b->rows.data(), b->rows.size() * sizeof(DevRow), hipMemcpyHostToDevice));
+    b->pf_on = filtered > 0;
+    return filtered;
+}
+
+int r433_batch_set_prefilter(r433_batch *b, int on)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    if (on && b->pf_tables.empty())
+        return fail(R433_EINVAL, "no pre-filter tables: call r433_batch_probe_prefilter first");
+    b->pf_on = on != 0;
+    return 0;
+}
+
+int r433_batch_prefilter_counts(r433_batch *b, uint32_t const **counts, uint32_t *n_devices)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    if (counts)
+        *counts = b->pf_ran ? b->h_pf_counts.p : nullptr;
+    if (n_devices)
+        *n_devices = b->pf_ran ? (uint32_t)b->pf_index.size() : 0u;
+    return 0;
+}
+
+} // extern "C"

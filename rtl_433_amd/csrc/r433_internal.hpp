@@ -122,7 +122,12 @@ struct DevRow {
     int valid;    // 0: "sample rate too low" early return, or degenerate timing
     int orig;     // index in registration order; -1 = padding row
     int is_fsk;
+    int pf;       // index of the decoder's pre-filter table (SliceParams.pf_tables), -1 = none: every record goes to the host
 };
+
+// pre-filter tables: one byte per (num_rows 0..50, bits_per_row[0] 0..kPfBits-1); kPfKeep, or the decode_fn failure code negated
+constexpr uint32_t kPfRows = 51, kPfBits = 1024, kPfKeep = 0xff;
+constexpr uint32_t kPfTable = kPfRows * kPfBits;
 
 struct SliceParams {
     uint8_t const *arena;
@@ -142,6 +147,8 @@ struct SliceParams {
     uint8_t *stage;             // [pkg][row] slots of stage_cap bytes, or nullptr: count + write passes
     uint32_t stage_cap;
     uint32_t max_pkgs;
+    uint8_t const *pf_tables;   // pre-filter (r433_batch_probe_prefilter), or nullptr
+    uint32_t *pf_counts;        // [orig dev][5]: records the filter dropped, by failure code
 };
 
 // `order` (may be null = identity) lists the wavefront slots (whole captures or the chosen segments of split

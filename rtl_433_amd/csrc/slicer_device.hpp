@@ -46,6 +46,9 @@ template <bool WRITE> struct BitSink {
     uint32_t acc;       // bits of the dword being filled, MSB first
     uint32_t row_hdr;   // offset of the current row's header (relative to out)
     uint32_t wr;        // write cursor (relative to out)
+    // decoder pre-filter (r433_batch_probe_prefilter): the decoder's table, and what it refused so far
+    uint8_t const *pf;  // kPfTable verdicts, or nullptr
+    uint32_t pf_drop[5];
 
     __device__ __forceinline__ void put32(uint32_t at, uint32_t v)
     {
@@ -61,6 +64,8 @@ template <bool WRITE> struct BitSink {
         pkg = pkg_;
         dev = (uint16_t)dev_;
         ordinal = 0;
+        pf = nullptr;
+        pf_drop[0] = pf_drop[1] = pf_drop[2] = pf_drop[3] = pf_drop[4] = 0;
         clear();
     }
 
@@ -224,6 +229,18 @@ template <bool WRITE> struct BitSink {
     // account_event + bitbuffer_clear, src/pulse_slicer.c:26-66
     __device__ __forceinline__ void fire()
     {
+        // A bitbuffer its decoder provably refuses on num_rows / free_row / bits_per_row[0] alone never becomes a record:
+        // the next one is built over it (same offset, next ordinal), the refusal is counted under the code the decoder
+        // would have returned.  Every pass of the slicer takes the same decisions, so sizes and offsets agree.
+        if (pf && num_rows <= R433_BB_ROWS && free_row == num_rows && row0_bits < kPfBits) {
+            uint32_t const verdict = pf[num_rows * kPfBits + row0_bits];
+            if (verdict != kPfKeep) {
+                pf_drop[verdict < 5u ? verdict : 0u] += 1;
+                ordinal++;
+                clear();
+                return;
+            }
+        }
         if (num_rows > 0)
             close_row();
         put32(off, wr - off);

@@ -50,16 +50,19 @@ template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
     uint32_t const n_pkgs = min(*p.n_pkgs, p.max_pkgs);
     uint32_t const chunks = p.n_rows / 64;
     uint32_t const lane = threadIdx.x;
+    // the grid is a multiple of `chunks` (slice_grid): a workgroup keeps its 64 devices for all its packages, so what the
+    // pre-filter drops is counted in registers and leaves with one atomic per lane and code at the end
+    uint32_t const chunk = blockIdx.x % chunks;
+    uint32_t const di = chunk * 64 + lane;
+    DevRow const t = p.devs[di];
+    uint8_t const *const pf_tab = (p.pf_tables && t.pf >= 0) ? p.pf_tables + (uint64_t)t.pf * kPfTable : nullptr;
+    uint32_t dropped[5] = {0, 0, 0, 0, 0};
 
-    for (uint32_t work = blockIdx.x; work < n_pkgs * chunks; work += gridDim.x) {
-        uint32_t const pkg = work / chunks;
-        uint32_t const chunk = work - pkg * chunks;
+    for (uint32_t pkg = blockIdx.x / chunks; pkg < n_pkgs; pkg += gridDim.x / chunks) {
         uint8_t const *rec = p.arena + (uint64_t)p.dir_stream[pkg] * p.arena_stride + p.dir_off[pkg];
         uint32_t const type = ((uint32_t const *)rec)[2];
         uint32_t const num = min(((uint32_t const *)rec)[3], (uint32_t)R433_PD_MAX_PULSES);
         int2 const *src = (int2 const *)(rec + sizeof(r433_pkg_rec));
-        uint32_t const di = chunk * 64 + lane;
-        DevRow const t = p.devs[di];
         uint32_t my_size = 0;
         if (PLACE && t.orig >= 0)
             my_size = p.sizes[(uint64_t)pkg * p.n_devs + t.orig];
@@ -100,8 +103,14 @@ template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
             if (slice && fits) {
                 PulseView pv{pairs, num};
                 sink.begin(out, limit, pkg, (uint32_t)t.orig);
+                sink.pf = pf_tab;
                 slice_dispatch<STORE>(pv, t, sink);
                 my_bytes = sink.off;
+                if (!PLACE) { // the sizing pass counts; the placing pass only repeats its decisions
+#pragma unroll
+                    for (int c = 0; c < 5; ++c)
+                        dropped[c] += sink.pf_drop[c];
+                }
             }
             if (!PLACE)
                 p.sizes[(uint64_t)pkg * p.n_devs + t.orig] = my_bytes;
@@ -163,6 +172,12 @@ template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
             if (lane == 0 && tot)
                 atomicAdd(&p.pkg_bytes[pkg], tot);
         }
+    }
+    if (!PLACE && pf_tab && p.pf_counts) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+            if (dropped[c])
+                atomicAdd(&p.pf_counts[(uint32_t)t.orig * 5u + (uint32_t)c], dropped[c]);
     }
 }
 
@@ -227,11 +242,13 @@ __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t const *in, uint32_t 
 
 uint32_t slice_grid(uint32_t grid_pkgs, uint32_t n_rows)
 {
-    uint64_t items = (uint64_t)grid_pkgs * (n_rows / 64);
-    if (items < 1)
-        items = 1;
-    // 256 CUs x 8 wavefront slots per SIMD pair is plenty; the kernel grid-strides beyond this
-    return (uint32_t)(items < 16384 ? items : 16384);
+    uint32_t const chunks = n_rows / 64 ? n_rows / 64 : 1;
+    uint64_t items = (uint64_t)grid_pkgs * chunks;
+    if (items < chunks)
+        items = chunks;
+    // 256 CUs x 8 wavefront slots per SIMD pair is plenty; the kernel strides over the packages beyond this.  Always a
+    // multiple of `chunks`: a workgroup serves one chunk of devices.
+    return (uint32_t)(items < 16384 ? items : 16384 / chunks * chunks);
 }
 
 } // namespace

@@ -101,6 +101,23 @@ class BatchEngine:
                                                 C.byref(hooks) if hooks is not None else None, n_threads)
         return _lib.check(rc, "r433_batch_dispatch_ordered", self.L)
 
+    def probe_prefilter(self, rdevices):
+        """Learn which bitbuffers each decoder provably refuses on its head alone (r433_batch_probe_prefilter); from the
+        next run on the slicer kernel drops those records.  -> number of decoders with a table."""
+        rc = self.L.r433_batch_probe_prefilter(self.h, C.cast(rdevices, C.c_void_p), len(rdevices))
+        return _lib.check(rc, "r433_batch_probe_prefilter", self.L)
+
+    def set_prefilter(self, on):
+        _lib.check(self.L.r433_batch_set_prefilter(self.h, int(on)), "r433_batch_set_prefilter", self.L)
+
+    def prefilter_counts(self):
+        """[device][5] records the last run dropped on the device, by failure code (0, 1 = ABORT_LENGTH, 2 = ABORT_EARLY ...)"""
+        p, n = C.c_void_p(), C.c_uint32()
+        _lib.check(self.L.r433_batch_prefilter_counts(self.h, C.byref(p), C.byref(n)), "r433_batch_prefilter_counts", self.L)
+        if not n.value or not p.value:
+            return np.zeros((0, 5), dtype=np.uint32)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n.value, 5)).copy()
+
     def decoded(self):
         """per package: events reported by its decoders in the last dispatch"""
         p, n = C.c_void_p(), C.c_uint32()

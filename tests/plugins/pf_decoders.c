@@ -1,0 +1,82 @@
+/* TEST INFRASTRUCTURE: decode_fn plugins with the reference signature (include/r_device.h:59-92) whose first tests look
+ * like the ones in the reference's src/devices/ -- for tests/test_prefilter.py.  Compiled by the test with gcc. */
+#include <stdint.h>
+
+typedef struct { uint16_t num_rows, free_row, bits_per_row[50], syncs_before_row[50]; uint8_t bb[50][128]; } bitbuffer_t;
+struct r_device;
+
+unsigned long pf_calls[8]; /* calls that reached each decoder */
+unsigned pf_moody_n;        /* the moody decoder's memory */
+
+static int payload_verdict(bitbuffer_t *b, int row)
+{
+    unsigned s = 0;
+    for (int i = 0; i < (b->bits_per_row[row] + 7) / 8 && i < 128; ++i)
+        s += b->bb[row][i];
+    return (s % 5 == 0) ? 1 : (s % 5 == 1) ? -3 : (s % 5 == 2) ? -4 : 0; /* ok / MIC / sanity / legacy 0 */
+}
+
+/* like nice_flor_s.c:84: one exact length on row 0 */
+int pf_dec_exact(struct r_device *d, bitbuffer_t *b)
+{
+    (void)d;
+    pf_calls[0]++;
+    if (b->bits_per_row[0] != 24 && b->bits_per_row[0] != 25)
+        return -1;
+    return payload_verdict(b, 0);
+}
+
+/* like tpms_*.c: one row only, then a minimum length, then the data */
+int pf_dec_onerow(struct r_device *d, bitbuffer_t *b)
+{
+    (void)d;
+    pf_calls[1]++;
+    if (b->num_rows != 1)
+        return -2;
+    if (b->bits_per_row[0] < 16)
+        return -1;
+    return payload_verdict(b, 0);
+}
+
+/* walks the rows: looks at lengths the filter cannot vouch for */
+int pf_dec_rows(struct r_device *d, bitbuffer_t *b)
+{
+    (void)d;
+    pf_calls[2]++;
+    for (int r = 0; r < b->num_rows; ++r)
+        if (b->bits_per_row[r] >= 20)
+            return payload_verdict(b, r);
+    return -1;
+}
+
+/* the data first */
+int pf_dec_data(struct r_device *d, bitbuffer_t *b)
+{
+    (void)d;
+    pf_calls[3]++;
+    if (b->bb[0][0] == 0xff)
+        return -2;
+    return b->bits_per_row[0] < 12 ? -1 : payload_verdict(b, 0);
+}
+
+/* keeps state that its length test looks at: the probe must refuse to learn anything from it */
+int pf_dec_moody(struct r_device *d, bitbuffer_t *b)
+{
+    (void)d;
+    pf_calls[4]++;
+    if (b->bits_per_row[0] < (++pf_moody_n % 3 == 0 ? 8 : 30))
+        return -1;
+    return payload_verdict(b, 0);
+}
+
+/* an empty bitbuffer and the "legacy" 0 code */
+int pf_dec_zero(struct r_device *d, bitbuffer_t *b)
+{
+    (void)d;
+    pf_calls[5]++;
+    if (b->num_rows == 0 || b->bits_per_row[0] == 0)
+        return 0;
+    if (b->num_rows > 3)
+        return -4;
+    return payload_verdict(b, 0);
+}
