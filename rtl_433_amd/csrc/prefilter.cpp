@@ -102,7 +102,7 @@ struct Fence {
         head[1] = (uint16_t)rows;
         head[2] = (uint16_t)bits0;
         int ret = INT_MIN;
-        if (sigsetjmp(t_jump, 1) == 0) {
+        if (sigsetjmp(t_jump, 0) == 0) { // (the handler runs with SA_NODEFER and an empty mask: no signal mask to put back)
             t_armed = 1;
             ret = dev->decode_fn(dev, bits);
             t_armed = 0;
@@ -196,22 +196,37 @@ int r433_batch_probe_prefilter(r433_batch *b, r433_r_device *const *devices, uin
         if (!any || accepts)
             continue;
         bool useful = false;
-        for (unsigned rows = 0; rows < kPfRows && !accepts; ++rows)
-            for (unsigned bits0 = 0; bits0 < kPfBits && !accepts; ++bits0) {
-                // (an empty bitbuffer has no row: bits_per_row[0] is 0 there)
-                int const ret = rows == 0 && bits0 != 0 ? INT_MIN : fence.ask(dev, rows, bits0);
+        unsigned faults = 0;
+        std::fill(tab.begin(), tab.end(), (uint8_t)kPfKeep); // a head nobody asked about goes to the host: always safe
+        for (unsigned rows = 0; rows < kPfRows && !accepts && faults < 6000; ++rows) {
+            // a decoder that walks all its rows reaches past the head for every length of row 0: eight lengths tell
+            if (rows > 0) {
+                static unsigned const spread[8] = {0, 1, 9, 40, 77, 200, 520, 1023};
+                bool all_fault = true;
+                for (unsigned l : spread)
+                    all_fault &= fence.ask(dev, rows, l) == INT_MIN;
+                if (all_fault) {
+                    faults += 8;
+                    continue;
+                }
+            }
+            for (unsigned bits0 = 0; bits0 < (rows ? kPfBits : 1u) && !accepts; ++bits0) { // (an empty bitbuffer has no row)
+                int const ret = fence.ask(dev, rows, bits0);
+                faults += ret == INT_MIN;
                 accepts = ret != INT_MIN && ret > 0;
                 uint8_t const v = verdict_of(ret);
                 tab[rows * kPfBits + bits0] = v;
                 useful |= v != kPfKeep;
             }
+        }
         if (!useful || accepts)
             continue;
         // the same questions again: a decoder whose answers move between calls keeps state that its length test looks at
         bool steady = true;
         for (unsigned rows = 0; rows < kPfRows && steady; ++rows)
             for (unsigned bits0 = 0; bits0 < (rows ? kPfBits : 1u) && steady; bits0 += 7)
-                steady = tab[rows * kPfBits + bits0] == verdict_of(fence.ask(dev, rows, bits0));
+                if (tab[rows * kPfBits + bits0] != kPfKeep)
+                    steady = tab[rows * kPfBits + bits0] == verdict_of(fence.ask(dev, rows, bits0));
         if (!steady)
             continue;
         b->pf_index[d] = (int)(b->pf_tables.size() / kPfTable);
