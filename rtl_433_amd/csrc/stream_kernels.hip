@@ -279,7 +279,16 @@ __device__ __forceinline__ void ema_groups(v2s &x, int rot, int nb)
     ema_group8<56>(x, rot);
 }
 
-template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_wave(StreamParams p)
+// PAIR: a producer and a consumer wavefront per capture (workgroups of 128); otherwise one wavefront does both in turn
+// (workgroups of 64).  Two kernels, because the two forms want different register budgets: a pair's wavefront runs one role
+// only and fits three to a SIMD, the lone wavefront carries both roles' state across the tile loop.
+#ifdef R433_EMU
+#define R433_WAVES_PER_SIMD(n)
+#else
+#define R433_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#endif
+template <int SS, bool FAST, bool FM, bool SEAM = false, bool PAIR = false> __global__ __launch_bounds__(PAIR ? 128 : 64)
+        R433_WAVES_PER_SIMD(PAIR ? 3 : 2) void k_wave(StreamParams p)
 {
     using G = Geom<SS>;
     __shared__ __attribute__((aligned(16))) uint8_t s_env[64 * kPitch16];
@@ -296,13 +305,18 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
 #else
     extern __shared__ __attribute__((aligned(16))) uint8_t s_tiles[];
 #endif
-    __shared__ int s_cmax[2 * 64], s_cmin[2 * 64];
-    __shared__ int s_pflag[2]; // producer -> consumer, per buffer: the establishing tile could not be proven
-    __shared__ int s_pover;    // producer -> consumer: a filter carry was refused (det.overflow codes 2, 3)
+    // What else crosses from phase B to phase C lives in the 16 bytes of padding behind every chunk of s_env (phase A only
+    // ever stores the 64 bytes in front of them): per chunk and tile buffer the extrema of its filtered envelope, and in
+    // chunks 0..2 the producer's flags.  Kept out of arrays of their own, a pair's LDS is 26 KB: six workgroups to a CU.
+    auto st_cmax = [&](int buf, int chunk) -> short & { return *(short *)(s_env + chunk * kPitch16 + 2 * kChunk + buf * 2); };
+    auto st_cmin = [&](int buf, int chunk) -> short & { return *(short *)(s_env + chunk * kPitch16 + 2 * kChunk + 4 + buf * 2); };
+    // producer -> consumer, per buffer: the establishing tile could not be proven
+    auto st_pflag = [&](int buf) -> int & { return *(int *)(s_env + buf * kPitch16 + 2 * kChunk + 8); };
+    int &s_pover = *(int *)(s_env + 2 * kPitch16 + 2 * kChunk + 8); // producer -> consumer: a filter carry was refused (det.overflow codes 2, 3)
 
     int const lane = (int)threadIdx.x & 63;
     int const wave = (int)threadIdx.x >> 6;
-    bool const solo = blockDim.x == 64; // one wavefront does both halves
+    constexpr bool solo = !PAIR; // one wavefront does both halves
     uint8_t *const s_am = s_tiles, *const s_fm = s_tiles + (solo ? 1 : 2) * (64 * kPitchOut);
     // role 0 produces, role 1 consumes.  Workgroups alternate which wavefront takes which role, so that the two wavefronts
     // that end up on one SIMD are one of each kind, and the consumer -- the serial critical path -- issues first.
@@ -370,9 +384,13 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
 #endif
     // phase timing (RUN_DBG_TIMING only): A+B, idle, gap, pulse, gap-start, general step, resolve, iterations.
     // In LDS behind a scalar branch: an array in registers costs a select chain per update even when unused.
+#ifdef R433_KERNEL_TIMING
     __shared__ long long s_tk[16]; // 8..15: inside the train engine (window loads, pulse prologue, averages, candidate check, debounce, gap, chunk skip, legs)
     if (timing && lane < 16)
         s_tk[lane] = 0;
+#else
+    long long s_tk[16] = {0}; // never touched: `timing` is a constant false
+#endif
     auto tick = [&](int slot, long long since) {
         if (timing) {
             long long const d = (long long)clock64() - since;
@@ -830,8 +848,8 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
         carry_yf = __builtin_amdgcn_readlane(sf.y_end, 63);
         carry_xa = __builtin_amdgcn_readlane(xa1, 63);
         carry_ff = __builtin_amdgcn_readlane(ff1, 63);
-        s_cmax[buf * 64 + lane] = cmax;
-        s_cmin[buf * 64 + lane] = cmin;
+        st_cmax(buf, lane) = (short)max(cmax, -32768); // (an empty chunk keeps its sentinels, clamped to 16 bits)
+        st_cmin(buf, lane) = (short)min(cmin, 32767);
         if (p_over && lane == 0)
             s_pover = p_over;
 
@@ -842,7 +860,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
             if (__ballot(!tail_ok))
                 p_fail |= 16;
             if (lane == 0)
-                s_pflag[buf] = p_fail;
+                st_pflag(buf) = p_fail;
             return; // the consumer walks the floor over this tile
         }
         // per-frame envelope sums (u32, wraps like the reference's accumulator, baseband.c:39-44)
@@ -887,12 +905,12 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
         if (p.flags & RUN_DBG_SKIP_FILTERS)
             return;
         if (warm) {
-            if (s_pflag[buf]) // (bits: 1 the filters -- 8 a carry that cannot be proven inside the tile, 16 an unproven chunk among
-                seg_fail |= 1 | s_pflag[buf]; // those the floor is walked over --, 2 floor range too wide, 4 the walks did not meet)
+            if (st_pflag(buf)) // (bits: 1 the filters -- 8 a carry that cannot be proven inside the tile, 16 an unproven chunk among
+                seg_fail |= 1 | st_pflag(buf); // those the floor is walked over --, 2 floor range too wide, 4 the walks did not meet)
             // Noise floor at the segment's first sample: the detector is assumed idle over the last 512
             // samples with a floor of the assumed parity somewhere inside the tile's sample range; both
             // extremes of that parity are walked and must meet (see the lazy floor below).
-            int rmax = lane >= 4 ? s_cmax[buf * 64 + lane] : -0x7fffffff, rmin = lane >= 4 ? s_cmin[buf * 64 + lane] : 0x7fffffff;
+            int rmax = lane >= 4 ? st_cmax(buf, lane) : -0x7fffffff, rmin = lane >= 4 ? st_cmin(buf, lane) : 0x7fffffff;
             for (int o = 32; o > 0; o >>= 1) {
                 rmax = max(rmax, __shfl_xor(rmax, o, 64));
                 rmin = min(rmin, __shfl_xor(rmin, o, 64));
@@ -931,7 +949,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
         int ff_pk_l = 0;           // fm / 64 in both halves (the package's and the FSK detector's carrier averages)
         int bmax = 0, bmin = 0;
         // chunk statistics (lane = chunk) and their suffix extrema, for jumping over whole chunks
-        int const my_cmax = s_cmax[buf * 64 + lane], my_cmin = s_cmin[buf * 64 + lane];
+        int const my_cmax = st_cmax(buf, lane), my_cmin = st_cmin(buf, lane);
         int sfx_max = my_cmax, sfx_min = my_cmin;
         for (int o = 1; o < 64; o <<= 1) {
             int const qa = __shfl_down(sfx_max, o, 64), qb = __shfl_down(sfx_min, o, 64);
@@ -1113,8 +1131,8 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                 in_pk_l = (a64_l & 0xffff) | (f64_l << 16);
                 in_pkn_l = (a64_l & 0xffff) | (-f64_l << 16);
                 ff_pk_l = (f64_l & 0xffff) | (f64_l << 16);
-                bmax = uni(max(s_cmax[buf * 64 + (base >> 5)], s_cmax[buf * 64 + (base >> 5) + 1]));
-                bmin = uni(min(s_cmin[buf * 64 + (base >> 5)], s_cmin[buf * 64 + (base >> 5) + 1]));
+                bmax = uni(max((int)st_cmax(buf, base >> 5), (int)st_cmax(buf, (base >> 5) + 1)));
+                bmin = uni(min((int)st_cmin(buf, base >> 5), (int)st_cmin(buf, (base >> 5) + 1)));
                 loaded = base;
             };
             load_block();
@@ -1872,8 +1890,9 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
         tick(6, t_res); // the samples leave LDS with the tile
     };
 
-    // tile t + 1 is produced while tile t is consumed; one barrier per tile hands a buffer over and takes one back
-    if (solo) {
+    // tile t + 1 is produced while tile t is consumed; one barrier per tile hands a buffer over and takes one back.  The two
+    // roles are two loops: what one role keeps across tiles is dead in the other's loop (registers, scalar and vector).
+    if constexpr (solo) {
         for (uint32_t tile = tile_first; tile < tile_end; ++tile) {
             produce(tile, 0);
             wave_sync();
@@ -1881,15 +1900,17 @@ template <int SS, bool FAST, bool FM, bool SEAM = false> __global__ __launch_bou
                 consume(tile, 0);
         }
     }
+    else if (role == 0) {
+        for (uint32_t it = tile_first; it <= tile_end; ++it) {
+            if (it < tile_end)
+                produce(it, (int)(it & 1u));
+            __syncthreads();
+        }
+    }
     else {
         for (uint32_t it = tile_first; it <= tile_end; ++it) {
-            if (role == 0) {
-                if (it < tile_end)
-                    produce(it, (int)(it & 1u));
-            }
-            else if (it > tile_first) {
+            if (it > tile_first)
                 consume(it - 1, (int)((it - 1) & 1u));
-            }
             __syncthreads();
         }
     }
@@ -2022,11 +2043,13 @@ void launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st)
 {
     if (p.n_streams == 0)
         return;
-    // Two wavefronts per capture (producer + consumer) while that is what fills the chip: 1024 SIMDs x 2 wavefront slots
-    // (amdgpu_waves_per_eu(2,2)).  Past 1024 captures single wavefronts begin to fill the second slots by themselves and the
-    // pair only adds its barriers and its second pair of tile buffers (per launch, single / pair: 1024 captures 1.65 / 1.35 ms,
-    // 1536: 1.90 / 1.97, 2048: 1.90 / 2.43, 8192: 5.74 / 7.43).  RUN_ONE_WAVE / RUN_PAIR force either form (A/B timing, tests).
-    bool const pair = (p.flags & RUN_PAIR) || (!(p.flags & RUN_ONE_WAVE) && p.n_streams <= 1280u);
+    // Two wavefronts per capture (producer + consumer), three of them to a SIMD (the pair kernel is built for 168 VGPRs, a
+    // workgroup's 26 KB of LDS make six workgroups to a CU): 1536 captures in flight.  One wavefront doing both in turn needs
+    // the registers of both roles (two to a SIMD, 2048 captures in flight) and only wins where exactly that many more
+    // captures fit the chip at once.  Per launch on an MI355X, pair / single, round 3: 1024 captures 1.34 / 1.60 ms,
+    // 1536: 1.42 / 1.86, 2048: 1.99 / 1.88, 3072: 2.63 / 2.93, 4096: 3.09 / 3.33, 8192: 5.56 / 5.73
+    // (profiles/r03_b_pair_vs_single.txt).  RUN_ONE_WAVE / RUN_PAIR force either form (A/B timing, tests).
+    bool const pair = (p.flags & RUN_PAIR) || (!(p.flags & RUN_ONE_WAVE) && !(p.n_streams > 1536u && p.n_streams <= 2304u));
     dim3 grid(p.n_streams), block(pair ? 128 : 64);
     uint32_t const lds = (pair ? 4u : 2u) * 64u * (uint32_t)kPitchOut; // the tile buffers (s_tiles)
     // FAST: no filter step can wrap and both feedback coefficients are non-negative (see Track16).
@@ -2038,21 +2061,25 @@ void launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st)
     else
         fast = !p.enable_fm || (p.a32 >= 0 && p.b32 >= 0 && p.a32 + 2 * p.b32 <= (1ll << 30));
     bool const fm = p.enable_fm != 0;
-#define R433_LAUNCH_WAVE(SS)                                                                                           \
+#define R433_LAUNCH_WAVE(SS, PR)                                                                                       \
     do {                                                                                                               \
         if (fast && fm)                                                                                                \
-            hipLaunchKernelGGL((k_wave<SS, true, true>), grid, block, lds, st, p);                                       \
+            hipLaunchKernelGGL((k_wave<SS, true, true, false, PR>), grid, block, lds, st, p);                            \
         else if (fast)                                                                                                 \
-            hipLaunchKernelGGL((k_wave<SS, true, false>), grid, block, lds, st, p);                                      \
+            hipLaunchKernelGGL((k_wave<SS, true, false, false, PR>), grid, block, lds, st, p);                           \
         else if (fm)                                                                                                   \
-            hipLaunchKernelGGL((k_wave<SS, false, true>), grid, block, lds, st, p);                                      \
+            hipLaunchKernelGGL((k_wave<SS, false, true, false, PR>), grid, block, lds, st, p);                           \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_wave<SS, false, false>), grid, block, lds, st, p);                                     \
+            hipLaunchKernelGGL((k_wave<SS, false, false, false, PR>), grid, block, lds, st, p);                          \
     } while (0)
-    if (sample_size == 2)
-        R433_LAUNCH_WAVE(2);
+    if (sample_size == 2 && pair)
+        R433_LAUNCH_WAVE(2, true);
+    else if (sample_size == 2)
+        R433_LAUNCH_WAVE(2, false);
+    else if (pair)
+        R433_LAUNCH_WAVE(4, true);
     else
-        R433_LAUNCH_WAVE(4);
+        R433_LAUNCH_WAVE(4, false);
 #undef R433_LAUNCH_WAVE
 }
 
