@@ -1,0 +1,248 @@
+"""Protocol-valid synthetic transmissions: signals the reference's REAL decoders (src/devices/*.c) accept.
+
+The config-2 bursts of synth.py carry random payloads: they exercise detection and the slicers, but of 335 decoders
+hardly one ever says yes.  Here every transmission is a frame its decoder checks out -- length, fixed fields, checksum --
+keyed with the line code and the timing of that decoder's r_device entry, so the decoded JSON (model, id, values,
+mod / freq / rssi) can be compared with the reference CLI's output, priority gating and stateful decoders included.
+
+Frames come from rtl_433_amd/data/protocol_frames.json (made by tools/gen_protocol_frames.py: payload fields drawn at
+random, integrity fields found by asking the reference's own decode_fn, so nothing here restates a decoder); this
+module only turns bits into a key-on / key-off (or frequency) schedule and that into IQ samples.  The line codes are the
+inverses of the reference's slicers (src/pulse_slicer.c:68-918), written from their bit conventions:
+
+    pwm      short pulse = 1, long pulse = 0, fixed gap; optional sync pulse in front of a row
+    ppm      fixed pulse, short gap = 0, long gap = 1, a closing pulse
+    mc       Manchester, half bit = short_width; the slicer starts every row with a 0 of its own
+    dmc      differential Manchester: a level change in mid-bit = 1 (two short symbols), none = 0 (one long symbol)
+    piwm     pulse-interval and -width: every symbol (pulse or gap alike) short = 1, long = 0
+    osv1     Oregon Scientific v1 Manchester with its sync pulses
+    pcm      NRZ or RZ bits of fixed width (OOK or FSK)
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FRAMES_PATH = os.path.join(HERE, "data", "protocol_frames.json")
+_frames = None
+
+
+def frames():
+    global _frames
+    if _frames is None:
+        with open(FRAMES_PATH) as f:
+            _frames = json.load(f)
+    return _frames
+
+
+# ---------------------------------------------------------------- line codes: bits -> [(microseconds, level)]
+# level: 1 = carrier on (OOK) or the upper frequency (FSK), 0 = carrier off, -1 = the lower frequency (FSK)
+
+def _pairs(pulses):
+    out = []
+    for on, off in pulses:
+        out.append((on, 1))
+        if off:
+            out.append((off, 0))
+    return out
+
+
+def code_pwm(bits, short, long_, gap, sync=0, sync_gap=None):
+    p = []
+    if sync:
+        p.append((sync, gap if sync_gap is None else sync_gap))
+    for b in bits:
+        p.append((short if b else long_, gap))
+    return _pairs(p)
+
+
+def code_ppm(bits, pulse, gap0, gap1, closing=True):
+    p = [(pulse, gap1 if b else gap0) for b in bits]
+    out = _pairs(p)
+    if closing:
+        out.append((pulse, 1))
+    return out
+
+
+def code_mc(bits, half, lead_one=False):
+    """Manchester as pulse_slicer_manchester_zerobit reads it: a 1 is on-then-off, a 0 off-then-on.  The slicer puts a 0
+    in front of what it sees on its own account; `bits` is what should FOLLOW that 0."""
+    out = []
+    for b in bits:
+        out += [(half, 1), (half, 0)] if b else [(half, 0), (half, 1)]
+    return out
+
+
+def code_levels(levels, unit):
+    """one level per unit of time (NRZ), merged into runs"""
+    out = []
+    for lv in levels:
+        if out and out[-1][1] == lv:
+            out[-1] = (out[-1][0] + unit, lv)
+        else:
+            out.append((unit, lv))
+    return out
+
+
+def code_dmc(bits, short, long_, start_level=1):
+    """Differential Manchester, pulse_slicer_dmc: a short symbol followed by a short symbol = 1, one long symbol = 0;
+    symbols alternate pulse / gap."""
+    out, lv = [], start_level
+    for b in bits:
+        if b:
+            out += [(short, lv), (short, 1 - lv)]
+        else:
+            out.append((long_, lv))
+            lv = 1 - lv
+    return out
+
+
+def code_piwm(bits, short, long_, start_level=1):
+    """pulse_slicer_piwm_dc: every symbol, pulse or gap, short = 1 / long = 0"""
+    out, lv = [], start_level
+    for b in bits:
+        out.append((short if b else long_, lv))
+        lv = 1 - lv
+    return out
+
+
+def merge(schedule):
+    out = []
+    for us, lv in schedule:
+        if us <= 0:
+            continue
+        if out and out[-1][1] == lv:
+            out[-1] = (out[-1][0] + us, lv)
+        else:
+            out.append((us, lv))
+    return out
+
+
+# ---------------------------------------------------------------- schedule -> IQ
+
+def render_cu8(schedule, rate, rng, fsk=False, lead_us=8000.0, tail_us=None, tone_hz=None, amp=None, sigma=None, dev_hz=40e3,
+               n_samples=None):
+    """cu8 IQ of one transmission.  OOK: a tone keyed on and off; FSK: a constant envelope whose frequency steps between
+    +-dev_hz.  Random carrier offset, amplitude and noise like synth.ook_stream unless given."""
+    us = rate / 1e6
+    sched = merge(schedule)
+    lens = [max(1, int(round(d * us))) for d, _ in sched]
+    lead = int(round(lead_us * us))
+    tail = int(round((tail_us if tail_us is not None else 12000.0) * us))
+    n = lead + sum(lens) + tail
+    if n_samples is not None:
+        n = n_samples
+    level = np.zeros(n, dtype=np.float64)
+    keyed = np.zeros(n, dtype=bool)
+    pos = lead
+    for ln, (_, lv) in zip(lens, sched):
+        end = min(n, pos + ln)
+        if end > pos:
+            if fsk:
+                keyed[pos:end] = lv != 0
+                level[pos:end] = float(lv)
+            else:
+                keyed[pos:end] = lv == 1
+        pos += ln
+    tone = float(rng.uniform(-40e3, 40e3)) if tone_hz is None else tone_hz
+    a = float(rng.uniform(50.0, 110.0)) if amp is None else amp
+    sg = float(rng.integers(0, 3)) if sigma is None else sigma
+    t = np.arange(n, dtype=np.float64)
+    if fsk:
+        ph = np.cumsum(2.0 * np.pi * (dev_hz * level) / rate)
+        if tone_hz is not None:
+            ph = ph + 2.0 * np.pi * tone_hz / rate * t
+    else:
+        ph = 2.0 * np.pi * tone / rate * t
+    i = 128.0 + a * keyed * np.cos(ph)
+    q = 128.0 + a * keyed * np.sin(ph)
+    if sg > 0:
+        i = i + rng.normal(0.0, sg, n)
+        q = q + rng.normal(0.0, sg, n)
+    out = np.empty(2 * n, dtype=np.uint8)
+    out[0::2] = np.clip(np.rint(i), 0, 255).astype(np.uint8)
+    out[1::2] = np.clip(np.rint(q), 0, 255).astype(np.uint8)
+    return out
+
+
+# ---------------------------------------------------------------- the protocols
+
+def _bits(s):
+    return [int(c) for c in s if c in "01"]
+
+
+def _rows(frame):
+    """a frame of the JSON file: one bit string, or a list of them (the rows of one transmission)"""
+    return [_bits(r) for r in (frame if isinstance(frame, list) else [frame])]
+
+
+def _repeat(one_row_fn, rows, repeats, row_gap):
+    """rows keyed one after the other, `row_gap` microseconds of silence between them, the lot `repeats` times"""
+    out = []
+    k = 0
+    for _ in range(repeats):
+        for r in rows:
+            if k:
+                out.append((row_gap, 0))
+            out += one_row_fn(r)
+            k += 1
+    return out
+
+
+# name -> dict(model, protocol, fsk, rate, schedule(frame) -> [(us, level)], and what the reference CLI needs to be told)
+PROTOCOLS = {}
+
+
+def protocol(name, **kw):
+    def deco(fn):
+        PROTOCOLS[name] = dict(name=name, schedule=fn, fsk=False, rate=250000, freq=433920000, repeats=1, **kw)
+        return fn
+    return deco
+
+
+def transmission(name, seed, rate=None, n_samples=None, **render_kw):
+    """-> (cu8 IQ as uint8 array, dict(name, model, frame, rate, freq)) : frame number `seed` of the protocol's list."""
+    p = PROTOCOLS[name]
+    fr = frames()[name]
+    frame = fr[seed % len(fr)]
+    rng = np.random.default_rng(1000003 * (seed + 1) + sum(map(ord, name)))
+    rate = rate or p["rate"]
+    iq = render_cu8(p["schedule"](frame), rate, rng, fsk=p["fsk"], n_samples=n_samples, **{**p.get("render", {}), **render_kw})
+    return iq, dict(name=name, model=p["model"], frame=frame, rate=rate, freq=p["freq"])
+
+
+def file_name(name, seed, rate, freq):
+    """a file name the reference CLI reads rate and frequency from (include/fileformat.h:100-128)"""
+    f = f"{freq / 1e6:.2f}M" if freq % 1000000 else f"{freq // 1000000}M"
+    return f"p_{name}_{seed:04d}_{f}_{rate // 1000}k.cu8"
+
+
+# ---- OOK_PULSE_PPM ----
+
+def _ppm_rows(frame, pulse, gap0, gap1, row_gap, repeats):
+    return _repeat(lambda r: code_ppm(r, pulse, gap0, gap1), _rows(frame), repeats, row_gap)
+
+
+@protocol("rubicson", model="Rubicson-Temperature", protocol=2)
+def _rubicson(frame):  # src/devices/rubicson.c: 36 bits, at least three equal rows
+    return _ppm_rows(frame, 500, 1000, 2000, 4000, 4)
+
+
+@protocol("nexus", model="Nexus-TH", protocol=19)
+def _nexus(frame):  # src/devices/nexus.c: priority 10 -- runs only where no priority-0 decoder (Rubicson) had an event
+    return _ppm_rows(frame, 500, 1000, 2000, 4000, 4)
+
+
+@protocol("prologue", model="Prologue-TH", protocol=3)
+def _prologue(frame):  # src/devices/prologue.c: 36 bits, four equal rows; priority 10
+    return _ppm_rows(frame, 500, 2000, 4000, 8500, 5)
+
+
+# ---- OOK_PULSE_PWM ----
+
+@protocol("generic_remote", model="Generic-Remote", protocol=30)
+def _generic_remote(frame):  # src/devices/generic_remote.c: one row of 25 bits, fixed period
+    return code_pwm(_rows(frame)[0], 464, 1404, 464) + [(20000, 0)] + code_pwm(_rows(frame)[0], 464, 1404, 464)
