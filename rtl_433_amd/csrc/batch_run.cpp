@@ -583,7 +583,8 @@ int run_slice_and_mirror(RunCtx &r)
             // time -- and in the end the count + write pair, never a failed run)
             // do not even ask for more than the device has free: ensure() rounds up by a quarter
             size_t mem_free = 0, mem_total = 0;
-            if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess)
+            // (only when the arena has to grow: the call is a millisecond of driver time with the stream idle)
+            if (b->d_stage.cap < (size_t)r.total_pkgs * b->rows.size() * stage_cap && hipMemGetInfo(&mem_free, &mem_total) == hipSuccess)
                 while (stage_cap >= 512 && b->d_stage.cap < (size_t)r.total_pkgs * b->rows.size() * stage_cap
                         && (size_t)r.total_pkgs * b->rows.size() * stage_cap / 4 * 5 > mem_free + b->d_stage.cap)
                     stage_cap >>= 1;
