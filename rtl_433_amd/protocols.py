@@ -198,7 +198,7 @@ PROTOCOLS = {}
 
 def protocol(name, **kw):
     def deco(fn):
-        PROTOCOLS[name] = dict(name=name, schedule=fn, fsk=False, rate=250000, freq=433920000, repeats=1, **kw)
+        PROTOCOLS[name] = {**dict(name=name, schedule=fn, fsk=False, rate=250000, freq=433920000), **kw}
         return fn
     return deco
 
@@ -246,3 +246,126 @@ def _prologue(frame):  # src/devices/prologue.c: 36 bits, four equal rows; prior
 @protocol("generic_remote", model="Generic-Remote", protocol=30)
 def _generic_remote(frame):  # src/devices/generic_remote.c: one row of 25 bits, fixed period
     return code_pwm(_rows(frame)[0], 464, 1404, 464) + [(20000, 0)] + code_pwm(_rows(frame)[0], 464, 1404, 464)
+
+
+@protocol("s3318p", model="Conrad-S3318P", protocol=47)
+def _s3318p(frame):  # src/devices/s3318p.c: 42 bits, four equal rows
+    return _ppm_rows(frame, 500, 1900, 3800, 5200, 5)
+
+
+@protocol("tfa_pool", model="TFA-Pool", protocol=56)
+def _tfa_pool(frame):  # src/devices/tfa_pool_thermometer.c: 28 bits, seven equal rows
+    return _ppm_rows(frame, 500, 2000, 4600, 8800, 8)
+
+
+@protocol("thermopro_tp11", model="Thermopro-TP11", protocol=84)
+def _tp11(frame):  # src/devices/thermopro_tp11.c: 32 bits, two equal rows
+    return _ppm_rows(frame, 500, 500, 1500, 3000, 3)
+
+
+@protocol("kerui", model="Kerui-Security", protocol=68)
+def _kerui(frame):  # src/devices/kerui.c: 25 bits, nine equal rows
+    return _repeat(lambda r: code_pwm(r, 420, 960, 960), _rows(frame), 10, 7000)  # (silence between rows = this + the last bit's gap, below the reset limit)
+
+
+@protocol("quhwa", model="Quhwa-Doorbell", protocol=49)
+def _quhwa(frame):  # src/devices/quhwa.c: 18 bits, five equal rows
+    return _repeat(lambda r: code_pwm(r, 360, 1070, 700), _rows(frame), 6, 4500)
+
+
+@protocol("waveman", model="Waveman-Switch", protocol=4)
+def _waveman(frame):  # src/devices/waveman.c: one row of 25 bits
+    return code_pwm(_rows(frame)[0], 357, 1064, 700)
+
+
+# ---- OOK_PULSE_PCM ----
+
+@protocol("secplus_v1", model="Secplus-v1", protocol=178, freq=315000000)
+def _secplus(frame):  # src/devices/secplus_v1.c: two halves of 21 ternary symbols, a package each; the decoder keeps the first
+    out = []
+    for k, half in enumerate(_rows(frame)):
+        if k:
+            out.append((60000, 0))
+        out += code_levels(half, 500)
+    return out
+
+
+# ---- OOK_PULSE_MANCHESTER_ZEROBIT ----
+
+@protocol("ambient_f007th", model="Ambientweather-F007TH", protocol=20)
+def _ambient(frame):  # src/devices/ambient_weather.c: preamble 0x01 0x45 then 5 bytes and an LFSR digest; three copies in a row
+    row = _rows(frame)[0]
+    return code_mc(row + row + row, 500)
+
+
+# ---- OOK_PULSE_DMC ----
+
+@protocol("wt450", model="WT450-TH", protocol=33)
+def _wt450(frame):  # src/devices/wt450.c: 36 bits behind four preamble ones
+    return _repeat(lambda r: code_dmc(r, 976, 1952), _rows(frame), 2, 30000)
+
+
+# ---- OOK_PULSE_PWM_OSV1 ----
+
+@protocol("oregon_v1", model="Oregon-v1", protocol=50)
+def _osv1(frame):  # src/devices/oregon_scientific_v1.c behind pulse_slicer_osv1: twelve preamble pulses, the sync, 32 Manchester bits
+    h = 1465
+    out = []
+    for k in range(12):
+        out += [(h, 1), (4200 if k == 11 else h, 0)]
+    out += [(5780, 1), (5200, 0)]
+    for b in _rows(frame)[0]:
+        out += [(h, 1), (h, 0)] if b else [(h, 0), (h, 1)]
+    return out
+
+
+# ---- FSK ----
+
+def _fsk(levels_schedule):
+    """0/1 levels -> lower / upper frequency"""
+    return [(us, 1 if lv else -1) for us, lv in levels_schedule]
+
+
+@protocol("lacrosse_tx29", model="LaCrosse-TX29IT", protocol=76, fsk=True, freq=868300000, rate=1000000, render=dict(dev_hz=60e3, lead_us=3000.0, tail_us=3000.0, amp=100.0, sigma=1.0))
+def _tx29(frame):  # src/devices/lacrosse_tx35.c: preamble aa.., sync 2d d4, 5 bytes with CRC-8, NRZ at 55 us
+    return _fsk(code_levels(_rows(frame)[0], 55))
+
+
+@protocol("steelmate", model="Steelmate", protocol=59, fsk=True, rate=1000000, render=dict(dev_hz=60e3, lead_us=3000.0, tail_us=3000.0, amp=100.0, sigma=1.0))
+def _steelmate(frame):  # src/devices/steelmate.c: Manchester at 50 us half bits
+    return [(800, -1)] + _fsk(code_mc(_rows(frame)[0], 50))  # (a stretch of plain carrier first: the FSK detector settles on it)
+
+
+@protocol("efergy_e2", model="Efergy-e2CT", protocol=36, fsk=True)
+def _efergy(frame):  # src/devices/efergy_e2_classic.c: FSK PWM, a 500 us sync, 64 bits
+    return _fsk(_pairs([(500, 136)] + [(64 if b else 136, 136 if b else 64) for b in _rows(frame)[0]]))
+
+
+@protocol("acurite_606", model="Acurite-606TX", protocol=55)
+def _acurite606(frame):  # src/devices/acurite.c acurite_606_decode: 32 bits, three equal rows
+    return _ppm_rows(frame, 500, 2000, 4000, 8500, 4)
+
+
+@protocol("thermopro_tp12", model="Thermopro-TP12", protocol=97)
+def _tp12(frame):  # src/devices/thermopro_tp12.c: 41 bits, rows repeated
+    return _ppm_rows(frame, 500, 500, 1500, 3000, 4)
+
+
+@protocol("gt_wt_02", model="GT-WT02", protocol=25)
+def _gtwt02(frame):  # src/devices/gt_wt_02.c: 37 bits a row, at least two rows
+    return _ppm_rows(frame, 500, 2500, 5000, 9500, 3)
+
+
+@protocol("bresser_3ch", model="Bresser-3CH", protocol=52)
+def _bresser3ch(frame):  # src/devices/bresser_3ch.c: sync pulses, then 40 bits in a 750 us period; three equal rows
+    def row(r):
+        return _pairs([(750, 750)] * 4 + [(250, 500) if b else (500, 250) for b in r])
+    out = []
+    for _ in range(4):
+        out += row(_rows(frame)[0])
+    return out + _pairs([(750, 0)])
+
+
+@protocol("ht680", model="HT680-Remote", protocol=46)
+def _ht680(frame):  # src/devices/ht680.c: 41 bits, sync 10101 in front
+    return _repeat(lambda r: code_pwm(r, 200, 600, 400), _rows(frame), 3, 9000)

@@ -115,14 +115,26 @@ def solve(dec, rows_bits, same_rows=True, fixed=(), max_pairs=True):
 
 
 def check_signal(name, frame, seed=0):
-    """the keyed frame through the reference's whole path: does the decoder fire?"""
+    """the keyed frame through the reference CLI itself (oracle/_ref/rtl_433_ref, all default decoders): does the model
+    come out?  -> number of JSON lines with this protocol's model"""
+    import subprocess
+    import tempfile
     p = P.PROTOCOLS[name]
     rng = np.random.default_rng(seed)
     iq = P.render_cu8(p["schedule"](frame), p["rate"], rng, fsk=p["fsk"], **p.get("render", {}))
-    ref = po.Ref(protocols=[p["protocol"]], call_real=True, record=False)
-    ev = ref.run(iq, 2, p["rate"], p["freq"], fpdm=2, stream_index=0)["events_ok"]
-    ref.close()
-    return ev
+    with tempfile.TemporaryDirectory() as d:
+        fn = os.path.join(d, P.file_name(name, seed, p["rate"], p["freq"]))
+        with open(fn, "wb") as f:
+            f.write(iq.tobytes())
+        r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "rtl_433_ref"), "-r", fn, "-F", "json"] + p.get("cli", []),
+                           capture_output=True, text=True)
+    hits = 0
+    for line in r.stdout.splitlines():
+        try:
+            hits += json.loads(line).get("model") == p["model"]
+        except ValueError:
+            pass
+    return hits
 
 
 # ---------------------------------------------------------------- templates: name -> fn(rng) -> rows of bits the DECODER sees
@@ -165,10 +177,14 @@ def main(names):
         while len(good) < t.get("count", 6) and tries < t.get("tries", 60):
             tries += 1
             rows = t["fn"](rng)
-            sol = solve(dec, rows, same_rows=t.get("same_rows", True), fixed=t.get("fixed", ()), max_pairs=t.get("pairs", True))
-            if sol is None:
-                continue
-            frame = t["to_frame"](sol) if "to_frame" in t else "".join(map(str, sol[0]))
+            if t.get("raw"):  # a transmission that is not one bitbuffer (several packages): only the signal check applies
+                sol = rows
+                frame = ["".join(map(str, r)) for r in rows]
+            else:
+                sol = solve(dec, rows, same_rows=t.get("same_rows", True), fixed=t.get("fixed", ()), max_pairs=t.get("pairs", True))
+                if sol is None:
+                    continue
+                frame = t["to_frame"](sol) if "to_frame" in t else "".join(map(str, sol[0]))
             if check_signal(name, frame, seed=len(good)) <= 0:
                 print(f"  {name}: the decoder takes the bitbuffer but not the signal ({frame if isinstance(frame, str) else frame[0]})")
                 continue
