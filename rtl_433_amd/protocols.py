@@ -369,3 +369,33 @@ def _bresser3ch(frame):  # src/devices/bresser_3ch.c: sync pulses, then 40 bits 
 @protocol("ht680", model="HT680-Remote", protocol=46)
 def _ht680(frame):  # src/devices/ht680.c: 41 bits, sync 10101 in front
     return _repeat(lambda r: code_pwm(r, 200, 600, 400), _rows(frame), 3, 9000)
+
+
+_fits = {}
+
+
+def bench_capture(seed, n_samples=65536, rate=250000):
+    """A config-2 sized capture (one burst in n_samples at `rate`) that carries a protocol-valid transmission: the protocol
+    is drawn from those whose transmission fits the capture at this rate, the frame and the channel (carrier offset,
+    amplitude, noise) from the seed.  -> (cu8 IQ, meta)"""
+    tail = int(0.016 * rate)  # the end-of-package count has to fire inside the capture (src/pulse_detect.c:446-450)
+    key = (n_samples, rate)
+    if key not in _fits:
+        ok = []
+        for name in sorted(PROTOCOLS):
+            p = PROTOCOLS[name]
+            if p["rate"] != rate:
+                continue
+            busy = max(sum(us for us, _ in merge(p["schedule"](f))) for f in frames()[name]) * rate / 1e6
+            if 4000 + busy + tail <= n_samples:
+                ok.append(name)
+        _fits[key] = ok
+    names = _fits[key]
+    rng = np.random.default_rng(7919 * (seed + 1))
+    name = names[int(rng.integers(0, len(names)))]
+    p = PROTOCOLS[name]
+    fr = frames()[name]
+    frame = fr[int(rng.integers(0, len(fr)))]
+    lead = int(rng.integers(1400, 4000))
+    iq = render_cu8(p["schedule"](frame), rate, rng, fsk=p["fsk"], n_samples=n_samples, **{**p.get("render", {}), "lead_us": lead * 1e6 / rate})
+    return iq, dict(name=name, model=p["model"], frame=frame, rate=rate, freq=p["freq"])
