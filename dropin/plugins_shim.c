@@ -1,0 +1,113 @@
+/* plugins_shim.c -- the reference's protocol decoders as a shared library of plugins (dropin/_build/libr433plugins.so).
+ *
+ * The decoders are the CONSUMERS of the hot path: unchanged host C behind r_device.decode_fn (reference
+ * include/r_device.h:59-92).  A host that is not the rtl_433 CLI -- bench.py's multi-GPU run, a service that decodes
+ * uploaded captures -- needs them without the CLI around them: this file, linked with the reference's sources compiled
+ * where they lie (dropin/Makefile `plugins`; everything but src/rtl_433.c and src/r_flow.c), registers the default
+ * protocols the way the CLI does (register_all_protocols, src/r_api.c) and hands out the r_device instances.  What the
+ * decoders report (data_t) is printed with the reference's own JSON printer (data_print_jsons, src/data.c) into a
+ * buffer the host takes, one line per message -- the payload of the final event gather of BASELINE.json configs[3].
+ *
+ * Own code: only this file.  Compiled against the reference's headers; C99. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "data.h"
+#include "list.h"
+#include "logger.h"
+#include "r_api.h"
+#include "r_device.h"
+#include "r_private.h"
+#include "rtl_433.h"
+
+typedef struct r433p {
+    r_cfg_t *cfg;
+    char *text;
+    size_t len, cap;
+    unsigned long messages;
+} r433p;
+
+static void quiet_log(log_level_t level, char const *src, char const *msg, void *userdata)
+{
+    (void)level;
+    (void)src;
+    (void)msg;
+    (void)userdata;
+}
+
+static void take_message(r_device *decoder, data_t *data)
+{
+    r433p *h = decoder->output_ctx;
+    if (h->cap - h->len < 8192) {
+        h->cap  = h->cap ? h->cap * 2 : 65536;
+        h->text = realloc(h->text, h->cap);
+        if (!h->text)
+            abort();
+    }
+    size_t n = data_print_jsons(data, h->text + h->len, h->cap - h->len - 2);
+    h->len += n < h->cap - h->len - 2 ? n : strlen(h->text + h->len);
+    h->text[h->len++] = '\n';
+    h->text[h->len]   = '\0';
+    h->messages += 1;
+    data_free(data);
+}
+
+static void drop_log(r_device *decoder, int level, data_t *data)
+{
+    (void)decoder;
+    (void)level;
+    data_free(data);
+}
+
+/* all default-enabled protocols, in registration order */
+void *r433p_create(void)
+{
+    r433p *h = calloc(1, sizeof(*h));
+    if (!h)
+        return NULL;
+    r_logger_set_log_handler(quiet_log, NULL);
+    h->cfg = r_create_cfg();
+    register_all_protocols(h->cfg, 0);
+    for (void **it = h->cfg->demod->r_devs.elems; it && *it; ++it) {
+        r_device *d   = *it;
+        d->output_fn  = take_message;
+        d->log_fn     = drop_log;
+        d->output_ctx = h;
+    }
+    return h;
+}
+
+int r433p_devices(void *hv, r_device **out, int cap)
+{
+    r433p *h = hv;
+    int n    = 0;
+    for (void **it = h->cfg->demod->r_devs.elems; it && *it; ++it, ++n)
+        if (out && n < cap)
+            out[n] = *it;
+    return n;
+}
+
+/* the JSON lines since the last call (valid until the next message arrives); *messages = how many */
+size_t r433p_take(void *hv, char const **text, unsigned long *messages)
+{
+    r433p *h   = hv;
+    size_t len = h->len;
+    if (text)
+        *text = h->text ? h->text : "";
+    if (messages)
+        *messages = h->messages;
+    h->len      = 0;
+    h->messages = 0;
+    return len;
+}
+
+void r433p_destroy(void *hv)
+{
+    r433p *h = hv;
+    if (!h)
+        return;
+    r_free_cfg(h->cfg);
+    free(h->text);
+    free(h);
+}

@@ -161,36 +161,38 @@ __global__ __launch_bounds__(256) void k_cf32_to_cs16(float const *in, uint64_t 
             dst[i] = (int16_t)cf32_to_s16(src[i]);
 }
 
-// Mean raw envelope of every 2048-sample tile (as a sum): where a long capture may be cut into
-// independently processed segments -- tiles that carry no more energy than the noise floor.  A
-// heuristic only: every cut is verified after the fact.
+// Mean raw envelope of every 2048-sample tile (as a sum), ESTIMATED from an eighth of it: where a long capture may be cut
+// into independently processed segments -- tiles that carry no more energy than the noise floor -- and how heavy a
+// segment is.  A heuristic only (every cut is verified after the fact), so it must not cost a second pass over the
+// stream: eight 64-byte lines per tile, evenly spread, four lanes to a line, scaled back to the whole tile.
 template <int KIND> __global__ __launch_bounds__(64) void k_tile_max(uint8_t const *iq, uint64_t stride_bytes,
-        uint32_t const *stream_bytes, uint32_t uniform_bytes, uint32_t tiles_cap, uint32_t *tile_sum)
+        uint32_t const *stream_bytes, uint32_t uniform_bytes, uint32_t tiles_cap, uint32_t n_items, uint32_t *tile_sum)
 {
     constexpr int SS = KIND == ENV_MAG_CS16 ? 4 : 2;
-    constexpr int SPV = 16 / SS;
-    uint32_t const s = blockIdx.x / tiles_cap, t = blockIdx.x % tiles_cap;
+    constexpr uint32_t kLines = 2048u * SS / 64u; // 64-byte lines of a tile
+    constexpr uint32_t kTaken = 8;
+    // two tiles per workgroup: lanes 0..31 the first, 32..63 the second
+    uint32_t const item = min(blockIdx.x * 2u + (threadIdx.x >> 5), n_items - 1u); // (an odd count: the last half workgroup repeats the last tile)
+    uint32_t const s = item / tiles_cap, t = item % tiles_cap;
+    uint32_t const lane = threadIdx.x & 31u;
     uint32_t const my_n = (stream_bytes ? stream_bytes[s] : uniform_bytes) / SS;
     uint64_t const start = (uint64_t)t * 2048u;
     uint32_t acc = 0;
-    if (start + 2048u <= my_n) { // whole tiles only: nobody cuts next to the ragged end of a capture
+    bool const whole = start + 2048u <= my_n; // whole tiles only: nobody cuts next to the ragged end of a capture
+    if (whole) {
         uint8_t const *base = iq + (uint64_t)s * stride_bytes + start * SS;
-        for (uint32_t v = threadIdx.x; v < 2048u / SPV; v += 64) {
-            uint4 w = ((uint4 const *)base)[v];
-            if (SS == 2)
-                acc += env_one<KIND>(w.x & 0xffffu) + env_one<KIND>(w.x >> 16) + env_one<KIND>(w.y & 0xffffu) + env_one<KIND>(w.y >> 16)
-                        + env_one<KIND>(w.z & 0xffffu) + env_one<KIND>(w.z >> 16) + env_one<KIND>(w.w & 0xffffu) + env_one<KIND>(w.w >> 16);
-            else
-                acc += env_one<KIND>(w.x) + env_one<KIND>(w.y) + env_one<KIND>(w.z) + env_one<KIND>(w.w);
-        }
+        uint4 const w = *(uint4 const *)(base + (uint64_t)(lane >> 2) * (kLines / kTaken) * 64u + (lane & 3u) * 16u);
+        if (SS == 2)
+            acc = env_one<KIND>(w.x & 0xffffu) + env_one<KIND>(w.x >> 16) + env_one<KIND>(w.y & 0xffffu) + env_one<KIND>(w.y >> 16)
+                    + env_one<KIND>(w.z & 0xffffu) + env_one<KIND>(w.z >> 16) + env_one<KIND>(w.w & 0xffffu) + env_one<KIND>(w.w >> 16);
+        else
+            acc = env_one<KIND>(w.x) + env_one<KIND>(w.y) + env_one<KIND>(w.z) + env_one<KIND>(w.w);
+        acc *= kLines / kTaken;
     }
-    else {
-        acc = 0xffffffffu / 64u; // loud
-    }
-    for (int o = 32; o > 0; o >>= 1)
+    for (int o = 16; o > 0; o >>= 1)
         acc += (uint32_t)__shfl_xor((int)acc, o, 64);
-    if (threadIdx.x == 0)
-        tile_sum[blockIdx.x] = acc;
+    if (lane == 0)
+        tile_sum[item] = whole ? acc : 0xffffffffu; // a ragged tile counts as loud
 }
 
 
@@ -335,14 +337,14 @@ void launch_convert(int input_format, void const *d_in, uint64_t in_stride_bytes
 void launch_tile_max(int kind, void const *d_iq, uint64_t stride_bytes, uint32_t const *stream_bytes, uint32_t uniform_bytes,
         uint32_t n_streams, uint32_t tiles_cap, uint32_t *tile_max, hipStream_t st)
 {
-    dim3 grid(n_streams * tiles_cap), block(64);
+    dim3 grid((n_streams * tiles_cap + 1) / 2), block(64); // two tiles per workgroup (k_tile_max); the buffer holds an even count
     uint8_t const *iq = (uint8_t const *)d_iq;
     if (kind == ENV_AMP_CU8)
-        hipLaunchKernelGGL(k_tile_max<ENV_AMP_CU8>, grid, block, 0, st, iq, stride_bytes, stream_bytes, uniform_bytes, tiles_cap, tile_max);
+        hipLaunchKernelGGL(k_tile_max<ENV_AMP_CU8>, grid, block, 0, st, iq, stride_bytes, stream_bytes, uniform_bytes, tiles_cap, n_streams * tiles_cap, tile_max);
     else if (kind == ENV_MAG_CU8)
-        hipLaunchKernelGGL(k_tile_max<ENV_MAG_CU8>, grid, block, 0, st, iq, stride_bytes, stream_bytes, uniform_bytes, tiles_cap, tile_max);
+        hipLaunchKernelGGL(k_tile_max<ENV_MAG_CU8>, grid, block, 0, st, iq, stride_bytes, stream_bytes, uniform_bytes, tiles_cap, n_streams * tiles_cap, tile_max);
     else
-        hipLaunchKernelGGL(k_tile_max<ENV_MAG_CS16>, grid, block, 0, st, iq, stride_bytes, stream_bytes, uniform_bytes, tiles_cap, tile_max);
+        hipLaunchKernelGGL(k_tile_max<ENV_MAG_CS16>, grid, block, 0, st, iq, stride_bytes, stream_bytes, uniform_bytes, tiles_cap, n_streams * tiles_cap, tile_max);
 }
 
 void launch_frame_sums(int kind, void const *d_iq, uint64_t stride_bytes, uint32_t const *stream_bytes, uint32_t uniform_bytes,

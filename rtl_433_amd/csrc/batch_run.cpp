@@ -27,6 +27,8 @@ struct RunCtx {
     std::vector<uint32_t> seg_first_of; // segs of capture c: [seg_first_of[c], seg_first_of[c+1])
     std::vector<uint32_t> cap_n;        // samples per capture
     uint32_t max_seg_samples = 0, n_planned = 0, n_slots = 0;
+    uint32_t tiles_cap = 0;             // split: tile sums per capture in b->h_tile_max
+    std::vector<uint64_t> quiet_below;  // split: per capture, the tile sum below which a tile counts as quiet
     // detection result
     uint32_t n_order = 0;              // slots that make up the result, in capture order
     uint32_t const *d_order = nullptr; // null = slot i is capture i
@@ -176,6 +178,8 @@ int run_plan_split(RunCtx &r, uint32_t split_samples)
     int rc;
     constexpr uint32_t kTileS = 2048;
     uint32_t const tiles_cap = r.max_samples / kTileS + 1;
+    r.tiles_cap = tiles_cap;
+    r.quiet_below.assign(r.n_streams, 0);
     if ((rc = b->d_tile_max.ensure((size_t)r.n_streams * tiles_cap)) || (rc = b->h_tile_max.ensure((size_t)r.n_streams * tiles_cap)))
         return rc;
     launch_tile_max(r.env_kind(), r.d_iq, r.stride_bytes, r.d_lens(), (uint32_t)r.stride_bytes, r.n_streams,
@@ -206,6 +210,7 @@ int run_plan_split(RunCtx &r, uint32_t split_samples)
             std::nth_element(med.begin(), med.begin() + med.size() / 2, med.end());
             quiet_below = std::max<uint64_t>(abs_quiet, (uint64_t)med[med.size() / 2] * 3 / 2);
         }
+        r.quiet_below[c] = quiet_below;
         std::vector<uint32_t> cuts;
         uint32_t pos = seg_len;
         while (n > seg_len && pos + seg_len / 2 < n) {
@@ -278,7 +283,7 @@ int run_plan(RunCtx &r)
         b->arena_stride = (uint32_t)std::min<uint64_t>((uint64_t)std::max<uint32_t>(16384u, ((r.max_seg_samples + 4096u) + 15u) & ~15u) * b->arena_growth, 1u << 30);
     if ((rc = b->d_ring.ensure((size_t)r.n_slots * R433_PD_MAX_PULSES)) || (rc = b->d_state.ensure(r.n_slots))
             || (rc = b->d_pkg_base.ensure(r.n_slots)) || (rc = b->h_state.ensure(r.n_slots)) || (rc = b->d_order.ensure(r.n_slots))
-            || (rc = b->d_segs.ensure(r.n_slots)))
+            || (rc = b->d_segs.ensure(r.n_slots)) || (rc = b->d_wg.ensure(r.n_slots)))
         return rc;
     return 0;
 }
@@ -320,6 +325,33 @@ StreamParams stream_params(RunCtx const &r)
     sp.tap_fm = (int16_t *)b->tap_fm;
     sp.tap_stride = b->tap_stride;
     return sp;
+}
+
+// The workgroups of a launch over `n` slots of split captures: a piece whose two parity variants sit in neighbouring slots
+// becomes ONE workgroup (a producer wavefront feeding two consumers, bit 31 of the entry), and the workgroups go out
+// heaviest first -- a piece costs its tiles, a loud tile (a burst the detector has to walk) several times a quiet one --
+// so that the long pieces do not start last and finish alone.
+void plan_workgroups(RunCtx const &r, SegDesc const *segs, uint32_t n, std::vector<uint32_t> &wgs)
+{
+    r433_batch *const b = r.b;
+    std::vector<std::pair<uint64_t, uint32_t>> order; // (cost, entry)
+    for (uint32_t i = 0; i < n;) {
+        SegDesc const &d = segs[i];
+        bool const twin = i + 1 < n && !(d.flags & (SEG_FIRST | SEG_ODD)) && (segs[i + 1].flags & SEG_ODD) && segs[i + 1].capture == d.capture
+                && segs[i + 1].start == d.start && segs[i + 1].end == d.end;
+        uint64_t cost = 0;
+        if (r.tiles_cap && d.capture < r.quiet_below.size()) {
+            uint32_t const *tm = b->h_tile_max.p + (size_t)d.capture * r.tiles_cap;
+            for (uint32_t t = d.start / 2048u; t < (d.end + 2047u) / 2048u && t < r.tiles_cap; ++t)
+                cost += tm[t] >= r.quiet_below[d.capture] ? 6u : 1u;
+        }
+        order.emplace_back(cost, i | (twin ? 0x80000000u : 0u));
+        i += twin ? 2 : 1;
+    }
+    std::stable_sort(order.begin(), order.end(), [](auto const &x, auto const &y) { return x.first > y.first; });
+    wgs.clear();
+    for (auto const &o : order)
+        wgs.push_back(o.second);
 }
 
 // Stitch.  Per capture an ordered list of pieces; every piece but the first exists in two
@@ -364,6 +396,12 @@ int run_stitch(RunCtx &r, StreamParams const &sp)
         HIP_TRY(hipMemcpyAsync(b->d_segs.p + n_have, launch_list.data(), launch_list.size() * sizeof(SegDesc), hipMemcpyHostToDevice, r.st));
         StreamParams sr = sp;
         sr.n_streams = (uint32_t)launch_list.size();
+        sr.frame_sums = nullptr; // counted by the first launch
+        std::vector<uint32_t> wgs;
+        plan_workgroups(r, launch_list.data(), (uint32_t)launch_list.size(), wgs);
+        HIP_TRY(hipMemcpyAsync(b->d_wg.p + n_have, wgs.data(), wgs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, r.st));
+        sr.wg_slot = b->d_wg.p + n_have;
+        sr.n_wgs = (uint32_t)wgs.size();
         sr.segs = b->d_segs.p + n_have;
         sr.arena = b->d_arena.p + (size_t)n_have * b->arena_stride;
         sr.fsk_ring = b->d_ring.p + (size_t)n_have * R433_PD_MAX_PULSES;
@@ -482,20 +520,21 @@ int run_detect(RunCtx &r)
         if ((rc = b->d_arena.ensure((size_t)r.n_slots * b->arena_stride)))
             return rc;
         StreamParams sp = stream_params(r);
-        if (r.split) { // segments overlap in frames and may be re-run: the sums come from their own HBM-bound pass
-            sp.frame_sums = nullptr;
-            launch_frame_sums(r.env_kind(), r.d_iq, r.stride_bytes, r.d_lens(), (uint32_t)r.stride_bytes, r.n_streams,
-                    b->cfg.frame_samples, r.frames_cap, b->d_frame_sums.p, r.st);
-        }
-        else {
-            HIP_TRY(hipMemsetAsync(b->d_frame_sums.p, 0, (size_t)r.n_streams * r.frames_cap * sizeof(uint32_t), r.st));
-        }
+        // Per-frame envelope sums come out of the producers (atomic adds: a frame may be shared by several pieces).  The
+        // pieces of the FIRST launch partition every capture and only their primary variant adds, so every sample is
+        // counted exactly once there; the launches that run merged pieces again (run_stitch) add nothing.
+        HIP_TRY(hipMemsetAsync(b->d_frame_sums.p, 0, (size_t)r.n_streams * r.frames_cap * sizeof(uint32_t), r.st));
         r.d_order = nullptr;
         b->last_segments = r.n_planned;
         b->last_redone = 0;
+        std::vector<uint32_t> wgs; // (outlives the copy below: the stream is waited for before this scope ends)
         if (r.split) {
             HIP_TRY(hipMemcpyAsync(b->d_segs.p, r.segs.data(), r.segs.size() * sizeof(SegDesc), hipMemcpyHostToDevice, r.st));
             sp.segs = b->d_segs.p;
+            plan_workgroups(r, r.segs.data(), (uint32_t)r.segs.size(), wgs);
+            HIP_TRY(hipMemcpyAsync(b->d_wg.p, wgs.data(), wgs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, r.st));
+            sp.wg_slot = b->d_wg.p;
+            sp.n_wgs = (uint32_t)wgs.size();
         }
         launch_stream(sp, r.ss, r.st);
         HIP_TRY(hipGetLastError());

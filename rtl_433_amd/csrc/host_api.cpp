@@ -239,6 +239,7 @@ void r433_batch_destroy(r433_batch *b)
     b->d_frame_min_high.release();
     b->d_tile_max.release();
     b->d_order.release();
+    b->d_wg.release();
     b->d_segs.release();
     b->h_tile_max.release();
     b->h_state.release();

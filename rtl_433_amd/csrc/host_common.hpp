@@ -206,7 +206,7 @@ struct r433_batch {
     DevBuf<uint8_t> d_logic;
     PinBuf<uint8_t> h_logic;
     uint64_t logic_stride = 0;
-    DevBuf<uint32_t> d_tile_max, d_order;
+    DevBuf<uint32_t> d_tile_max, d_order, d_wg;
     DevBuf<SegDesc> d_segs;
     PinBuf<uint32_t> h_tile_max;
     PinBuf<StreamState> h_state;

@@ -89,6 +89,11 @@ struct StreamParams {
     uint32_t arena_stride;
     int2 *fsk_ring;               // n_streams * 1200 pairs
     SegDesc const *segs;          // n_streams segments (nullptr: one whole capture per wavefront)
+    // Split captures: the workgroups of the launch, heaviest first.  Entry = first slot of the workgroup; bit 31 set = the
+    // slot after it is the same piece's odd-parity variant: one producer wavefront then feeds two consumer wavefronts
+    // (the filters of a piece are computed once, its samples read once).  nullptr: slot i is workgroup i.
+    uint32_t const *wg_slot;
+    uint32_t n_wgs;
     StreamState *state;           // n_streams
     uint32_t *frame_sums;         // n_streams * frames_cap (may be null)
     uint32_t frames_cap;

@@ -279,16 +279,18 @@ __device__ __forceinline__ void ema_groups(v2s &x, int rot, int nb)
     ema_group8<56>(x, rot);
 }
 
-// PAIR: a producer and a consumer wavefront per capture (workgroups of 128); otherwise one wavefront does both in turn
-// (workgroups of 64).  Two kernels, because the two forms want different register budgets: a pair's wavefront runs one role
+// FORM 1: one wavefront does both halves in turn (workgroups of 64).  FORM 2: a producer and a consumer wavefront per
+// capture (workgroups of 128).  FORM 3: a producer and TWO consumers (workgroups of 192) for the later pieces of a split
+// capture, which exist in two parity variants of the assumed noise floor: the filters do not depend on the variant.
+// Separate kernels, because the forms want different register budgets: in a pair or a triple a wavefront runs one role
 // only and fits three to a SIMD, the lone wavefront carries both roles' state across the tile loop.
 #ifdef R433_EMU
 #define R433_WAVES_PER_SIMD(n)
 #else
 #define R433_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #endif
-template <int SS, bool FAST, bool FM, bool SEAM = false, bool PAIR = false> __global__ __launch_bounds__(PAIR ? 128 : 64)
-        R433_WAVES_PER_SIMD(PAIR ? 3 : 2) void k_wave(StreamParams p)
+template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global__ __launch_bounds__(FORM * 64)
+        R433_WAVES_PER_SIMD(FORM == 1 ? 2 : 3) void k_wave(StreamParams p)
 {
     using G = Geom<SS>;
     __shared__ __attribute__((aligned(16))) uint8_t s_env[64 * kPitch16];
@@ -316,16 +318,20 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, bool PAIR = false> __gl
 
     int const lane = (int)threadIdx.x & 63;
     int const wave = (int)threadIdx.x >> 6;
-    constexpr bool solo = !PAIR; // one wavefront does both halves
+    constexpr bool solo = FORM == 1; // one wavefront does both halves
     uint8_t *const s_am = s_tiles, *const s_fm = s_tiles + (solo ? 1 : 2) * (64 * kPitchOut);
     // role 0 produces, role 1 consumes.  Workgroups alternate which wavefront takes which role, so that the two wavefronts
     // that end up on one SIMD are one of each kind, and the consumer -- the serial critical path -- issues first.
-    int const role = solo ? 0 : (wave ^ ((p.flags & RUN_NO_ROLE_SWAP) ? 0 : (int)(blockIdx.x & 1u)));
-    if (!solo && role == 1 && !(p.flags & RUN_NO_PRIO))
+    int const role = solo ? 0 : FORM == 3 ? (wave + (int)(blockIdx.x % 3u)) % 3
+                                          : (wave ^ ((p.flags & RUN_NO_ROLE_SWAP) ? 0 : (int)(blockIdx.x & 1u)));
+    if (!solo && role != 0 && !(p.flags & RUN_NO_PRIO))
         __builtin_amdgcn_s_setprio(3);
     if (threadIdx.x == 0)
         s_pover = 0;
-    uint32_t const s = blockIdx.x; // wavefront = one capture, or one segment of a split capture
+    // workgroup = one capture, or one piece of a split capture (in both parity variants: consumers 1 and 2 of a triple)
+    uint32_t const wg = p.wg_slot ? p.wg_slot[blockIdx.x] : blockIdx.x;
+    bool const idle = FORM == 3 && role == 2 && !(wg >> 31); // a triple whose piece has one variant only: the third wavefront just keeps the barriers
+    uint32_t const s = (wg & 0x7fffffffu) + (FORM == 3 && role == 2 && !idle ? 1u : 0u);
     uint32_t const cap = p.segs ? p.segs[s].capture : s;
     uint32_t const my_bytes = p.stream_bytes ? p.stream_bytes[cap] : p.uniform_bytes;
     uint32_t const my_n = my_bytes / SS;
@@ -1909,13 +1915,13 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, bool PAIR = false> __gl
     }
     else {
         for (uint32_t it = tile_first; it <= tile_end; ++it) {
-            if (it > tile_first)
+            if (it > tile_first && !idle)
                 consume(it - 1, (int)((it - 1) & 1u));
             __syncthreads();
         }
     }
-    if (!solo && role == 0)
-        return; // the consumer wavefront reports
+    if ((!solo && role == 0) || idle)
+        return; // the consumer wavefronts report
     if (s_pover)
         det.overflow = (uint32_t)s_pover;
 
@@ -2050,8 +2056,10 @@ void launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st)
     // 1536: 1.42 / 1.86, 2048: 1.99 / 1.88, 3072: 2.63 / 2.93, 4096: 3.09 / 3.33, 8192: 5.56 / 5.73
     // (profiles/r03_b_pair_vs_single.txt).  RUN_ONE_WAVE / RUN_PAIR force either form (A/B timing, tests).
     bool const pair = (p.flags & RUN_PAIR) || (!(p.flags & RUN_ONE_WAVE) && !(p.n_streams > 1536u && p.n_streams <= 2304u));
-    dim3 grid(p.n_streams), block(pair ? 128 : 64);
-    uint32_t const lds = (pair ? 4u : 2u) * 64u * (uint32_t)kPitchOut; // the tile buffers (s_tiles)
+    // split captures come with their workgroup list: a producer and (where a piece has both parity variants) two consumers
+    bool const triple = p.wg_slot != nullptr && !(p.flags & RUN_ONE_WAVE);
+    dim3 grid(p.wg_slot ? p.n_wgs : p.n_streams), block(triple ? 192 : pair ? 128 : 64);
+    uint32_t const lds = (pair || triple ? 4u : 2u) * 64u * (uint32_t)kPitchOut; // the tile buffers (s_tiles)
     // FAST: no filter step can wrap and both feedback coefficients are non-negative (see Track16).
     // The AM filter always qualifies (13993 + 2*1195 <= 16384); the FM filter does for every cutoff
     // up to half the Nyquist rate, which includes the defaults.
@@ -2061,25 +2069,29 @@ void launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st)
     else
         fast = !p.enable_fm || (p.a32 >= 0 && p.b32 >= 0 && p.a32 + 2 * p.b32 <= (1ll << 30));
     bool const fm = p.enable_fm != 0;
-#define R433_LAUNCH_WAVE(SS, PR)                                                                                       \
+#define R433_LAUNCH_WAVE(SS, FORM)                                                                                     \
     do {                                                                                                               \
         if (fast && fm)                                                                                                \
-            hipLaunchKernelGGL((k_wave<SS, true, true, false, PR>), grid, block, lds, st, p);                            \
+            hipLaunchKernelGGL((k_wave<SS, true, true, false, FORM>), grid, block, lds, st, p);                          \
         else if (fast)                                                                                                 \
-            hipLaunchKernelGGL((k_wave<SS, true, false, false, PR>), grid, block, lds, st, p);                           \
+            hipLaunchKernelGGL((k_wave<SS, true, false, false, FORM>), grid, block, lds, st, p);                         \
         else if (fm)                                                                                                   \
-            hipLaunchKernelGGL((k_wave<SS, false, true, false, PR>), grid, block, lds, st, p);                           \
+            hipLaunchKernelGGL((k_wave<SS, false, true, false, FORM>), grid, block, lds, st, p);                         \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_wave<SS, false, false, false, PR>), grid, block, lds, st, p);                          \
+            hipLaunchKernelGGL((k_wave<SS, false, false, false, FORM>), grid, block, lds, st, p);                        \
     } while (0)
-    if (sample_size == 2 && pair)
-        R433_LAUNCH_WAVE(2, true);
+    if (sample_size == 2 && triple)
+        R433_LAUNCH_WAVE(2, 3);
+    else if (sample_size == 2 && pair)
+        R433_LAUNCH_WAVE(2, 2);
     else if (sample_size == 2)
-        R433_LAUNCH_WAVE(2, false);
+        R433_LAUNCH_WAVE(2, 1);
+    else if (triple)
+        R433_LAUNCH_WAVE(4, 3);
     else if (pair)
-        R433_LAUNCH_WAVE(4, true);
+        R433_LAUNCH_WAVE(4, 2);
     else
-        R433_LAUNCH_WAVE(4, false);
+        R433_LAUNCH_WAVE(4, 1);
 #undef R433_LAUNCH_WAVE
 }
 

@@ -1,0 +1,44 @@
+"""The reference's protocol decoders as plugins for hosts that are not the rtl_433 CLI (dropin/_build/libr433plugins.so:
+the reference's sources compiled where they lie + dropin/plugins_shim.c).  They are the consumers of the hot path --
+unchanged host C behind r_device.decode_fn -- and what they report comes back as JSON lines printed by the reference's
+own data_print_jsons.  bench.py's multi-GPU run (configs[3]) gathers exactly those lines on rank 0."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "..", "dropin", "_build", "libr433plugins.so")
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+class Plugins:
+    def __init__(self):
+        if not available():
+            raise RuntimeError(f"{LIB_PATH} is missing: `make -C dropin plugins` (needs the reference tree once)")
+        L = C.CDLL(os.path.abspath(LIB_PATH))
+        L.r433p_create.restype = C.c_void_p
+        L.r433p_devices.restype = C.c_int
+        L.r433p_devices.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.r433p_take.restype = C.c_size_t
+        L.r433p_take.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_ulong)]
+        L.r433p_destroy.argtypes = [C.c_void_p]
+        self.L = L
+        self.h = L.r433p_create()
+        n = L.r433p_devices(self.h, None, 0)
+        self.devices = (C.c_void_p * n)()
+        assert L.r433p_devices(self.h, self.devices, n) == n
+
+    def take(self):
+        """-> (JSON lines since the last call as bytes, number of messages)"""
+        text, n = C.c_char_p(), C.c_ulong()
+        ln = self.L.r433p_take(self.h, C.byref(text), C.byref(n))
+        return (C.string_at(text, ln) if ln else b""), int(n.value)
+
+    def close(self):
+        if self.h:
+            self.L.r433p_destroy(self.h)
+            self.h = None

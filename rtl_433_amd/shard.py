@@ -94,12 +94,16 @@ def unpack_rank_record(blob: bytes) -> dict:
     return dict(first=f, packages=npk, events=nev, digest=dsum, extra=x, pk=blob[40:])
 
 
-def gather_rank_records(payload: bytes, dist_on: bool, dst=0, device=None):
-    """All ranks call this with their packed record; rank `dst` gets the list of unpacked records in rank order (and
-    the package records merged into the canonical stream of the whole list under "merged"), the others None."""
+def gather_rank_records(payload: bytes, dist_on: bool, dst=0, device=None, tail="packages"):
+    """All ranks call this with their packed record; rank `dst` gets the list of unpacked records in rank order, the
+    others None.  tail = "packages": the records' tails are package records, merged into the canonical stream of the
+    whole list under "merged"; tail = "text": the tails are the ranks' decoded events as JSON lines, which concatenate
+    as they are (capture order is rank order)."""
     got = gather_bytes(payload, dst=dst, device=device) if dist_on else [payload]
     if got is None:
         return None
     per = [unpack_rank_record(b) for b in got]
+    if tail == "text":
+        return dict(per_rank=per, merged=b"".join(p["pk"] for p in per))
     merged, _ = merge_rank_records([(p["first"], p["packages"], p["pk"], b"") for p in per])
     return dict(per_rank=per, merged=merged)

@@ -140,3 +140,61 @@ def test_two_rank_bench_record_gather():
         p.join(60)
         assert p.exitcode == 0
     assert all(res), res
+
+
+def _worker_decoded_gather(rank, world, port, out_q):
+    """configs[3] as bench.py --config 4 runs it: every rank decodes its shard of the list with the reference's real
+    decoders (dropin/_build/libr433plugins.so) behind the ordered replay, serialises what they report as JSON lines and the
+    ONE collective moves those bytes; rank 0's concatenation must be what a single process prints for the whole list."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from rtl_433_amd import plugins, protocols, shard, synth
+    from rtl_433_amd.engine import BatchEngine, flow_cfg, load_device_table
+    from tests.emu import host
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        devs = load_device_table()[0]
+        caps = [protocols.bench_capture(3 * i + 2)[0] if i % 2 else synth.ook_stream(700 + i)[0] for i in range(6)]
+
+        def decode(part):
+            plug = plugins.Plugins()
+            eng = BatchEngine(flow_cfg(2, 250000), devs, library=host.emu_lib())
+            eng.probe_prefilter(plug.devices)
+            n = eng.run_host(part)
+            eng.dispatch_ordered(plug.devices, None, 2)
+            text, n_msg = plug.take()
+            eng.close()
+            plug.close()
+            return n, n_msg, text
+        b = shard.partition(len(caps), world)
+        npk, n_msg, text = decode(caps[b[rank]:b[rank + 1]])
+        got = shard.gather_rank_records(shard.pack_rank_record(b[rank], npk, n_msg, 0, len(text), text), True, dst=0, tail="text")
+        if rank == 0:
+            _, n_all, text_all = decode(caps)
+            per = got["per_rank"]
+            out_q.put((got["merged"] == text_all, sum(p["events"] for p in per) == n_all, n_all >= 3, text_all.count(b'"model"') == n_all))
+        else:
+            assert got is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_decoded_event_gather():
+    from rtl_433_amd import plugins
+    if not plugins.available():
+        pytest.skip("dropin/_build/libr433plugins.so not built (needs /root/reference once)")
+    import torch.multiprocessing as mp
+    build_emu.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_decoded_gather, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=900)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(res), res

@@ -3,7 +3,7 @@
 (--kernel-trace, no other tracing domain), FETCH_SIZE doubled on gfx950 (128-byte requests of wide coalesced streaming
 reads are tallied at 64 bytes), WRITE_SIZE as it is (uncalibrated).  Run on the GPU box:
 
-    python tools/pmc_traffic.py            -> gpurun_out/r02_pmc/traffic.json   (copy to profiles/r02_pmc_traffic.json)
+    python tools/pmc_traffic.py[keys...]  -> gpurun_out/r03_pmc/traffic.json   (copy to profiles/r03_pmc_traffic.json)
 """
 import json
 import os
@@ -12,18 +12,18 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "gpurun_out", "r02_pmc")
+OUT = os.path.join(ROOT, "gpurun_out", "r03_pmc")
 
 WORKLOADS = {
     # key: (command, kernel name pattern, algorithmic bytes per launch, what a launch is)
     "config2": ([sys.executable, os.path.join(ROOT, "tools", "kbench.py"), "--reps", "2"], "k_wave<2", 2 * 1024 * 65536,
                 "k_wave<2,true,true>, 1024 captures x 65536 cu8 samples (tools/kbench.py, all decoders), one launch"),
-    "config3": ([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "3", "--quick", "--steps", "2", "--warmup", "1"], "k_wave<4", 4 * (64 << 20),
-                "k_wave<4,true,true> over the verified segments of one 64 Mi-sample cs16 stream (bench.py --config 3): all its launches of one pass"),
+    "config3": ([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "3", "--quick", "--steps", "2", "--warmup", "1"], ("k_wave<4", "k_tile_max", "k_frame_sums"), 4 * (64 << 20),
+                "every kernel that reads the stream in one pass of bench.py --config 3 (one 64 Mi-sample cs16 stream): the cut-planning estimate k_tile_max and k_wave<4,...> over the verified segments, all launches"),
     "config4": ([sys.executable, os.path.join(ROOT, "tools", "kbench.py"), "--reps", "2", "--nodevs", "--streams", "8192"], "k_wave<2", 2 * 8192 * 65536,
                 "k_wave<2,true,true>, one launch of 8192 captures x 65536 cu8 samples (what bench.py --config 4 launches eight times per step)"),
-    "config5": ([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "5", "--quick", "--steps", "2", "--warmup", "1"], "k_wave<2", 2 * (256 << 20),
-                "k_wave<2,..> over the verified segments of one 256 Mi-sample 2 MS/s cu8 stream (bench.py --config 5): all its launches of one pass"),
+    "config5": ([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "5", "--quick", "--steps", "2", "--warmup", "1"], ("k_wave<2", "k_tile_max", "k_frame_sums"), 2 * (256 << 20),
+                "every kernel that reads the stream in one pass of bench.py --config 5 (one 256 Mi-sample 2 MS/s cu8 stream, -Y autolevel): k_frame_sums (the levels of every frame have to be known before detection), k_tile_max, k_wave<2,...> over the segments"),
 }
 
 
@@ -46,14 +46,18 @@ def one_pass(tag, counter, cmd):
 
 def main():
     res = {}
+    want = sys.argv[1:] or list(WORKLOADS)
     for key, (cmd, pat, alg, what) in WORKLOADS.items():
+        if key not in want:
+            continue
         got = {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             rows = one_pass(key, counter, cmd)
             if rows is None:
                 got = None
                 break
-            mine = [(n, d, v) for n, d, v in rows if pat in n]
+            pats = pat if isinstance(pat, tuple) else (pat,)
+            mine = [(n, d, v) for n, d, v in rows if any(q in n for q in pats)]
             got[counter] = mine
         if not got:
             continue
