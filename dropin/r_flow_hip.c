@@ -96,11 +96,23 @@ typedef struct hip_capture {
     int irregular;
 } hip_capture;
 
-static struct {
+/* An engine per flow configuration met so far (a file list may alternate between sample rates or formats): creating one
+   costs device allocations, so the last few stay. */
+#define HIP_ENGINES 4
+typedef struct hip_engine {
     r433_batch *eng;
-    r433_flow_cfg eng_cfg;
-    size_t eng_devs;
-    void *eng_first_dev;
+    r433_flow_cfg cfg;
+    size_t devs;
+    void *first_dev;
+    int probed, tables; /* the decoder pre-filter of this engine: asked for, decoders with a table */
+    unsigned long used; /* for the least recently used */
+} hip_engine;
+
+static struct {
+    r433_batch *eng; /* the engine of the pass at hand (one of engines[]) */
+    hip_engine engines[HIP_ENGINES];
+    hip_engine *cur;
+    unsigned long eng_clock;
     uint8_t *stage; /* pinned */
     size_t stage_cap, stage_len;
     hip_capture *caps;
@@ -119,7 +131,6 @@ static struct {
     size_t quality_cap, quality_n;
     /* answering every push at once (-E: the file loop acts on the event count of a push) */
     int sync_active, sync_flush, warned_sync_grab;
-    int eng_probed, eng_tables; /* the decoder pre-filter of H.eng: asked for, decoders with a table */
     uint32_t sync_frame;            /* the frame just pushed */
     unsigned sync_count, sync_squelch; /* frames / noise-only frames the run before this one counted for the same capture */
     uint32_t fm_note_rate; /* the rate the "FM low pass filter" notice was last printed for (src/baseband.c:217,310) */
@@ -460,9 +471,21 @@ static void engine_ensure(r_cfg_t *cfg, r433_flow_cfg const *fc)
 {
     struct dm_state *demod = cfg->demod;
     void *first            = demod->r_devs.len ? demod->r_devs.elems[0] : NULL;
-    if (H.eng && memcmp(fc, &H.eng_cfg, sizeof(*fc)) == 0 && H.eng_devs == demod->r_devs.len && H.eng_first_dev == first)
-        return;
-    r433_batch_destroy(H.eng);
+    hip_engine *slot       = NULL;
+    for (int k = 0; k < HIP_ENGINES; ++k) {
+        hip_engine *e = &H.engines[k];
+        if (e->eng && memcmp(fc, &e->cfg, sizeof(*fc)) == 0 && e->devs == demod->r_devs.len && e->first_dev == first) {
+            e->used = ++H.eng_clock;
+            H.cur   = e;
+            H.eng   = e->eng;
+            return;
+        }
+        /* where a new engine would go: the first empty place, else the one that rested longest */
+        if (!slot || (slot->eng && (!e->eng || e->used < slot->used)))
+            slot = e;
+    }
+    r433_batch_destroy(slot->eng);
+    memset(slot, 0, sizeof(*slot));
     size_t n              = demod->r_devs.len;
     r433_dev_timing *rows = calloc(n ? n : 1, sizeof(*rows));
     if (!rows)
@@ -478,15 +501,16 @@ static void engine_ensure(r_cfg_t *cfg, r433_flow_cfg const *fc)
         rows[i].tolerance   = d->tolerance;
         rows[i].priority    = d->priority;
     }
-    H.eng = r433_batch_create(fc, rows, (uint32_t)n);
+    slot->eng = r433_batch_create(fc, rows, (uint32_t)n);
     free(rows);
-    if (!H.eng)
+    if (!slot->eng)
         hip_fatal("r433_batch_create");
-    H.eng_cfg       = *fc;
-    H.eng_devs      = n;
-    H.eng_first_dev = first;
-    H.eng_probed    = 0;
-    H.eng_tables    = 0;
+    slot->cfg       = *fc;
+    slot->devs      = n;
+    slot->first_dev = first;
+    slot->used      = ++H.eng_clock;
+    H.cur           = slot;
+    H.eng           = slot->eng;
 }
 
 /* The replay is quiet and spread over threads (see the dispatch below): then no hook looks at single decoder calls, and the
@@ -507,14 +531,14 @@ static void engine_prefilter(r_cfg_t *cfg)
     struct dm_state *demod = cfg->demod;
     char const *env        = getenv("RTL433_HIP_PREFILTER");
     int const want         = !(env && env[0] == '0') && !H.sync_active && replay_threads() > 1 && !replay_is_chatty(demod) && demod->r_devs.len;
-    if (want && !H.eng_probed) {
-        H.eng_probed = 1;
-        int const t  = r433_batch_probe_prefilter(H.eng, (r433_r_device *const *)demod->r_devs.elems, (uint32_t)demod->r_devs.len);
+    if (want && !H.cur->probed) {
+        H.cur->probed = 1;
+        int const t   = r433_batch_probe_prefilter(H.eng, (r433_r_device *const *)demod->r_devs.elems, (uint32_t)demod->r_devs.len);
         if (t < 0)
             hip_fatal("r433_batch_probe_prefilter");
-        H.eng_tables = t;
+        H.cur->tables = t;
     }
-    if (H.eng_tables > 0 && r433_batch_set_prefilter(H.eng, want) < 0)
+    if (H.cur->tables > 0 && r433_batch_set_prefilter(H.eng, want) < 0)
         hip_fatal("r433_batch_set_prefilter");
 }
 

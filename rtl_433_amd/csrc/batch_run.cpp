@@ -599,6 +599,9 @@ int run_slice_and_mirror(RunCtx &r)
     lp.pkg_bytes = b->d_pkg_bytes.p;
     lp.pkg_off = b->d_pkg_off.p;
     lp.max_pkgs = max_pkgs;
+    bool placed = false; // the event records are in d_events already (large batches: stretch by stretch)
+    lp.pkg_begin = 0;
+    lp.pkg_end = max_pkgs;
     b->pf_ran = b->pf_accounted = false;
     if (b->pf_on && n_devs && r.total_pkgs) { // decoder pre-filter (prefilter.cpp): records their decoder provably refuses stay here
         lp.pf_tables = b->d_pf_tables.p;
@@ -614,8 +617,16 @@ int run_slice_and_mirror(RunCtx &r)
         // (3.2 GB for the 1024 x 384 rows of the bench batch, of 288 GB).  Below 512 B the classic count + write
         // pair runs instead.
         constexpr size_t kStageMax = (size_t)32 << 30;
+        // Large batches go through the slicers a stretch of packages at a time, every stretch into the SAME staging slots:
+        // 8192 packages x 384 rows x 8 KB of sparsely written slots are 25 GB of address space, and the slicing pass of
+        // such a launch took twice what eight launches of 1024 packages take (TLB reach); stretches of 1024 packages keep
+        // the arena at 3 GB.  Each stretch: slice into the slots, scan its sizes on from the total so far, place.
+        uint32_t const stretch = (b->debug_flags & R433_DEBUG_TWO_PASS_SLICER) ? r.total_pkgs
+                : (b->debug_flags & R433_DEBUG_SMALL_STRETCH)                   ? std::min<uint32_t>(3u, r.total_pkgs)
+                : r.total_pkgs > 1536u                                         ? 1024u
+                                                                                : r.total_pkgs;
         uint32_t stage_cap = 8192;
-        while (stage_cap >= 512 && (size_t)r.total_pkgs * b->rows.size() * stage_cap > kStageMax)
+        while (stage_cap >= 512 && (size_t)stretch * b->rows.size() * stage_cap > kStageMax)
             stage_cap >>= 1;
         if (!(b->debug_flags & R433_DEBUG_TWO_PASS_SLICER)) {
             // (a device with less free memory than that: smaller slots -- a record that outgrows its slot is sliced a second
@@ -623,12 +634,12 @@ int run_slice_and_mirror(RunCtx &r)
             // do not even ask for more than the device has free: ensure() rounds up by a quarter
             size_t mem_free = 0, mem_total = 0;
             // (only when the arena has to grow: the call is a millisecond of driver time with the stream idle)
-            if (b->d_stage.cap < (size_t)r.total_pkgs * b->rows.size() * stage_cap && hipMemGetInfo(&mem_free, &mem_total) == hipSuccess)
-                while (stage_cap >= 512 && b->d_stage.cap < (size_t)r.total_pkgs * b->rows.size() * stage_cap
-                        && (size_t)r.total_pkgs * b->rows.size() * stage_cap / 4 * 5 > mem_free + b->d_stage.cap)
+            if (b->d_stage.cap < (size_t)stretch * b->rows.size() * stage_cap && hipMemGetInfo(&mem_free, &mem_total) == hipSuccess)
+                while (stage_cap >= 512 && b->d_stage.cap < (size_t)stretch * b->rows.size() * stage_cap
+                        && (size_t)stretch * b->rows.size() * stage_cap / 4 * 5 > mem_free + b->d_stage.cap)
                     stage_cap >>= 1;
             for (; stage_cap >= 512; stage_cap >>= 1) {
-                if (b->d_stage.ensure((size_t)r.total_pkgs * b->rows.size() * stage_cap) == 0) {
+                if (b->d_stage.ensure((size_t)stretch * b->rows.size() * stage_cap) == 0) {
                     lp.stage = b->d_stage.p;
                     lp.stage_cap = stage_cap;
                     break;
@@ -636,12 +647,47 @@ int run_slice_and_mirror(RunCtx &r)
                 (void)hipGetLastError(); // a refused allocation must not fail the launch checks below (sticky on some ROCm releases)
             }
         }
-        HIP_TRY(hipMemsetAsync(b->d_pkg_bytes.p, 0, (size_t)max_pkgs * sizeof(uint32_t), r.st));
-        launch_slice_count(lp, r.total_pkgs, r.st);
-        HIP_TRY(hipGetLastError());
-        if (b->profiling)
-            HIP_TRY(hipEventRecord(b->ev[3], r.st));
-        launch_scan_u32(b->d_pkg_bytes.p, b->d_pkg_off.p, b->d_scal.p, max_pkgs, b->d_scal.p + 3, r.st);
+        if (lp.stage && stretch < r.total_pkgs) {
+            // The event stream has to be there before the first stretch is placed, and its size is only known after the
+            // last: what the engine's earlier runs needed (or ~40 KB a package) is taken, records beyond it are left out
+            // by the placing pass (bounds-checked), and a total that did not fit means one more round with the exact size.
+            size_t want = std::max<size_t>(b->d_events.cap, (size_t)r.total_pkgs * 40960u);
+            for (int round = 0;; ++round) {
+                if ((rc = b->d_events.ensure(std::min<size_t>(want, 0xf0000010ull))))
+                    return rc;
+                lp.events = b->d_events.p;
+                lp.events_cap = (uint32_t)std::min<size_t>(b->d_events.cap, 0xffffffffu);
+                HIP_TRY(hipMemsetAsync(b->d_pkg_bytes.p, 0, (size_t)max_pkgs * sizeof(uint32_t), r.st));
+                HIP_TRY(hipMemsetAsync(b->d_scal.p + 3, 0, sizeof(uint32_t), r.st));
+                if (lp.pf_counts)
+                    HIP_TRY(hipMemsetAsync(b->d_pf_counts.p, 0, (size_t)n_devs * 5 * sizeof(uint32_t), r.st));
+                for (uint32_t p0 = 0; p0 < r.total_pkgs; p0 += stretch) {
+                    lp.pkg_begin = p0;
+                    lp.pkg_end = std::min(r.total_pkgs, p0 + stretch);
+                    launch_slice_count(lp, lp.pkg_end - p0, r.st);
+                    launch_scan_u32(b->d_pkg_bytes.p, b->d_pkg_off.p, b->d_scal.p, lp.pkg_end, b->d_scal.p + 3, r.st, b->d_scal.p + 3, p0);
+                    launch_slice_write(lp, lp.pkg_end - p0, r.st);
+                }
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(b->h_scal.p, b->d_scal.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, r.st));
+                HIP_TRY(stream_wait(b, r.st));
+                size_t const total = b->h_scal.p[3];
+                if (total + 16 <= b->d_events.cap || total > 0xf0000000ull || round >= 2)
+                    break;
+                want = total + total / 8 + 16;
+            }
+            placed = true;
+            if (b->profiling)
+                HIP_TRY(hipEventRecord(b->ev[3], r.st));
+        }
+        else {
+            HIP_TRY(hipMemsetAsync(b->d_pkg_bytes.p, 0, (size_t)max_pkgs * sizeof(uint32_t), r.st));
+            launch_slice_count(lp, r.total_pkgs, r.st);
+            HIP_TRY(hipGetLastError());
+            if (b->profiling)
+                HIP_TRY(hipEventRecord(b->ev[3], r.st));
+            launch_scan_u32(b->d_pkg_bytes.p, b->d_pkg_off.p, b->d_scal.p, max_pkgs, b->d_scal.p + 3, r.st);
+        }
     }
     else {
         HIP_TRY(hipMemsetAsync(b->d_scal.p + 3, 0, sizeof(uint32_t), r.st));
@@ -669,7 +715,7 @@ int run_slice_and_mirror(RunCtx &r)
         launch_gather_packages(b->d_arena.p, b->arena_stride, b->d_dir_stream.p, b->d_dir_off.p, b->d_rec_off.p,
                 b->d_scal.p, max_pkgs, b->d_pkg_blob.p, (uint32_t)std::min<size_t>(b->d_pkg_blob.cap, 0xffffffffu),
                 r.total_pkgs, r.st);
-        if (n_devs && evt_bytes) {
+        if (n_devs && evt_bytes && !placed) {
             lp.events = b->d_events.p;
             lp.events_cap = (uint32_t)std::min<size_t>(b->d_events.cap, 0xffffffffu);
             launch_slice_write(lp, r.total_pkgs, r.st);
@@ -693,8 +739,6 @@ int run_slice_and_mirror(RunCtx &r)
     }
     HIP_TRY(hipMemcpyAsync(b->h_frame_sums.p, b->d_frame_sums.p, (size_t)r.n_streams * r.frames_cap * sizeof(uint32_t),
             hipMemcpyDeviceToHost, r.st));
-    if (lp.pf_counts)
-        HIP_TRY(hipMemcpyAsync(b->h_pf_counts.p, b->d_pf_counts.p, (size_t)n_devs * 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, r.st));
     if (lp.pf_counts)
         HIP_TRY(hipMemcpyAsync(b->h_pf_counts.p, b->d_pf_counts.p, (size_t)n_devs * 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, r.st));
     if (b->logic_on && r.d_iq)

@@ -13,6 +13,8 @@
 // functions add the kernel's per-decoder, per-code counts to the same statistics (dispatch.cpp, apply_prefilter_counts).
 #include <climits>
 #include <csetjmp>
+#include <map>
+#include <tuple>
 #include <csignal>
 
 #include <sys/mman.h>
@@ -113,6 +115,19 @@ struct Fence {
 
 std::mutex g_probe_lock; // signal dispositions are the process's
 
+// What a decoder answered is kept for the life of the process: a host that runs several engines over the same decoders
+// (a pipeline of engines, the drop-in's engine per sample rate) asks once.  Keyed by the decoder object and everything of
+// it the probe depends on; an empty table = nothing to filter.
+struct ProbeKey {
+    void const *dev, *fn, *ctx;
+    int verbose;
+    bool operator<(ProbeKey const &o) const
+    {
+        return std::tie(dev, fn, ctx, verbose) < std::tie(o.dev, o.fn, o.ctx, o.verbose);
+    }
+};
+std::map<ProbeKey, std::vector<uint8_t>> g_known;
+
 // While a decoder is being asked, whatever it hands out goes nowhere.  (A decoder that SUCCEEDS on a head alone -- a flex
 // decoder without a minimum length does -- builds a message for it; the library cannot free a data_t, so the probe drops
 // such a decoder at its first success and at most a handful of small messages are lost per engine.)
@@ -169,6 +184,17 @@ int r433_batch_probe_prefilter(r433_batch *b, r433_r_device *const *devices, uin
         // only decoders that are called for every package, and quietly (account_event prints refused bitbuffers at -vv)
         if (!dev || !dev->decode_fn || dev->verbose || b->timing[d].priority != lowest)
             continue;
+        ProbeKey const key{dev, (void const *)dev->decode_fn, dev->decode_ctx, dev->verbose};
+        auto const known = g_known.find(key);
+        if (known != g_known.end()) {
+            if (!known->second.empty()) {
+                b->pf_index[d] = (int)(b->pf_tables.size() / kPfTable);
+                b->pf_tables.insert(b->pf_tables.end(), known->second.begin(), known->second.end());
+                filtered += 1;
+            }
+            continue;
+        }
+        std::vector<uint8_t> &verdicts = g_known[key]; // stays empty unless the questions below end well
         struct Quiet { // outputs off for the time of the questions
             r433_r_device *d;
             decltype(d->output_fn) out;
@@ -231,6 +257,7 @@ int r433_batch_probe_prefilter(r433_batch *b, r433_r_device *const *devices, uin
             continue;
         b->pf_index[d] = (int)(b->pf_tables.size() / kPfTable);
         b->pf_tables.insert(b->pf_tables.end(), tab.begin(), tab.end());
+        verdicts = tab;
         filtered += 1;
     }
     for (DevRow &r : b->rows)

@@ -152,6 +152,7 @@ struct SliceParams {
     uint8_t *stage;             // [pkg][row] slots of stage_cap bytes, or nullptr: count + write passes
     uint32_t stage_cap;
     uint32_t max_pkgs;
+    uint32_t pkg_begin, pkg_end; // the packages of this launch: [pkg_begin, min(pkg_end, *n_pkgs)); staging slots count from pkg_begin
     uint8_t const *pf_tables;   // pre-filter (r433_batch_probe_prefilter), or nullptr
     uint32_t *pf_counts;        // [orig dev][5]: records the filter dropped, by failure code
 };
@@ -166,8 +167,9 @@ void launch_directory(uint8_t const *arena, uint32_t arena_stride, StreamState c
         uint32_t n, uint32_t const *pkg_base, uint32_t *dir_stream, uint32_t *dir_off, uint32_t *rec_bytes,
         uint32_t max_pkgs, hipStream_t st);
 // out[i] = sum(in[0..i)), *total = sum(in[0..n)), n = min(*n_ptr, n_cap); single block
+// (carry_in, may be null or equal to total: the scan starts from *carry_in, e.g. the total of the stretch before this one)
 void launch_scan_u32(uint32_t const *in, uint32_t *out, uint32_t const *n_ptr, uint32_t n_cap, uint32_t *total,
-        hipStream_t st);
+        hipStream_t st, uint32_t const *carry_in = nullptr, uint32_t n_skip = 0);
 // dense copy of all package records in canonical order
 void launch_gather_packages(uint8_t const *arena, uint32_t arena_stride, uint32_t const *dir_stream,
         uint32_t const *dir_off, uint32_t const *rec_off, uint32_t const *n_pkgs, uint32_t max_pkgs, uint8_t *dst,

@@ -47,7 +47,7 @@ template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
     constexpr bool STORE = MODE != M_COUNT;                       // the sink stores bytes
     __shared__ int2 pairs[R433_PD_MAX_PULSES];
 
-    uint32_t const n_pkgs = min(*p.n_pkgs, p.max_pkgs);
+    uint32_t const n_pkgs = min(min(*p.n_pkgs, p.max_pkgs), p.pkg_end);
     uint32_t const chunks = p.n_rows / 64;
     uint32_t const lane = threadIdx.x;
     // the grid is a multiple of `chunks` (slice_grid): a workgroup keeps its 64 devices for all its packages, so what the
@@ -58,7 +58,7 @@ template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
     uint8_t const *const pf_tab = (p.pf_tables && t.pf >= 0) ? p.pf_tables + (uint64_t)t.pf * kPfTable : nullptr;
     uint32_t dropped[5] = {0, 0, 0, 0, 0};
 
-    for (uint32_t pkg = blockIdx.x / chunks; pkg < n_pkgs; pkg += gridDim.x / chunks) {
+    for (uint32_t pkg = p.pkg_begin + blockIdx.x / chunks; pkg < n_pkgs; pkg += gridDim.x / chunks) {
         uint8_t const *rec = p.arena + (uint64_t)p.dir_stream[pkg] * p.arena_stride + p.dir_off[pkg];
         uint32_t const type = ((uint32_t const *)rec)[2];
         uint32_t const num = min(((uint32_t const *)rec)[3], (uint32_t)R433_PD_MAX_PULSES);
@@ -79,7 +79,7 @@ template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
         if (t.orig >= 0) { // not a padding row
             bool const run = t.valid && (t.is_fsk != 0) == (type == R433_PKG_FSK);
             uint8_t *const slot = MODE == M_STAGE || MODE == M_COMPACT
-                    ? p.stage + ((uint64_t)pkg * p.n_rows + di) * p.stage_cap : nullptr;
+                    ? p.stage + ((uint64_t)(pkg - p.pkg_begin) * p.n_rows + di) * p.stage_cap : nullptr;
             BitSink<STORE> sink;
             uint8_t *out = nullptr;
             uint32_t limit = 0;
@@ -122,7 +122,7 @@ template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
             // per record, 64 in a row.  The rare long record is left to the whole wavefront below.
             constexpr uint32_t kOwn = 512;
             if (copy_bytes > 0 && copy_bytes <= kOwn) {
-                uint8_t const *src_r = p.stage + ((uint64_t)pkg * p.n_rows + di) * p.stage_cap;
+                uint8_t const *src_r = p.stage + ((uint64_t)(pkg - p.pkg_begin) * p.n_rows + di) * p.stage_cap;
                 uint32_t *dst = (uint32_t *)(p.events + copy_base);
                 uint32_t const words = copy_bytes / 4;
                 for (uint32_t w = 0; w < words; w += 16) {
@@ -146,7 +146,7 @@ template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
                 todo &= todo - 1;
                 uint32_t const nb = (uint32_t)__builtin_amdgcn_readlane((int)copy_bytes, r);
                 uint32_t const at = (uint32_t)__builtin_amdgcn_readlane((int)copy_base, r);
-                uint8_t const *src_r = p.stage + ((uint64_t)pkg * p.n_rows + chunk * 64 + (uint32_t)r) * p.stage_cap;
+                uint8_t const *src_r = p.stage + ((uint64_t)(pkg - p.pkg_begin) * p.n_rows + chunk * 64 + (uint32_t)r) * p.stage_cap;
                 uint32_t *const dst = (uint32_t *)(p.events + at);
                 for (uint32_t w0 = 0; w0 < nb; w0 += 4096) { // 4 KB a round: four 16-byte loads per lane in flight, then the stores
                     uint4 v[4];
@@ -185,11 +185,11 @@ template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
 // of sizes[pkg][.] in registration order, once per package (every (package, 64 devices) item of the placing pass needs
 // one entry of it; computed inside that pass it was six dependent load + scan rounds per item, most of the pass).
 __global__ __launch_bounds__(64) void k_dev_prefix(uint32_t const *sizes, uint32_t *dev_off, uint32_t const *n_pkgs_ptr,
-        uint32_t max_pkgs, uint32_t n_devs)
+        uint32_t max_pkgs, uint32_t n_devs, uint32_t pkg_begin, uint32_t pkg_end)
 {
-    uint32_t const n_pkgs = min(*n_pkgs_ptr, max_pkgs);
+    uint32_t const n_pkgs = min(min(*n_pkgs_ptr, max_pkgs), pkg_end);
     uint32_t const lane = threadIdx.x;
-    for (uint32_t pkg = blockIdx.x; pkg < n_pkgs; pkg += gridDim.x) {
+    for (uint32_t pkg = pkg_begin + blockIdx.x; pkg < n_pkgs; pkg += gridDim.x) {
         uint32_t carry = 0;
         for (uint32_t b = 0; b < n_devs; b += 64) {
             uint32_t const i = b + lane;
@@ -207,16 +207,16 @@ __global__ __launch_bounds__(64) void k_dev_prefix(uint32_t const *sizes, uint32
 // 32-bit by format, and a batch whose records pass 4 GiB must come back as R433_EOVERFLOW (the host checks the total),
 // never as offsets that wrapped around and records that overwrite each other.
 __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t const *in, uint32_t *out, uint32_t const *n_ptr,
-        uint32_t n_cap, uint32_t *total)
+        uint32_t n_cap, uint32_t *total, uint32_t const *carry_in, uint32_t n_skip)
 {
     __shared__ uint64_t part[1024];
     __shared__ uint64_t carry;
-    uint32_t const n = min(*n_ptr, n_cap);
+    uint32_t const n = min(*n_ptr, n_cap); // elements [n_skip, n) of in / out; the sums start from *carry_in
     int const tid = (int)threadIdx.x;
     if (tid == 0)
-        carry = 0;
+        carry = carry_in ? *carry_in : 0u;
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024) {
+    for (uint32_t base = n_skip; base < n; base += 1024) {
         uint32_t i = base + (uint32_t)tid;
         uint64_t v = i < n ? in[i] : 0u;
         part[tid] = v;
@@ -253,6 +253,7 @@ uint32_t slice_grid(uint32_t grid_pkgs, uint32_t n_rows)
 
 } // namespace
 
+// (grid_pkgs: the packages of THIS launch, p.pkg_end - p.pkg_begin or fewer)
 void launch_slice_count(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st)
 {
     if (p.stage)
@@ -262,15 +263,15 @@ void launch_slice_count(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st
 }
 
 void launch_scan_u32(uint32_t const *in, uint32_t *out, uint32_t const *n_ptr, uint32_t n_cap, uint32_t *total,
-        hipStream_t st)
+        hipStream_t st, uint32_t const *carry_in, uint32_t n_skip)
 {
-    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, in, out, n_ptr, n_cap, total);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, in, out, n_ptr, n_cap, total, carry_in, n_skip);
 }
 
 void launch_slice_write(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st)
 {
     hipLaunchKernelGGL(k_dev_prefix, dim3(grid_pkgs < 1 ? 1 : grid_pkgs < 16384 ? grid_pkgs : 16384), dim3(64), 0, st, p.sizes, p.dev_off,
-            p.n_pkgs, p.max_pkgs, p.n_devs);
+            p.n_pkgs, p.max_pkgs, p.n_devs, p.pkg_begin, p.pkg_end);
     if (p.stage)
         hipLaunchKernelGGL(k_slice<M_COMPACT>, dim3(slice_grid(grid_pkgs, p.n_rows)), dim3(64), 0, st, p);
     else

@@ -18,7 +18,13 @@ pytestmark = pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/rtl
 
 
 def write_corpus(d, n_files, names=None):
-    names = names or sorted(P.PROTOCOLS)
+    """n_files transmissions, the protocols taking turns.  The files of the stateful decoder go FIRST: secplus_v1 pairs the
+    halves it is handed within 800 ms of WALL CLOCK (src/devices/secplus_v1.c:140,196-215), and a Generic-Remote burst
+    happens to look like one half to it -- with such a stray half pending, what the reference itself prints for the next
+    Secplus file depends on how fast the machine is."""
+    # (Generic-Remote stays out of the long lists for the same reason: two of its bursts, files apart, pair up as one
+    # Secplus message or do not, by the clock.  It is in the short list of the emulator test, where nothing follows it.)
+    names = names or [n for n in sorted(P.PROTOCOLS) if n != "generic_remote"]
     files, want = [], []
     for k in range(n_files):
         name = names[k % len(names)]
@@ -28,7 +34,8 @@ def write_corpus(d, n_files, names=None):
         iq.tofile(os.path.join(d, fn))
         files.append(fn)
         want.append(meta["model"])
-    return files, want
+    first = [f for f in files if f.startswith("p_secplus")]
+    return first + [f for f in files if not f.startswith("p_secplus")], want
 
 
 def models_of(stdout):
