@@ -621,7 +621,7 @@ int run_slice_and_mirror(RunCtx &r)
         // 8192 packages x 384 rows x 8 KB of sparsely written slots are 25 GB of address space, and the slicing pass of
         // such a launch took twice what eight launches of 1024 packages take (TLB reach); stretches of 1024 packages keep
         // the arena at 3 GB.  Each stretch: slice into the slots, scan its sizes on from the total so far, place.
-        uint32_t const stretch = (b->debug_flags & R433_DEBUG_TWO_PASS_SLICER) ? r.total_pkgs
+        uint32_t const stretch = (b->debug_flags & (R433_DEBUG_TWO_PASS_SLICER | R433_DEBUG_ONE_STRETCH)) ? r.total_pkgs
                 : (b->debug_flags & R433_DEBUG_SMALL_STRETCH)                   ? std::min<uint32_t>(3u, r.total_pkgs)
                 : r.total_pkgs > 1536u                                         ? 1024u
                                                                                 : r.total_pkgs;

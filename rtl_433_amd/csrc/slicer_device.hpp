@@ -48,7 +48,7 @@ template <bool WRITE> struct BitSink {
     uint32_t wr;        // write cursor (relative to out)
     // decoder pre-filter (r433_batch_probe_prefilter): the decoder's table, and what it refused so far
     uint8_t const *pf;  // kPfTable verdicts, or nullptr
-    uint32_t pf_drop[5];
+    uint32_t pf_d0, pf_d1, pf_d2, pf_d3, pf_d4; // (five scalars, not an array: a dynamically indexed array would live in scratch memory)
 
     __device__ __forceinline__ void put32(uint32_t at, uint32_t v)
     {
@@ -65,7 +65,7 @@ template <bool WRITE> struct BitSink {
         dev = (uint16_t)dev_;
         ordinal = 0;
         pf = nullptr;
-        pf_drop[0] = pf_drop[1] = pf_drop[2] = pf_drop[3] = pf_drop[4] = 0;
+        pf_d0 = pf_d1 = pf_d2 = pf_d3 = pf_d4 = 0;
         clear();
     }
 
@@ -235,7 +235,11 @@ template <bool WRITE> struct BitSink {
         if (pf && num_rows <= R433_BB_ROWS && free_row == num_rows && row0_bits < kPfBits) {
             uint32_t const verdict = pf[num_rows * kPfBits + row0_bits];
             if (verdict != kPfKeep) {
-                pf_drop[verdict < 5u ? verdict : 0u] += 1;
+                pf_d0 += verdict == 0u || verdict > 4u;
+                pf_d1 += verdict == 1u;
+                pf_d2 += verdict == 2u;
+                pf_d3 += verdict == 3u;
+                pf_d4 += verdict == 4u;
                 ordinal++;
                 clear();
                 return;

@@ -54,15 +54,23 @@ template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
     // pre-filter drops is counted in registers and leaves with one atomic per lane and code at the end
     uint32_t const chunk = blockIdx.x % chunks;
     uint32_t const di = chunk * 64 + lane;
-    DevRow const t = p.devs[di];
-    uint8_t const *const pf_tab = (p.pf_tables && t.pf >= 0) ? p.pf_tables + (uint64_t)t.pf * kPfTable : nullptr;
-    uint32_t dropped[5] = {0, 0, 0, 0, 0};
+    int const my_pf = p.devs[di].pf, my_orig = p.devs[di].orig;
+    uint8_t const *const pf_tab = (p.pf_tables && my_pf >= 0) ? p.pf_tables + (uint64_t)my_pf * kPfTable : nullptr;
+    uint32_t dropped0 = 0, dropped1 = 0, dropped2 = 0, dropped3 = 0, dropped4 = 0;
 
     for (uint32_t pkg = p.pkg_begin + blockIdx.x / chunks; pkg < n_pkgs; pkg += gridDim.x / chunks) {
         uint8_t const *rec = p.arena + (uint64_t)p.dir_stream[pkg] * p.arena_stride + p.dir_off[pkg];
         uint32_t const type = ((uint32_t const *)rec)[2];
         uint32_t const num = min(((uint32_t const *)rec)[3], (uint32_t)R433_PD_MAX_PULSES);
         int2 const *src = (int2 const *)(rec + sizeof(r433_pkg_rec));
+        // The device row is read again for every package ON PURPOSE (the index is made opaque): with the row known to be the
+        // same for all packages the compiler unswitches the loop on its modulation -- ten copies of the loop, twice the
+        // registers, three times the run time.
+        uint32_t di_now = di;
+#ifndef R433_EMU
+        asm volatile("" : "+v"(di_now));
+#endif
+        DevRow const t = p.devs[di_now];
         uint32_t my_size = 0;
         if (PLACE && t.orig >= 0)
             my_size = p.sizes[(uint64_t)pkg * p.n_devs + t.orig];
@@ -107,9 +115,11 @@ template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
                 slice_dispatch<STORE>(pv, t, sink);
                 my_bytes = sink.off;
                 if (!PLACE) { // the sizing pass counts; the placing pass only repeats its decisions
-#pragma unroll
-                    for (int c = 0; c < 5; ++c)
-                        dropped[c] += sink.pf_drop[c];
+                    dropped0 += sink.pf_d0;
+                    dropped1 += sink.pf_d1;
+                    dropped2 += sink.pf_d2;
+                    dropped3 += sink.pf_d3;
+                    dropped4 += sink.pf_d4;
                 }
             }
             if (!PLACE)
@@ -174,10 +184,12 @@ template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
         }
     }
     if (!PLACE && pf_tab && p.pf_counts) {
-#pragma unroll
-        for (int c = 0; c < 5; ++c)
-            if (dropped[c])
-                atomicAdd(&p.pf_counts[(uint32_t)t.orig * 5u + (uint32_t)c], dropped[c]);
+        uint32_t *const c = p.pf_counts + (uint32_t)my_orig * 5u;
+        if (dropped0) atomicAdd(c + 0, dropped0);
+        if (dropped1) atomicAdd(c + 1, dropped1);
+        if (dropped2) atomicAdd(c + 2, dropped2);
+        if (dropped3) atomicAdd(c + 3, dropped3);
+        if (dropped4) atomicAdd(c + 4, dropped4);
     }
 }
 
