@@ -86,6 +86,16 @@ typedef struct r433_r_device {
     void *output_ctx;
 } r433_r_device;
 
+/* pulse_detect_fsk_t, reference include/pulse_detect_fsk.h:23-41 (32 bytes) */
+typedef struct r433_fsk_state {
+    unsigned fsk_pulse_length; /* counter for internal FSK pulse detection */
+    unsigned fsk_state;        /* PD_FSK_STATE_INIT 0, _FH 1, _FL 2, _ERROR 3 */
+    int fm_f1_est;             /* estimate for the F1 frequency for FSK */
+    int fm_f2_est;             /* estimate for the F2 frequency for FSK */
+    int16_t var_test_max, var_test_min, maxx, minn, midd; /* min/max detector */
+    int skip_samples;
+} r433_fsk_state;
+
 /* decode_fn return codes, reference include/r_device.h:45-53 */
 #define R433_DECODE_FAIL_OTHER 0
 #define R433_DECODE_ABORT_LENGTH (-1)
@@ -95,6 +105,7 @@ typedef struct r433_r_device {
 
 #if defined(__cplusplus)
 static_assert(sizeof(r433_bitbuffer) == 6604, "bitbuffer_t layout");
+static_assert(sizeof(r433_fsk_state) == 32, "pulse_detect_fsk_t layout");
 static_assert(sizeof(r433_pulse_data) == 9672, "pulse_data_t layout");
 static_assert(offsetof(r433_pulse_data, pulse) == 28, "pulse_data_t layout");
 static_assert(offsetof(r433_pulse_data, ook_low_estimate) == 9628, "pulse_data_t layout");

@@ -309,6 +309,16 @@ void r433_detector_set_levels(r433_detector *d, int use_mag_est, float fixed_hig
 int r433_detector_package(r433_detector *d, int16_t const *envelope, int16_t const *fm, int len, uint32_t samp_rate, uint64_t sample_offset,
         r433_pulse_data *pulses, r433_pulse_data *fsk_pulses, unsigned fpdm);
 
+/* The FSK sub-detectors pulse_detect_package drives, one sample per call, as calls of their own (reference
+ * include/pulse_detect_fsk.h:46-75, src/pulse_detect_fsk.c:34-221): the caller's pulse_detect_fsk_t and pulse list go to the
+ * device, one wavefront runs the step the detection kernel runs (csrc/detect_device.hpp), both come back.  op:
+ * R433_FSK_CLASSIC / R433_FSK_MINMAX take the sample fm; R433_FSK_WRAP_UP closes the list (classic detector, :143-156).
+ * For the completeness of the function-level seam; the fast path has these fused into k_wave. */
+#define R433_FSK_CLASSIC 1
+#define R433_FSK_MINMAX 2
+#define R433_FSK_WRAP_UP 3
+int r433_fsk_step(int op, r433_fsk_state *s, int fm, r433_pulse_data *fsk_pulses);
+
 /* The file loop's input conversions (src/rtl_433.c:1811-1834) on device buffers: n = number of components
  * (2 per IQ sample).  cs8 -> cu8: +128.  cf32 -> cs16: (int)(f * 32767) clamped to +-32767, with C-on-x86
  * semantics for values no int can hold (they become -32767). */

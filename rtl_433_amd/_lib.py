@@ -128,7 +128,7 @@ EXPORTS = [
     "r433_filter_frame", "r433_envelope_host", "r433_host_alloc", "r433_host_free", "r433_batch_run_host", "r433_batch_dispatch_hooks", "r433_batch_dispatch_ordered", "r433_batch_decoded",
     "r433_dump_convert_host", "r433_batch_set_package_quality",
     "r433_batch_probe_prefilter", "r433_batch_set_prefilter", "r433_batch_prefilter_counts",
-    "r433_detector_create", "r433_detector_destroy", "r433_detector_reset", "r433_detector_set_levels", "r433_detector_package",
+    "r433_fsk_step", "r433_detector_create", "r433_detector_destroy", "r433_detector_reset", "r433_detector_set_levels", "r433_detector_package",
 ]
 
 
@@ -245,6 +245,8 @@ def bind(L):
     L.r433_detector_set_levels.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float]
     L.r433_detector_package.restype = C.c_int
     L.r433_detector_package.argtypes = [vp, vp, vp, C.c_int, C.c_uint32, C.c_uint64, vp, vp, C.c_uint]
+    L.r433_fsk_step.restype = C.c_int
+    L.r433_fsk_step.argtypes = [C.c_int, vp, C.c_int, vp]
     L.r433_host_alloc.restype = vp
     L.r433_host_alloc.argtypes = [C.c_size_t]
     L.r433_host_free.restype = None

@@ -264,3 +264,112 @@ int r433_detector_package(r433_detector *d, int16_t const *envelope, int16_t con
 }
 
 } // extern "C"
+
+// ---- the FSK sub-detectors on their own: pulse_detect_fsk_classic / _minmax / _wrap_up (reference
+// include/pulse_detect_fsk.h:46-75, src/pulse_detect_fsk.c:34-221).  In the reference only pulse_detect_package calls them,
+// one sample at a time; here they are the device functions the detection kernel runs (detect_device.hpp: fsk_classic,
+// fsk_minmax, the wrap-up at the head of emit_fsk).  Exported for the completeness of the function-level seam: one call
+// is one sample through one wavefront, with the caller's pulse list carried to the device and back -- about the contract,
+// not about speed. ----
+
+namespace r433 {
+namespace {
+
+struct FskSeamIO {
+    uint32_t f_run;
+    int f_state, f_f1, f_f2, f_vmax, f_vmin, f_skip;
+    uint32_t fsk_num;
+    uint64_t fsk_offset;
+};
+
+__global__ __launch_bounds__(64) void k_fsk_step(int op, int fm, FskSeamIO *io, int2 *ring)
+{
+    DetLane d;
+    det_reset(d);
+    d.f_run = io->f_run, d.f_state = io->f_state, d.f_f1 = io->f_f1, d.f_f2 = io->f_f2, d.f_vmax = io->f_vmax, d.f_vmin = io->f_vmin;
+    d.f_skip = io->f_skip;
+    d.fsk_num = io->fsk_num;
+    d.fsk_offset = io->fsk_offset;
+    d.fsk_ring = ring;
+    d.writer = threadIdx.x == 0;
+    d.arena = nullptr;
+    d.arena_cap = 0;
+    d.cursor = d.ook_base = d.n_pkgs = d.overflow = d.stream = 0;
+    __syncthreads(); // every lane has read the state before lane 0 writes it back
+    if (op == R433_FSK_CLASSIC) {
+        fsk_classic(d, fm);
+    }
+    else if (op == R433_FSK_MINMAX) {
+        fsk_minmax(d, fm);
+    }
+    else if (d.fsk_num < R433_PD_MAX_PULSES) { // wrap-up, src/pulse_detect_fsk.c:143-156
+        d.f_run += 1;
+        if (d.f_state == 1) {
+            ring_set(d, 2 * d.fsk_num, (int)d.f_run);
+            ring_set(d, 2 * d.fsk_num + 1, 0);
+        }
+        else {
+            ring_set(d, 2 * d.fsk_num + 1, (int)d.f_run);
+        }
+        d.fsk_num += 1;
+    }
+    if (threadIdx.x == 0) {
+        io->f_run = d.f_run, io->f_state = d.f_state, io->f_f1 = d.f_f1, io->f_f2 = d.f_f2, io->f_vmax = d.f_vmax, io->f_vmin = d.f_vmin;
+        io->f_skip = d.f_skip;
+        io->fsk_num = d.fsk_num;
+        io->fsk_offset = d.fsk_offset;
+    }
+}
+
+struct FskSeamBufs {
+    FskSeamIO *d_io = nullptr;
+    int2 *d_ring = nullptr;
+    FskSeamIO *h_io = nullptr; // pinned
+    int2 *h_ring = nullptr;
+    std::mutex m;
+} g_fsk;
+
+} // namespace
+} // namespace r433
+
+extern "C" int r433_fsk_step(int op, r433_fsk_state *s, int fm, r433_pulse_data *fsk_pulses)
+{
+    if (!s || !fsk_pulses || op < R433_FSK_CLASSIC || op > R433_FSK_WRAP_UP)
+        return fail(R433_EINVAL, "r433_fsk_step: bad argument");
+    std::lock_guard<std::mutex> g(g_fsk.m);
+    if (!g_fsk.d_io) {
+        HIP_TRY(hipMalloc((void **)&g_fsk.d_io, sizeof(FskSeamIO)));
+        HIP_TRY(hipMalloc((void **)&g_fsk.d_ring, sizeof(int2) * R433_PD_MAX_PULSES));
+        HIP_TRY(hipHostMalloc((void **)&g_fsk.h_io, sizeof(FskSeamIO), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&g_fsk.h_ring, sizeof(int2) * R433_PD_MAX_PULSES, hipHostMallocDefault));
+    }
+    FskSeamIO &io = *g_fsk.h_io;
+    io.f_run = s->fsk_pulse_length;
+    io.f_state = (int)s->fsk_state;
+    io.f_f1 = s->fm_f1_est, io.f_f2 = s->fm_f2_est;
+    io.f_vmax = s->var_test_max, io.f_vmin = s->var_test_min;
+    io.f_skip = s->skip_samples;
+    io.fsk_num = fsk_pulses->num_pulses;
+    io.fsk_offset = fsk_pulses->offset;
+    for (unsigned k = 0; k < R433_PD_MAX_PULSES; ++k)
+        g_fsk.h_ring[k] = make_int2(fsk_pulses->pulse[k], fsk_pulses->gap[k]);
+    HIP_TRY(hipMemcpyAsync(g_fsk.d_io, g_fsk.h_io, sizeof(FskSeamIO), hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(g_fsk.d_ring, g_fsk.h_ring, sizeof(int2) * R433_PD_MAX_PULSES, hipMemcpyHostToDevice, nullptr));
+    hipLaunchKernelGGL(k_fsk_step, dim3(1), dim3(64), 0, nullptr, op, fm, g_fsk.d_io, g_fsk.d_ring);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(g_fsk.h_io, g_fsk.d_io, sizeof(FskSeamIO), hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipMemcpyAsync(g_fsk.h_ring, g_fsk.d_ring, sizeof(int2) * R433_PD_MAX_PULSES, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    s->fsk_pulse_length = io.f_run;
+    s->fsk_state = (unsigned)io.f_state;
+    s->fm_f1_est = io.f_f1, s->fm_f2_est = io.f_f2;
+    s->var_test_max = (int16_t)io.f_vmax, s->var_test_min = (int16_t)io.f_vmin;
+    s->skip_samples = io.f_skip;
+    fsk_pulses->num_pulses = io.fsk_num;
+    fsk_pulses->offset = io.fsk_offset;
+    for (unsigned k = 0; k < R433_PD_MAX_PULSES; ++k) {
+        fsk_pulses->pulse[k] = g_fsk.h_ring[k].x;
+        fsk_pulses->gap[k] = g_fsk.h_ring[k].y;
+    }
+    return 0;
+}

@@ -17,8 +17,9 @@
 // computed here.  A per-call round trip over PCIe makes these slower than the CPU code they replace -- they exist so the
 // seam is complete; the fast path is the batch entry (dropin/r_flow_hip.c).
 //
-// NOT exported: pulse_detect_fsk_classic / _minmax / _wrap_up (include/pulse_detect_fsk.h:46-75): only
-// pulse_detect_package calls them, and here they are part of its device code (csrc/detect_device.hpp).
+//   include/pulse_detect_fsk.h:46-75  pulse_detect_fsk_init / _classic / _minmax / _wrap_up over r433_fsk_step: one sample,
+//                                  one wavefront, one round trip per call (in the reference only pulse_detect_package calls
+//                                  them; exported so that the four headers are complete)
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -44,6 +45,7 @@ typedef struct demodfm_state {
 } demodfm_state_t;
 
 typedef r433_pulse_data pulse_data_t; // include/pulse_data.h:30-50 (sizes asserted in tests/test_abi.py)
+typedef r433_fsk_state pulse_detect_fsk_t; // include/pulse_detect_fsk.h:23-41
 typedef r433_r_device r_device;       // include/r_device.h:59-92
 typedef r433_bitbuffer bitbuffer_t;   // include/bitbuffer.h:34-40
 
@@ -376,6 +378,35 @@ int pulse_slicer_string(const char *code, r_device *device)
     EventHook hook = {__func__};
     on_event(&hook, device, ret, &bits);
     return ret;
+}
+
+
+// ---- include/pulse_detect_fsk.h ----
+
+void pulse_detect_fsk_init(pulse_detect_fsk_t *s) // src/pulse_detect_fsk.c:26-32: constants, nothing to compute
+{
+    memset(s, 0, sizeof(*s));
+    s->var_test_max = INT16_MIN;
+    s->var_test_min = INT16_MAX;
+    s->skip_samples = 40;
+}
+
+void pulse_detect_fsk_classic(pulse_detect_fsk_t *s, int16_t fm_n, pulse_data_t *fsk_pulses)
+{
+    if (r433_fsk_step(R433_FSK_CLASSIC, s, fm_n, fsk_pulses) < 0)
+        die("pulse_detect_fsk_classic");
+}
+
+void pulse_detect_fsk_minmax(pulse_detect_fsk_t *s, int16_t fm_n, pulse_data_t *fsk_pulses)
+{
+    if (r433_fsk_step(R433_FSK_MINMAX, s, fm_n, fsk_pulses) < 0)
+        die("pulse_detect_fsk_minmax");
+}
+
+void pulse_detect_fsk_wrap_up(pulse_detect_fsk_t *s, pulse_data_t *fsk_pulses)
+{
+    if (r433_fsk_step(R433_FSK_WRAP_UP, s, 0, fsk_pulses) < 0)
+        die("pulse_detect_fsk_wrap_up");
 }
 
 } // extern "C"

@@ -290,7 +290,7 @@ __device__ __forceinline__ void ema_groups(v2s &x, int rot, int nb)
 #define R433_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #endif
 template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global__ __launch_bounds__(FORM * 64)
-        R433_WAVES_PER_SIMD(FORM == 1 || SS == 4 ? 2 : 3) void k_wave(StreamParams p) // (cs16: 64-bit filter arithmetic, no room for a third)
+        R433_WAVES_PER_SIMD(FORM == 1 ? 2 : 3) void k_wave(StreamParams p) // (cs16 at 168 VGPRs spills a dozen dwords; at two per SIMD and 208 VGPRs a 64 Mi-sample stream took 10.4 ms against 8.1)
 {
     using G = Geom<SS>;
     __shared__ __attribute__((aligned(16))) uint8_t s_env[64 * kPitch16];

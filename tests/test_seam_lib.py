@@ -301,3 +301,58 @@ def test_pulse_detect_package_against_reference(name, rate, fpdm, frames, backen
         assert 2 in log, log
     S.pulse_detect_free(pa)
     R.pulse_detect_free(pb)
+
+
+class FskState(C.Structure):  # pulse_detect_fsk_t, reference include/pulse_detect_fsk.h:23-41
+    _fields_ = [("fsk_pulse_length", C.c_uint), ("fsk_state", C.c_uint), ("fm_f1_est", C.c_int), ("fm_f2_est", C.c_int),
+                ("var_test_max", C.c_int16), ("var_test_min", C.c_int16), ("maxx", C.c_int16), ("minn", C.c_int16), ("midd", C.c_int16),
+                ("skip_samples", C.c_int)]
+
+
+@pytest.mark.parametrize("which", ["classic", "minmax"])
+def test_pulse_detect_fsk_functions_against_reference(which, backend):
+    """pulse_detect_fsk_init / _classic / _minmax / _wrap_up (include/pulse_detect_fsk.h:46-75) of the seam and of the
+    reference, sample by sample over a discriminator trace with bursts, spurious short stretches and enough toggles to
+    overflow the list (pulse_data_shift): the same pulse_detect_fsk_t and the same pulse list after every call."""
+    from rtl_433_amd import _lib
+    assert C.sizeof(FskState) == 32
+    S, R = seam_lib(backend), ref_lib()
+    for L in (S, R):
+        L.pulse_detect_fsk_init.argtypes = [C.c_void_p]
+        L.pulse_detect_fsk_classic.argtypes = [C.c_void_p, C.c_int16, C.c_void_p]
+        L.pulse_detect_fsk_minmax.argtypes = [C.c_void_p, C.c_int16, C.c_void_p]
+        L.pulse_detect_fsk_wrap_up.argtypes = [C.c_void_p, C.c_void_p]
+        for f in (L.pulse_detect_fsk_init, L.pulse_detect_fsk_classic, L.pulse_detect_fsk_minmax, L.pulse_detect_fsk_wrap_up):
+            f.restype = None
+    rng = np.random.default_rng(11)
+    trace = []
+    level = 9000
+    for k in range(260 if backend == "gpu" else 60):  # toggles: some stretches shorter than 10 samples (spurious)
+        n = int(rng.integers(3, 40))
+        level = -level
+        trace += list((level + rng.integers(-1500, 1500, n)).astype(np.int16))
+    if backend == "gpu":  # enough toggles to fill the 1200-pair list and shift it (src/pulse_data.c:27-34)
+        for k in range(2600):
+            level = -level
+            trace += [int(level)] * 12
+    sa, sb = FskState(), FskState()
+    pa, pb = _lib.PulseData(), _lib.PulseData()
+    S.pulse_detect_fsk_init(C.byref(sa))
+    R.pulse_detect_fsk_init(C.byref(sb))
+
+    def view(s, p):
+        n = p.num_pulses
+        return (s.fsk_pulse_length, s.fsk_state, s.fm_f1_est, s.fm_f2_est, s.var_test_max, s.var_test_min, s.skip_samples,
+                n, p.offset, list(p.pulse[:min(n + 1, 1200)]), list(p.gap[:min(n + 1, 1200)]))
+    assert view(sa, pa) == view(sb, pb)
+    step_s = S.pulse_detect_fsk_classic if which == "classic" else S.pulse_detect_fsk_minmax
+    step_r = R.pulse_detect_fsk_classic if which == "classic" else R.pulse_detect_fsk_minmax
+    for i, v in enumerate(trace):
+        step_s(C.byref(sa), int(v), C.byref(pa))
+        step_r(C.byref(sb), int(v), C.byref(pb))
+        if i % 7 == 0 or i > len(trace) - 50:
+            assert view(sa, pa) == view(sb, pb), i
+    S.pulse_detect_fsk_wrap_up(C.byref(sa), C.byref(pa))
+    R.pulse_detect_fsk_wrap_up(C.byref(sb), C.byref(pb))
+    assert view(sa, pa) == view(sb, pb)
+    assert pb.num_pulses > 10
