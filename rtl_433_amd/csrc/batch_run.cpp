@@ -1,5 +1,7 @@
 // batch_run.cpp -- r433_batch_run / r433_batch_run_pulses: the kernel sequence of one pass of the hot path, stage by
 // stage (input conversion, autolevel, segment planning, detection + stitch, slicer fan-out, host mirrors).
+#include <chrono>
+
 #include "host_common.hpp"
 
 using namespace r433;
@@ -185,8 +187,11 @@ int run_plan_split(RunCtx &r, uint32_t split_samples)
     launch_tile_max(r.env_kind(), r.d_iq, r.stride_bytes, r.d_lens(), (uint32_t)r.stride_bytes, r.n_streams,
             tiles_cap, b->d_tile_max.p, r.st);
     HIP_TRY(hipGetLastError());
+    auto const t_plan = std::chrono::steady_clock::now();
     HIP_TRY(hipMemcpyAsync(b->h_tile_max.p, b->d_tile_max.p, (size_t)r.n_streams * tiles_cap * sizeof(uint32_t), hipMemcpyDeviceToHost, r.st));
     HIP_TRY(stream_wait(b, r.st));
+    if (b->debug_flags & R433_DEBUG_SPLIT_TRACE)
+        fprintf(stderr, "r.split: tile estimate %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_plan).count());
     // A tile is quiet when it carries no more energy than the noise floor: mean envelope at most 1.5x
     // the capture's median tile, or -- for captures that are mostly signal -- below half the
     // falling-edge level of the lowest threshold the detector can have (pulse_detect.c:300-304).
@@ -393,6 +398,7 @@ int run_stitch(RunCtx &r, StreamParams const &sp)
         if (n_have + launch_list.size() > r.n_slots)
             return fail(R433_EHIP, "r.split bookkeeping ran out of slots");
         b->last_redone += (uint32_t)launch_list.size();
+        auto const t_round = std::chrono::steady_clock::now();
         HIP_TRY(hipMemcpyAsync(b->d_segs.p + n_have, launch_list.data(), launch_list.size() * sizeof(SegDesc), hipMemcpyHostToDevice, r.st));
         StreamParams sr = sp;
         sr.n_streams = (uint32_t)launch_list.size();
@@ -410,12 +416,19 @@ int run_stitch(RunCtx &r, StreamParams const &sp)
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(b->h_state.p + n_have, b->d_state.p + n_have, launch_list.size() * sizeof(StreamState), hipMemcpyDeviceToHost, r.st));
         HIP_TRY(stream_wait(b, r.st));
+        if (b->debug_flags & R433_DEBUG_SPLIT_TRACE)
+            fprintf(stderr, "r.split: round over %zu slots %.3f ms\n", launch_list.size(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_round).count());
         n_have += (uint32_t)launch_list.size();
         launch_list.clear();
         return 0;
     };
+    auto const t_first = std::chrono::steady_clock::now();
     HIP_TRY(hipMemcpyAsync(b->h_state.p, b->d_state.p, (size_t)r.n_planned * sizeof(StreamState), hipMemcpyDeviceToHost, r.st));
     HIP_TRY(stream_wait(b, r.st));
+    if (b->debug_flags & R433_DEBUG_SPLIT_TRACE)
+        fprintf(stderr, "r.split: waited %.3f ms for the first launch (%u slots)\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_first).count(), r.n_planned);
     // (1) cuts neither variant could start from (no provable filter carry or floor: digital
     // silence does that) are known now, all at once: merge across them in one extra launch
     for (uint32_t c = 0; c < r.n_streams; ++c) {
