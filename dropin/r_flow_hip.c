@@ -33,8 +33,8 @@
     the capture as far as it has come and replays its newest packages (sync_step below), and the loop quits where the
     reference's does.
 
-    Not served by this flow (reported once, then ignored): S16_AM / S16_FM pseudo-IQ input files; the raw rtl_tcp output's
-    per-frame pacing is kept.  The sample grabber (-S all | unknown | known | undecoded, raw or SigMF) writes its files after
+    S16_AM / S16_FM pseudo-IQ input files are served (the library's R433_IN_S16_AM / R433_IN_S16_FM); the raw rtl_tcp
+    output's per-frame pacing is kept.  The sample grabber (-S all | unknown | known | undecoded, raw or SigMF) writes its files after
     the replay of a pass (write_grabs below).  Every -w / -W dumper is served: the input's own format is a
     copy, the other IQ formats are the library's dump kernel on each frame, am / fm dumps come from the detection pass's
     taps, .u8 is painted by the detection kernel, .ook / .vcd are written during the replay.  (One quirk of the reference
@@ -451,6 +451,13 @@ static uint32_t capture_frame_samples(hip_capture const *c)
     return c->frame_bytes / c->sample_size;
 }
 
+/* am.s16 / fm.s16 input files reach push_sdr_flow as they are (src/rtl_433.c:1735-1739): the library takes their words for
+   the demodulated buffers where the reference's flow copies them there (src/r_flow.c:212-225) */
+static uint32_t capture_input_format(hip_capture const *c)
+{
+    return c->load_info.format == S16_AM ? R433_IN_S16_AM : c->load_info.format == S16_FM ? R433_IN_S16_FM : R433_IN_NATIVE;
+}
+
 static void engine_config(r_cfg_t *cfg, hip_capture const *c, r433_flow_cfg *fc)
 {
     struct dm_state *demod = cfg->demod;
@@ -465,6 +472,7 @@ static void engine_config(r_cfg_t *cfg, hip_capture const *c, r433_flow_cfg *fc)
     fc->min_snr_db       = demod->min_snr;
     fc->auto_level       = demod->auto_level;
     fc->center_frequency = c->center_frequency;
+    fc->input_format     = capture_input_format(c);
 }
 
 static void engine_ensure(r_cfg_t *cfg, r433_flow_cfg const *fc)
@@ -861,7 +869,8 @@ static int same_group(r_cfg_t *cfg, hip_capture const *a, hip_capture const *b)
 {
     (void)cfg;
     return a->sample_size == b->sample_size && a->samp_rate == b->samp_rate && a->fpdm == b->fpdm
-            && a->center_frequency == b->center_frequency && capture_frame_samples(a) == capture_frame_samples(b);
+            && a->center_frequency == b->center_frequency && capture_frame_samples(a) == capture_frame_samples(b)
+            && capture_input_format(a) == capture_input_format(b);
 }
 
 int hip_sdr_flow_drain(struct r_cfg *cfg)
@@ -1064,11 +1073,6 @@ int push_sdr_flow(r_cfg_t *cfg, unsigned char *iq_buf, uint32_t len)
     }
 
     get_time_now(&demod->now);
-
-    if (demod->load_info.format == S16_AM || demod->load_info.format == S16_FM) {
-        print_log(LOG_ERROR, "HIP", "AM / FM sample files are not served by the HIP flow");
-        return -1;
-    }
 
     /* what baseband_demod_FM(_cs16) tells a -vv user when it derives its filter: on the first frame after a reset and on
        every change of the sample rate (src/baseband.c:217-223,310-316; same float arithmetic, same wording) */

@@ -53,11 +53,18 @@ typedef struct r433_flow_cfg {
     uint32_t center_frequency; /* only for reporting (freq fields of calc_rssi_snr) */
     uint32_t input_format;  /* R433_IN_NATIVE, or a file format the reference converts on load (src/rtl_433.c:1811-1834):
                              * R433_IN_CS8 (sample_size 2: int8 pairs -> cu8) / R433_IN_CF32 (sample_size 4: float pairs -> cs16).
-                             * Strides and lengths given to r433_batch_run are then in the input format's bytes. */
+                             * Strides and lengths given to r433_batch_run are then in the input format's bytes.
+                             * R433_IN_S16_AM / R433_IN_S16_FM (sample_size 2): the reference's am.s16 / fm.s16 input files
+                             * (file_info S16_AM / S16_FM).  Their bytes go through the flow as if they were cu8 pairs -- frame
+                             * level, squelch and the other demodulator see exactly that, src/rtl_433.c:1735-1739 -- and the
+                             * int16 words then stand in for the filtered envelope / the filtered discriminator in front of the
+                             * pulse detector (src/r_flow.c:212-225). */
 } r433_flow_cfg;
 #define R433_IN_NATIVE 0u
 #define R433_IN_CS8 1u
 #define R433_IN_CF32 2u
+#define R433_IN_S16_AM 3u
+#define R433_IN_S16_FM 4u
 
 void r433_flow_cfg_default(r433_flow_cfg *cfg, uint32_t sample_size, uint32_t samp_rate);
 

@@ -338,6 +338,11 @@ class Ref:
     def set_enable_fm(self, on):
         self.L.refh_set_enable_fm(self.h, int(on))
 
+    def set_load_format(self, fmt):
+        """0: cu8 / cs16 by sample size; 1: am.s16, 2: fm.s16 input files (sample_size 2)"""
+        self.L.refh_set_load_format.argtypes = [C.c_void_p, C.c_int]
+        self.L.refh_set_load_format(self.h, int(fmt))
+
     def run(self, iq, sample_size=2, samp_rate=250000, center_freq=433920000, fpdm=2, stream_index=0, taps=False):
         iq = np.ascontiguousarray(iq)
         n = iq.nbytes // sample_size

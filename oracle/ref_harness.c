@@ -82,6 +82,7 @@ typedef struct harness {
     uint64_t digest;
     uint32_t digest_events;
     int16_t *tap_am, *tap_fm;
+    int load_format; /* 0: what the sample size says; 1 / 2: am.s16 / fm.s16 input files (file_info S16_AM / S16_FM) */
     size_t tap_pos;
     uint32_t *frame_sums;
     float *frame_db;
@@ -406,6 +407,13 @@ void refh_set_levels(void *hv, int use_mag_est, float level_limit, float min_lev
     pulse_detect_set_levels(dm->pulse_detect, dm->use_mag_est, dm->level_limit, dm->min_level, dm->min_snr, dm->detect_verbosity);
 }
 
+/* the next captures are am.s16 (1) / fm.s16 (2) files: src/rtl_433.c:1735-1739 reads them as 2-byte samples and
+ * src/r_flow.c:212-225 puts their words in place of the demodulated buffers */
+void refh_set_load_format(void *hv, int fmt)
+{
+    ((harness *)hv)->load_format = fmt;
+}
+
 void refh_set_enable_fm(void *hv, int on)
 {
     ((harness *)hv)->cfg->demod->enable_FM_demod = on;
@@ -428,7 +436,7 @@ int refh_run_capture(void *hv, uint8_t const *iq, size_t n_bytes, uint32_t sampl
     cfg->samp_rate = samp_rate;
     cfg->center_frequency = center_freq;
     dm->sample_size = (int)sample_size;
-    dm->load_info.format = sample_size == 2 ? CU8_IQ : CS16_IQ;
+    dm->load_info.format = h->load_format == 1 ? S16_AM : h->load_format == 2 ? S16_FM : sample_size == 2 ? CU8_IQ : CS16_IQ;
     dm->sample_file_pos = 0.0f;
 
     unsigned mode = (unsigned)fpdm;

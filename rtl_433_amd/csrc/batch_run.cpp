@@ -46,8 +46,8 @@ struct RunCtx {
 int run_convert_input(RunCtx &r)
 {
     r433_batch *const b = r.b;
-    if (b->cfg.input_format == R433_IN_NATIVE)
-        return 0;
+    if (b->cfg.input_format == R433_IN_NATIVE || b->cfg.input_format == R433_IN_S16_AM || b->cfg.input_format == R433_IN_S16_FM)
+        return 0; // (am.s16 / fm.s16 words go through the flow as if they were cu8 pairs, src/rtl_433.c:1735-1739)
     // The reference converts these formats while it loads a file (src/rtl_433.c:1811-1834): one HBM-bound
     // map into an internal buffer, then everything below sees cu8 / cs16 like the reference's flow does.
     uint32_t const shrink = b->cfg.input_format == R433_IN_CF32 ? 2 : 1; // 8 B -> 4 B per sample
@@ -271,6 +271,8 @@ int run_plan(RunCtx &r)
     // again across a cut that did not verify is one wavefront's serial time, so short pieces keep the later rounds short;
     // 64 Mi-sample cs16 FSK stream 20.0 -> 15.5 ms, 256 Mi-sample 2 MS/s stream 27.0 -> 22.5 ms against 32 Ki / 4096).
     uint32_t split_samples = b->logic_on ? 0u : b->split_samples; // the logic dump is painted by whole-capture wavefronts
+    if (b->cfg.input_format == R433_IN_S16_AM || b->cfg.input_format == R433_IN_S16_FM)
+        split_samples = 0; // where a cut may go is read off the IQ envelope, which these files do not have
     if (split_samples == R433_SPLIT_AUTO) {
         uint64_t total = 0;
         for (uint32_t c = 0; c < r.n_streams; ++c)
@@ -305,7 +307,7 @@ StreamParams stream_params(RunCtx const &r)
     sp.uniform_bytes = (uint32_t)r.stride_bytes;
     sp.n_streams = r.n_planned;
     sp.frame_samples = b->cfg.frame_samples;
-    sp.flags = 0;
+    sp.flags = b->cfg.input_format == R433_IN_S16_AM ? RUN_AM_IS_INPUT : b->cfg.input_format == R433_IN_S16_FM ? RUN_FM_IS_INPUT : 0u;
     sp.flags |= b->debug_flags & (RUN_DBG_SKIP_DETECT | RUN_DBG_SKIP_FILTERS | RUN_DBG_TIMING | RUN_NO_TRAIN_ENGINE | RUN_ONE_WAVE | RUN_NO_ROLE_SWAP | RUN_NO_PRIO | RUN_PAIR); // r433_batch_set_debug
     sp.det = b->det;
     sp.use_mag = (int)b->cfg.use_mag_est;

@@ -160,8 +160,9 @@ r433_batch *r433_batch_create(r433_flow_cfg const *cfg, r433_dev_timing const *d
         return nullptr;
     }
     if ((cfg->input_format == R433_IN_CS8 && cfg->sample_size != 2) || (cfg->input_format == R433_IN_CF32 && cfg->sample_size != 4)
-            || cfg->input_format > R433_IN_CF32) {
-        fail(R433_EINVAL, "input_format: cs8 goes with sample_size 2, cf32 with sample_size 4");
+            || ((cfg->input_format == R433_IN_S16_AM || cfg->input_format == R433_IN_S16_FM) && cfg->sample_size != 2)
+            || cfg->input_format > R433_IN_S16_FM) {
+        fail(R433_EINVAL, "input_format: cs8, am.s16 and fm.s16 go with sample_size 2, cf32 with sample_size 4");
         return nullptr;
     }
     if (r433_device_count() < 0)

@@ -62,6 +62,8 @@ enum : uint32_t {
     RUN_NOFLUSH = 2u,  // do not issue the end-of-input flush call
     RUN_ENV_RAW16 = 4u, // filters-only launches: the input is a u16 envelope (2 B/sample), not IQ (baseband_low_pass_filter's x_buf)
     // profiling aids (env R433_DEBUG_FLAGS, never set by the product path): stop after a phase
+    RUN_AM_IS_INPUT = 65536u,  // cu8 launches: the capture's 16-bit words ARE the AM samples (am.s16 files, src/r_flow.c:213-217)
+    RUN_FM_IS_INPUT = 131072u, // ... the FM samples (fm.s16 files, src/r_flow.c:218-224)
     RUN_DBG_SKIP_DETECT = 256u,
     RUN_DBG_SKIP_FILTERS = 512u,
     RUN_DBG_TIMING = 1024u, // per-phase shader-clock ticks into unused StreamState slots (r433_batch_debug_state)

@@ -303,7 +303,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
     // (the tile buffers are dynamic LDS: two of each for a pair, one for a single wavefront -- 8 KB that decide whether
     // five or eight single-wavefront workgroups fit a CU)
 #ifdef R433_EMU
-    __shared__ __attribute__((aligned(16))) uint8_t s_tiles[4 * 64 * kPitchOut];
+    __shared__ __attribute__((aligned(16))) uint8_t s_tiles[4 * 64 * kPitchOut + 64 * kPitch16];
 #else
     extern __shared__ __attribute__((aligned(16))) uint8_t s_tiles[];
 #endif
@@ -320,6 +320,9 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
     int const wave = (int)threadIdx.x >> 6;
     constexpr bool solo = FORM == 1; // one wavefront does both halves
     uint8_t *const s_am = s_tiles, *const s_fm = s_tiles + (solo ? 1 : 2) * (64 * kPitchOut);
+    // am.s16 / fm.s16 input files (RUN_AM_IS_INPUT / RUN_FM_IS_INPUT; the launch adds the room): the tile's words as they came
+    uint8_t *const s_raw = s_tiles + (solo ? 2 : 4) * (64 * kPitchOut);
+    bool const raw_in = SS == 2 && !SEAM && (p.flags & (RUN_AM_IS_INPUT | RUN_FM_IS_INPUT)) != 0;
     // role 0 produces, role 1 consumes.  Workgroups alternate which wavefront takes which role, so that the two wavefronts
     // that end up on one SIMD are one of each kind, and the consumer -- the serial critical path -- issues first.
     int const role = solo ? 0 : FORM == 3 ? (wave + (int)(blockIdx.x % 3u)) % 3
@@ -541,6 +544,8 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
             int const sub = lane & 3; // 8-sample group inside the chunk
             *(uint4 *)(s_env + chunk * kPitch16 + sub * 16) = make_uint4(ev[0] | (ev[1] << 16), ev[2] | (ev[3] << 16),
                     ev[4] | (ev[5] << 16), ev[6] | (ev[7] << 16));
+            if (SS == 2 && raw_in)
+                *(uint4 *)(s_raw + chunk * kPitch16 + sub * 16) = pf[SS == 2 ? r : 0];
             if (SS == 2) {
                 *(uint4 *)(s_f + chunk * G::f_pitch + sub * 16) = make_uint4(((uint32_t)fv[0] & 0xffffu) | ((uint32_t)fv[1] << 16),
                         ((uint32_t)fv[2] & 0xffffu) | ((uint32_t)fv[3] << 16), ((uint32_t)fv[4] & 0xffffu) | ((uint32_t)fv[5] << 16),
@@ -849,6 +854,28 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
             }
         }
 
+        if (raw_in) {
+            // "The IQ buffer is really AM (FM) demodulated data" (src/r_flow.c:212-225): everything above ran on the file's
+            // bytes taken as cu8 pairs -- the frame level and the squelch see that envelope, like the reference's do -- and
+            // then the file's int16 words replace the filtered envelope (am.s16) or the filtered discriminator (fm.s16).
+            bool const am_in = (p.flags & RUN_AM_IS_INPUT) != 0;
+            uint8_t *const dst = (am_in ? p_am : p_fm) + lane * kPitchOut;
+            if (am_in)
+                cmax = -0x7fffffff, cmin = 0x7fffffff;
+#pragma unroll 1
+            for (int g = 0; g < kChunk / 8; ++g) {
+                uint4 const w = *(uint4 const *)(s_raw + lane * kPitch16 + g * 16);
+                *(uint4 *)(dst + g * 16) = w;
+                uint32_t const ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    int const v = (int)(int16_t)((ww[u >> 1] >> ((u & 1) * 16)) & 0xffffu);
+                    bool const in = am_in && g * 8 + u < cnt;
+                    cmax = in ? max(cmax, v) : cmax;
+                    cmin = in ? min(cmin, v) : cmin;
+                }
+            }
+        }
         // carries for the next tile (only meaningful when this tile is full)
         carry_ya = __builtin_amdgcn_readlane(sa.y_end, 63);
         carry_yf = __builtin_amdgcn_readlane(sf.y_end, 63);
@@ -2059,7 +2086,8 @@ void launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st)
     // split captures come with their workgroup list: a producer and (where a piece has both parity variants) two consumers
     bool const triple = p.wg_slot != nullptr && !(p.flags & RUN_ONE_WAVE);
     dim3 grid(p.wg_slot ? p.n_wgs : p.n_streams), block(triple ? 192 : pair ? 128 : 64);
-    uint32_t const lds = (pair || triple ? 4u : 2u) * 64u * (uint32_t)kPitchOut; // the tile buffers (s_tiles)
+    uint32_t const lds = (pair || triple ? 4u : 2u) * 64u * (uint32_t)kPitchOut // the tile buffers (s_tiles)
+            + ((p.flags & (RUN_AM_IS_INPUT | RUN_FM_IS_INPUT)) ? 64u * (uint32_t)kPitch16 : 0u); // + s_raw
     // FAST: no filter step can wrap and both feedback coefficients are non-negative (see Track16).
     // The AM filter always qualifies (13993 + 2*1195 <= 16384); the FM filter does for every cutoff
     // up to half the Nyquist rate, which includes the defaults.

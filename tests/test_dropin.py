@@ -361,6 +361,35 @@ def test_every_sample_dumper(binary, tmp_path):
 
 
 @pytest.mark.parametrize("binary", [pytest.param(EMU, id="emu"), pytest.param(HIP, id="hip", marks=pytest.mark.gpu)])
+def test_am_fm_sample_files_as_input(binary, tmp_path):
+    """-r x.am.s16 / -r x.fm.s16 (file_info S16_AM / S16_FM, src/r_flow.c:212-225): the stock binary writes the dumps, then both
+    binaries read them back in a list that also holds the cu8 captures they came from; events, levels and the dumps written
+    from such input equal the stock binary's."""
+    _ensure_built(binary)
+    shutil.copy(os.path.join(GOLD, "nice_250k.cu8"), tmp_path / "g001_433.92M_250k.cu8")
+    names = write_ook_files(tmp_path, [21, 22])
+    synth.fsk_stream_cu8(5, 40000, n_bursts=2, nbits=100).tofile(tmp_path / "f_433.92M_250k.cu8")
+    made = []
+    for src in ["g001_433.92M_250k.cu8", names[0], "f_433.92M_250k.cu8"]:
+        stem = src[:-4]
+        run_cli(REF, ["-r", src, "-W", stem + ".am.s16", "-W", stem + ".fm.s16"], tmp_path)
+        made += [stem + ".am.s16", stem + ".fm.s16"]
+        assert (tmp_path / made[-2]).stat().st_size > 0 and (tmp_path / made[-1]).stat().st_size > 0
+    order = [made[0], "g001_433.92M_250k.cu8", made[2], made[3], names[1], made[5], made[4], made[1]]
+    got = {}
+    for who, b in (("ref", REF), ("new", binary)):
+        d = tmp_path / who
+        d.mkdir()
+        args = sum((["-r", "../" + f] for f in order), []) + FLEX + ["-X", "n=fmc,m=FSK_MC_ZEROBIT,s=50,l=50,r=1200", "-F", "json",
+                "-M", "level", "-M", "bits", "-K", "FILE", "-W", "again.am.s16", "-W", "again.fm.s16"]
+        got[who] = (run_cli(b, args, d), (d / "again.am.s16").read_bytes(), (d / "again.fm.s16").read_bytes())
+    assert got["ref"][0].count("\n") >= 4 and "am.s16" in got["ref"][0]
+    assert got["new"][0] == got["ref"][0]
+    assert got["new"][1] == got["ref"][1] and len(got["ref"][1]) > 0
+    assert got["new"][2] == got["ref"][2]
+
+
+@pytest.mark.parametrize("binary", [pytest.param(EMU, id="emu"), pytest.param(HIP, id="hip", marks=pytest.mark.gpu)])
 def test_sample_grabber(binary, tmp_path):
     """-S all | unknown | known | undecoded and the SigMF variant over a list of files: the same g###_<freq>M_<rate>k files with the same
     bytes (the first grab reaches back across a file boundary: the ring's history), the same messages; also with one GPU pass

@@ -245,3 +245,12 @@ def test_input_formats_cs8_cf32(default_devices):
     n = want16.size // 2
     assert np.array_equal(g["taps"][0][0, :n], o["env"])
     assert g["packages"][0] == pk and g["events"][0] == ev
+
+
+def test_am_s16_fm_s16_input_files():
+    """am.s16 / fm.s16 pseudo-IQ input (R433_IN_S16_AM / R433_IN_S16_FM) against the unmodified reference, on the emulator."""
+    if not po.have_ref():
+        pytest.skip("oracle/_ref/libr433ref.so not present")
+    from tests.emu import host
+    from tests import s16_input_case
+    s16_input_case.check(lambda iq, devs, fmt, fm: host.emu_run(iq, 2, 250000, devs, fpdm=0, taps=True, enable_fm=fm, input_format=fmt))

@@ -284,3 +284,11 @@ def test_full_size_config2_vs_reference(default_devices):
     assert nev == nev_ref and nev > 1000000
     # the reference calls its decoders priority level by priority level; the records are (package, device, ordinal)
     assert po.events_normalize(ev) == po.events_normalize(po.canonical_events(ev_ref))
+
+
+def test_am_s16_fm_s16_input_files():
+    """am.s16 / fm.s16 pseudo-IQ input (R433_IN_S16_AM / R433_IN_S16_FM) against the unmodified reference."""
+    if not po.have_ref():
+        pytest.skip("oracle/_ref/libr433ref.so not present")
+    from tests import s16_input_case
+    s16_input_case.check(lambda iq, devs, fmt, fm: _gpu_run(iq, 2, 250000, 433920000, devs, taps=True, enable_fm=fm, input_format=fmt))
