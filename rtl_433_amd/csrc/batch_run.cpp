@@ -215,20 +215,43 @@ int run_plan_split(RunCtx &r, uint32_t split_samples)
             std::nth_element(med.begin(), med.begin() + med.size() / 2, med.end());
             quiet_below = std::max<uint64_t>(abs_quiet, (uint64_t)med[med.size() / 2] * 3 / 2);
         }
-        r.quiet_below[c] = quiet_below;
+        r.quiet_below[c] = quiet_below; // (what a workgroup's cost is estimated with, plan_workgroups)
+        // For the cuts the floor is taken locally: 1.5x the quietest tile among the ~190 around (blocks of 64 tiles, the
+        // tile's own and its two neighbours).  The median of the whole capture sits on a half-loud tile when about half of
+        // the capture is signal (config 3: bursts 47 % of the time), and calls everything quiet then; a floor that steps
+        // (config 5) makes any capture-wide quantile wrong for part of the capture.
+        uint32_t const n_whole = n / kTileS;
+        std::vector<uint32_t> block_min((n_whole + 63) / 64 + 1, 0xffffffffu);
+        for (uint32_t t = 0; t < n_whole; ++t)
+            block_min[t / 64] = std::min(block_min[t / 64], tm[t]);
+        auto quiet_at = [&](uint32_t t) {
+            uint32_t const bk = t / 64;
+            uint32_t lo = std::min(block_min[bk], block_min[bk + 1]);
+            if (bk > 0)
+                lo = std::min(lo, block_min[bk - 1]);
+            return tm[t] < std::max<uint64_t>(abs_quiet, (uint64_t)lo * 3 / 2);
+        };
         std::vector<uint32_t> cuts;
         uint32_t pos = seg_len;
         while (n > seg_len && pos + seg_len / 2 < n) {
-            uint32_t cut = 0;
+            // The tile sums are taken from a subsample (eight lines of a tile, k_tile_max): a burst that starts behind the
+            // last line of the tile in front of the cut goes unseen there, and that tile is the one the new piece
+            // establishes its filter carries and its floor on.  A cut whose own first tile is quiet too cannot have that
+            // (anything longer than the space between two lines shows in the next tile's first line): such cuts first.
+            uint32_t cut = 0, second_best = 0;
             for (uint32_t P = pos; P < std::min(n, pos + seg_len) && P + kTileS <= n; P += kTileS) {
                 bool quiet = P / kTileS >= quiet_tiles;
                 for (uint32_t q = 1; quiet && q <= quiet_tiles; ++q)
-                    quiet = tm[P / kTileS - q] < quiet_below;
-                if (blind || quiet) {
+                    quiet = quiet_at(P / kTileS - q);
+                if (blind || (quiet && quiet_at(P / kTileS))) {
                     cut = P;
                     break;
                 }
+                if (quiet && !second_best)
+                    second_best = P;
             }
+            if (!cut)
+                cut = second_best;
             if (cut) {
                 cuts.push_back(cut);
                 pos = cut + seg_len;

@@ -53,7 +53,7 @@ constexpr int kRow = 512;           // samples per phase-A row (8 per lane)
 constexpr int kRows = kTile / kRow;
 constexpr int kPitch16 = kChunk * 2 + 16;  // LDS pitch of a chunk of 16-bit samples: conflict-free b128 per lane
 constexpr int kPitch32 = kChunk * 4 + 16;
-constexpr int kFloorWindow = 512;           // samples a later segment of a split capture walks to find its noise floor
+constexpr int kFloorWindow = 1024;          // samples a later segment of a split capture walks to find its noise floor
 constexpr int kPitchOut = kChunk * 2;       // filtered samples: time-linear, read by sample index (the padded pitch buys
                                              // nothing there and 8 wavefronts' LDS must fit one CU: 8 x 20 KB = 160 KB)
 
@@ -723,8 +723,8 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
         }
         if (warm) {
             // An establishing tile is wanted for two things only: proven carries at its end and proven samples in its last
-            // sixteen chunks (the floor walk).  Its first lanes have no history: take what the tracks say, proven or not, and
-            // never wait for it.  The same goes for any lane before those sixteen chunks whose warm-up did not collapse (two
+            // thirty-two chunks (the floor walk).  Its first lanes have no history: take what the tracks say, proven or not, and
+            // never wait for it.  The same goes for any lane before those thirty-two chunks whose warm-up did not collapse (two
             // AM tracks one apart stay apart with probability 0.854 per step: 1-2 % of the lanes): its left neighbour may be
             // one of the unproven first lanes, then nobody could ever settle it and the whole cut would be given up.
             bool const early = lane < 64 - kFloorWindow / kChunk;
@@ -888,7 +888,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
 
         if (warm) {
             // ---- establishing tile of a later segment: no detection here.  The carries just taken must be
-            // proven, and so must the last sixteen chunks (the floor is walked over their samples).
+            // proven, and so must the last thirty-two chunks (the floor is walked over their samples).
             bool const tail_ok = lane < 64 - kFloorWindow / kChunk || (sa.start_known && sa.end_known && sf.start_known && sf.end_known);
             if (__ballot(!tail_ok))
                 p_fail |= 16;
@@ -940,7 +940,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
         if (warm) {
             if (st_pflag(buf)) // (bits: 1 the filters -- 8 a carry that cannot be proven inside the tile, 16 an unproven chunk among
                 seg_fail |= 1 | st_pflag(buf); // those the floor is walked over --, 2 floor range too wide, 4 the walks did not meet)
-            // Noise floor at the segment's first sample: the detector is assumed idle over the last 512
+            // Noise floor at the segment's first sample: the detector is assumed idle over the last 1024
             // samples with a floor of the assumed parity somewhere inside the tile's sample range; both
             // extremes of that parity are walked and must meet (see the lazy floor below).
             int rmax = lane >= 4 ? st_cmax(buf, lane) : -0x7fffffff, rmin = lane >= 4 ? st_cmin(buf, lane) : 0x7fffffff;
@@ -954,7 +954,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                 seg_fail |= 2; // steps of more than one are possible: not the regime the cut assumes
             a += (a ^ par) & 1;
             b -= (b ^ par) & 1;
-            for (int w = kTile - kFloorWindow; w < kTile; w += 64) { // chunks 48..63: proven above
+            for (int w = kTile - kFloorWindow; w < kTile; w += 64) { // chunks 32..63: proven above
                 int const v = ld16(c_am, w + lane);
 #pragma unroll 8
                 for (int u = 0; u < 64; ++u) {
@@ -966,7 +966,11 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
             if (a != b)
                 seg_fail |= 4;
             det.low = a;
-            det.high = max(cfg.ratio * a, cfg.min_high);
+            // (the high estimate a sample meets was made on the sample before it, pulse_detect.c:265-268,300-304: under -Y autolevel
+            // a piece that starts on a frame boundary inherits the level of the frame before)
+            int const min_high_before = p.frame_min_high ? p.frame_min_high[(uint64_t)cap * p.frames_cap + min((seg_start - 1u) / F, p.frames_cap - 1)]
+                                                         : cfg.min_high;
+            det.high = max(cfg.ratio * a, min_high_before);
             seg_init_low = a;
             seg_init_high = det.high;
             return;
