@@ -2,6 +2,8 @@
 // account_event (src/r_api.c:438-550, src/pulse_slicer.c:26-66), single- and multi-threaded, and the checksum plugin.
 #include "host_common.hpp"
 
+#include <chrono>
+
 using namespace r433;
 
 namespace {
@@ -380,29 +382,67 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
         n_threads = 1;
     uint8_t const *ev = b->h_events.p;
     uint8_t const *pk = b->h_pkg_blob.p;
+    bool const trace = (b->debug_flags & R433_DEBUG_DISPATCH_TRACE) != 0;
+    auto const t_begin = std::chrono::steady_clock::now();
+    auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+    std::vector<double> dev_ms(trace ? n_devices : 0, 0.0);
 
-    // index: the events of every device, in package order (the stream is sorted by package, device, ordinal)
-    std::vector<uint32_t> dev_count(n_devices + 1, 0);
-    size_t at = 0;
+    // index: the events of every device, in package order (the stream is sorted by package, device, ordinal).  Built by
+    // the pool over package ranges of about equal bytes (h_pkg_off delimits a package's events): every thread counts its
+    // range per device, the counts are laid out device-major / range-minor, every thread fills its own slices.
     size_t const end = b->evt_bytes;
-    while (at + sizeof(r433_evt_rec) <= end) {
-        r433_evt_rec eh;
-        memcpy(&eh, ev + at, sizeof(eh));
-        if (eh.dev >= n_devices || eh.pkg >= np || eh.total_bytes < sizeof(eh) || at + eh.total_bytes > end)
-            return fail(R433_EHIP, "corrupt event stream at byte %zu", at);
-        dev_count[eh.dev + 1]++;
-        at += eh.total_bytes;
+    uint32_t const *pkg_off = b->h_pkg_off.p;
+    unsigned const n_parts = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<uint32_t>(n_threads, 64), end / (256u << 10)));
+    std::vector<uint32_t> part_first(n_parts + 1, np);
+    part_first[0] = 0;
+    for (unsigned t = 1; t < n_parts; ++t) // the first package at or behind byte t / n_parts of the stream
+        part_first[t] = (uint32_t)(std::lower_bound(pkg_off, pkg_off + np, (uint32_t)(end / n_parts * t)) - pkg_off);
+    std::vector<uint32_t> part_count((size_t)n_parts * n_devices, 0);
+    std::atomic<size_t> corrupt_at{SIZE_MAX};
+    if (np && pkg_off[0] != 0)
+        corrupt_at.store(0);
+    auto walk = [&](unsigned t, auto &&visit) {
+        size_t at = part_first[t] < np ? pkg_off[part_first[t]] : end;
+        size_t const stop = part_first[t + 1] < np ? pkg_off[part_first[t + 1]] : end;
+        while (at < stop) {
+            r433_evt_rec eh;
+            if (at + sizeof(eh) > stop) {
+                corrupt_at.store(at);
+                return;
+            }
+            memcpy(&eh, ev + at, sizeof(eh));
+            if (eh.dev >= n_devices || eh.pkg >= np || eh.total_bytes < sizeof(eh) || at + eh.total_bytes > stop) {
+                corrupt_at.store(at);
+                return;
+            }
+            visit(eh, at);
+            at += eh.total_bytes;
+        }
+    };
+    b->pool.run(n_parts, [&](unsigned t) {
+        uint32_t *mine = part_count.data() + (size_t)t * n_devices;
+        walk(t, [&](r433_evt_rec const &eh, size_t) { mine[eh.dev]++; });
+    });
+    if (corrupt_at.load() != SIZE_MAX || (np == 0 && end != 0))
+        return fail(R433_EHIP, "corrupt event stream at byte %zu", corrupt_at.load() == SIZE_MAX ? (size_t)0 : corrupt_at.load());
+    std::vector<uint32_t> dev_count(n_devices + 1, 0);
+    {
+        uint32_t run = 0;
+        for (uint32_t d = 0; d < n_devices; ++d) {
+            dev_count[d] = run;
+            for (unsigned t = 0; t < n_parts; ++t) {
+                uint32_t const c = part_count[(size_t)t * n_devices + d];
+                part_count[(size_t)t * n_devices + d] = run; // from a count to the slice's first slot
+                run += c;
+            }
+        }
+        dev_count[n_devices] = run;
     }
-    for (uint32_t d = 0; d < n_devices; ++d)
-        dev_count[d + 1] += dev_count[d];
-    std::vector<uint32_t> dev_fill(dev_count.begin(), dev_count.end() - 1);
     std::vector<uint32_t> ev_off(dev_count[n_devices]);
-    for (at = 0; at + sizeof(r433_evt_rec) <= end;) {
-        r433_evt_rec eh;
-        memcpy(&eh, ev + at, sizeof(eh));
-        ev_off[dev_fill[eh.dev]++] = (uint32_t)at;
-        at += eh.total_bytes;
-    }
+    b->pool.run(n_parts, [&](unsigned t) {
+        uint32_t *fill = part_count.data() + (size_t)t * n_devices;
+        walk(t, [&](r433_evt_rec const &eh, size_t at) { ev_off[fill[eh.dev]++] = (uint32_t)at; });
+    });
     std::vector<uint32_t> pkg_stream(np), pkg_type(np), pkg_start_ago(np);
     std::vector<uint8_t> skipped(np, 0); // hooks->package_filter said no: no decoder sees the package, no hook is called for it
     for (uint32_t p = 0; p < np; ++p) {
@@ -438,7 +478,10 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
     std::string err;
     std::mutex err_m;
 
+    if (trace)
+        fprintf(stderr, "r.dispatch: index of %u records over %u packages %.3f ms\n", dev_count[n_devices], np, since(t_begin));
     for (uint32_t li = 0; li < b->prio_levels.size() && !failed.load(); ++li) {
+        auto const t_level = std::chrono::steady_clock::now();
         uint32_t const level = b->prio_levels[li];
         std::vector<uint32_t> devs_of_level;
         for (uint32_t d = 0; d < n_devices; ++d)
@@ -464,6 +507,7 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
                     break;
                 uint32_t const dev = devs_of_level[k];
                 r433_r_device *rd = devices[dev];
+                auto const t_dev = std::chrono::steady_clock::now();
                 unsigned n_ev = 0, n_ok = 0, n_msg = 0, fails[5] = {0, 0, 0, 0, 0};
                 for (uint32_t e = dev_count[dev]; e < dev_count[dev + 1]; ++e) {
                     uint8_t const *rec = ev + ev_off[e];
@@ -506,6 +550,8 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
                     memset(bits->bb, 0, (size_t)used_rows * R433_BITBUF_COLS);
                     memset(bits, 0, offsetof(r433_bitbuffer, bb));
                 }
+                if (trace)
+                    dev_ms[dev] = since(t_dev);
                 if (rd) { // this thread is the only one that touches this decoder
                     rd->decode_events += n_ev;
                     rd->decode_ok += n_ok;
@@ -518,7 +564,22 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
             digest_publish();
             free(bits);
         });
+        if (trace)
+            fprintf(stderr, "r.dispatch: level %u, %zu decoders on %u threads %.3f ms\n", level, devs_of_level.size(), nt, since(t_level));
     }
+    if (trace) {
+        std::vector<uint32_t> by(n_devices);
+        double sum = 0;
+        for (uint32_t d = 0; d < n_devices; ++d)
+            by[d] = d, sum += dev_ms[d];
+        std::sort(by.begin(), by.end(), [&](uint32_t x, uint32_t y) { return dev_ms[x] > dev_ms[y]; });
+        fprintf(stderr, "r.dispatch: decoder time in all %.3f ms; slowest:", sum);
+        for (uint32_t k = 0; k < std::min<uint32_t>(8, n_devices); ++k)
+            fprintf(stderr, " %s %.3f ms / %u calls;", devices[by[k]] && devices[by[k]]->name ? devices[by[k]]->name : "?", dev_ms[by[k]],
+                    dev_count[by[k] + 1] - dev_count[by[k]]);
+        fprintf(stderr, "\n");
+    }
+    auto const t_commit = std::chrono::steady_clock::now();
     for (uint32_t d = 0; d < n_devices; ++d) {
         if (!devices[d])
             continue;
@@ -590,6 +651,8 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
             hooks->package_end(hooks->user, &ph, pe);
     }
     free(pd);
+    if (trace)
+        fprintf(stderr, "r.dispatch: commit %.3f ms, whole replay %.3f ms\n", since(t_commit), since(t_begin));
     if (failed.load())
         return fail(R433_EDECODER, "%s", err.c_str());
     apply_prefilter_counts(b, devices, n_devices);
