@@ -115,6 +115,7 @@ static struct {
     unsigned long eng_clock;
     uint8_t *stage; /* pinned */
     size_t stage_cap, stage_len;
+    size_t staged_total; /* bytes of samples this process has taken so far (engine_prefilter) */
     hip_capture *caps;
     size_t n_caps, caps_cap;
     int open; /* the last capture is still being pushed to */
@@ -538,7 +539,12 @@ static void engine_prefilter(r_cfg_t *cfg)
 {
     struct dm_state *demod = cfg->demod;
     char const *env        = getenv("RTL433_HIP_PREFILTER");
-    int const want         = !(env && env[0] == '0') && !H.sync_active && replay_threads() > 1 && !replay_is_chatty(demod) && demod->r_devs.len;
+    /* Asking every decoder costs 0.1-0.2 s once per process; what it saves is ~40 % of the record copy and of the replay's
+       calls.  Measured with the CLI on the MI355X box (tools/cli_bench.sh): 1024 captures of 128 KiB 0.31 s without / 0.47 s
+       with, 8192 captures 1.49 s without / 1.26 s with.  So: from half a GiB of samples on, or when told to
+       (RTL433_HIP_PREFILTER=1; =0: never). */
+    int const worth        = (env && env[0] == '1') || H.staged_total >= ((size_t)1 << 29);
+    int const want         = !(env && env[0] == '0') && worth && !H.sync_active && replay_threads() > 1 && !replay_is_chatty(demod) && demod->r_devs.len;
     if (want && !H.cur->probed) {
         H.cur->probed = 1;
         int const t   = r433_batch_probe_prefilter(H.eng, (r433_r_device *const *)demod->r_devs.elems, (uint32_t)demod->r_devs.len);
@@ -1115,6 +1121,7 @@ int push_sdr_flow(r_cfg_t *cfg, unsigned char *iq_buf, uint32_t len)
     stage_reserve(c->offset + c->bytes + len + 16);
     memcpy(H.stage + c->offset + c->bytes, iq_buf, len);
     c->bytes += len;
+    H.staged_total += len;
     H.stage_len = c->offset + c->bytes;
 
     /* sample dumpers: the input's own format is a plain copy (src/r_flow.c:396,403); the package dumpers

@@ -67,7 +67,7 @@ def test_emu_corpus_subset(tmp_path):
         pytest.skip("wave emulator needs x86-64")
     _ensure_built(EMU)
     names = ["rubicson", "nexus", "secplus_v1", "generic_remote", "oregon_v1", "wt450", "ambient_f007th", "efergy_e2", "bresser_3ch"]
-    ref, seen = check_corpus(EMU, tmp_path, len(names), 9, names=names)
+    ref, seen = check_corpus(EMU, tmp_path, len(names), 9, {"RTL433_HIP_PREFILTER": "1"}, names=names)
     assert "Rubicson-Temperature" in seen and "Nexus-TH" in seen and "Secplus-v1" in seen
     # the Rubicson file decoded at priority 0, so Nexus (priority 10) never saw it; the Nexus file has no Rubicson event
     lines = [json.loads(x) for x in ref.splitlines() if x.startswith('{"tag"') or '"model"' in x]
@@ -84,7 +84,7 @@ def test_emu_corpus_subset(tmp_path):
 def test_hip_corpus_256_files(tmp_path):
     """256 files, 22 protocols, nine modulations through rtl_433_hip (device-side pre-filter on) and the stock binary"""
     _ensure_built(HIP)
-    ref, seen = check_corpus(HIP, tmp_path, 256, 20)
+    ref, seen = check_corpus(HIP, tmp_path, 256, 20, {"RTL433_HIP_PREFILTER": "1"})  # (by itself the CLI asks only from half a GiB of samples on)
     assert "Secplus-v1" in seen and "Rubicson-Temperature" in seen and "Nexus-TH" in seen
     assert '"mod" : "FSK"' in ref and '"mod" : "ASK"' in ref
 
