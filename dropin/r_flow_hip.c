@@ -49,6 +49,7 @@
 #include <string.h>
 #include <math.h>
 #include <unistd.h>
+#include <time.h>
 
 #include "r_flow.h"
 #include "rtl_433.h"
@@ -183,25 +184,55 @@ static int replay_threads(void)
     return n < 1 ? 1 : n > 16 ? 16 : (int)n;
 }
 
+/* RTL433_HIP_TRACE=1: where a pass spends its time, on stderr */
+static double trace_now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+static int trace_on(void)
+{
+    static int on = -1;
+    if (on < 0) {
+        char const *e = getenv("RTL433_HIP_TRACE");
+        on            = e && *e && *e != '0';
+    }
+    return on;
+}
+
 static void hip_fatal(char const *what)
 {
     print_logf(LOG_FATAL, "HIP", "%s: %s", what, r433_last_error());
     exit(1);
 }
 
+/* a pass is run when this much has been queued (1920 captures of 128 KiB): large enough to fill the GPU, small enough
+   that the buffers of a pass (pinned staging here, record mirrors in the library) are cheap to come by */
+#define STAGE_PASS ((size_t)256 << 20)
+
 static void stage_reserve(size_t need)
 {
     if (need <= H.stage_cap)
         return;
+    /* Pinning memory costs ~0.2 ms per MiB and a grown buffer has to be copied into: 8 MiB for the lone small file, then
+       straight to the size a pass is cut at (STAGE_PASS below), doubling only for captures that are larger than that.  (Growing
+       by doubling up to 1 GiB took 0.55 s of a 1.1 s run over 8192 captures, RTL433_HIP_TRACE=1.) */
     size_t cap = H.stage_cap ? H.stage_cap : (size_t)8 << 20;
+    if (cap < need && cap < STAGE_PASS)
+        cap = STAGE_PASS;
     while (cap < need)
         cap *= 2;
+    double const t_grow = trace_now();
     uint8_t *p = r433_host_alloc(cap);
     if (!p)
         hip_fatal("pinned staging buffer");
     if (H.stage_len)
         memcpy(p, H.stage, H.stage_len);
     r433_host_free(H.stage);
+    if (trace_on())
+        fprintf(stderr, "hip flow: staging buffer grown to %zu MiB in %.1f ms\n", cap >> 20, trace_now() - t_grow);
     H.stage     = p;
     H.stage_cap = cap;
 }
@@ -510,7 +541,10 @@ static void engine_ensure(r_cfg_t *cfg, r433_flow_cfg const *fc)
         rows[i].tolerance   = d->tolerance;
         rows[i].priority    = d->priority;
     }
+    double const t_create = trace_now();
     slot->eng = r433_batch_create(fc, rows, (uint32_t)n);
+    if (trace_on())
+        fprintf(stderr, "hip flow: engine created in %.1f ms\n", trace_now() - t_create);
     free(rows);
     if (!slot->eng)
         hip_fatal("r433_batch_create");
@@ -778,8 +812,13 @@ static int run_group(r_cfg_t *cfg, hip_capture *group, size_t n)
     else {
         r433_batch_set_taps(H.eng, NULL, NULL, NULL, 0);
     }
+    double const t_probe = trace_now();
     engine_prefilter(cfg);
+    double const t_run = trace_now();
     int n_pkgs = r433_batch_run_host(H.eng, ptrs, bytes, (uint32_t)n);
+    if (trace_on())
+        fprintf(stderr, "hip flow: %zu captures, %.1f MiB: pre-filter %.1f ms, GPU pass (H2D, kernels, D2H) %.1f ms\n", n, H.stage_len / 1048576.0,
+                t_run - t_probe, trace_now() - t_run);
     if (n_pkgs >= 0 && want_taps) {
         for (void **iter = demod->dumper.elems; iter && *iter; ++iter) {
             file_info_t const *dumper = *iter;
@@ -848,6 +887,7 @@ static int run_group(r_cfg_t *cfg, hip_capture *group, size_t n)
     int chatty    = replay_is_chatty(demod);
     int n_threads = replay_threads();
     int events;
+    double const t_replay = trace_now();
     if (chatty || n_threads <= 1) {
         r433_dispatch_hooks hooks = {NULL, on_package_begin, on_event_done, on_package_end, H.sync_active ? sync_filter : NULL};
         events = r433_batch_dispatch_hooks(H.eng, (r433_r_device *const *)demod->r_devs.elems, (uint32_t)demod->r_devs.len, &hooks);
@@ -863,6 +903,9 @@ static int run_group(r_cfg_t *cfg, hip_capture *group, size_t n)
     }
     if (events < 0)
         hip_fatal("r433_batch_dispatch_hooks");
+    if (trace_on())
+        fprintf(stderr, "hip flow: %d packages replayed into %zu decoders on %d thread(s) %.1f ms, %d events\n", n_pkgs, demod->r_devs.len,
+                chatty ? 1 : n_threads, trace_now() - t_replay, events);
     write_grabs(cfg, group, n);
     /* captures without packages (and the frames after the last package) still count their frames */
     enter_capture((uint32_t)n - 1);
@@ -895,6 +938,10 @@ int hip_sdr_flow_drain(struct r_cfg *cfg)
 
     int events   = 0;
     size_t n_run = H.n_caps - (H.open ? 1 : 0); /* a capture still being pushed to stays queued */
+    static double t_last_drain;
+    double const t_drain = trace_now();
+    if (trace_on())
+        fprintf(stderr, "hip flow: %zu captures queued over %.1f ms (since the start / the pass before)\n", n_run, t_last_drain ? t_drain - t_last_drain : 0.0);
     for (size_t i = 0; i < n_run;) {
         hip_capture *c = &H.caps[i];
         if (c->irregular || c->bytes == 0 || c->n_frames == 0 || (c->n_frames > 1 && c->frame_bytes / c->sample_size % 64 != 0)) {
@@ -951,6 +998,9 @@ int hip_sdr_flow_drain(struct r_cfg *cfg)
         H.stage_len = 0;
     }
 
+    if (trace_on())
+        fprintf(stderr, "hip flow: pass %.1f ms\n", trace_now() - t_drain);
+    t_last_drain = trace_now();
     cfg->in_filename             = keep_filename;
     demod->load_info             = keep_load_info;
     cfg->samp_rate               = keep_rate;
@@ -1062,7 +1112,7 @@ int push_sdr_flow(r_cfg_t *cfg, unsigned char *iq_buf, uint32_t len)
             return ev;
         }
         H.open = 0;
-        if (H.n_caps >= batch_limit(cfg) || H.stage_len >= ((size_t)1 << 30))
+        if (H.n_caps >= batch_limit(cfg) || H.stage_len + STAGE_PASS / 16 >= STAGE_PASS)
             return hip_sdr_flow_drain(cfg);
         return 0;
     }

@@ -20,6 +20,7 @@ REF=$GRAFT_REPO_ROOT/oracle/_ref/rtl_433_ref
 HIP=$GRAFT_REPO_ROOT/dropin/_build/rtl_433_hip
 [ -z "$GRAFT_REPO_ROOT" ] && REF=/root/repo/oracle/_ref/rtl_433_ref && HIP=/root/repo/dropin/_build/${CLI_BIN:-rtl_433_hip}
 t() { local s=$(date +%s%N); "$@"; local e=$(date +%s%N); echo "$(( (e - s) / 1000000 )) m"; }
+rm -f ref.json hip.json
 for rep in 1 2 3; do
   tr=$(t $REF $ARGS $X -F json:ref.json -M level -K FILE 2>/dev/null); mv ref.json ref.$rep.json
   th=$(t $HIP $ARGS $X -F json:hip.json -M level -K FILE 2>/dev/null); mv hip.json hip.$rep.json
