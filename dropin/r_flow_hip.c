@@ -1121,6 +1121,12 @@ int push_sdr_flow(r_cfg_t *cfg, unsigned char *iq_buf, uint32_t len)
     if (n_samples * demod->sample_size != len) {
         print_log(LOG_WARNING, __func__, "Sample buffer length not aligned to sample size!");
     }
+    /* A receiver never flushes: this flow would queue samples for ever and say nothing (captures are run when they end).
+       Frames one by one are what the function seam is for (make -C dropin refflow: the reference's own flow over librtl433seam.so). */
+    if (cfg->in_files.len == 0 && !demod->load_info.format) {
+        print_log(LOG_FATAL, "HIP", "live input is not served by the batch flow (it decodes whole captures): use the function-seam build, dropin/_build/rtl_433_refflow_hip");
+        exit(1);
+    }
 
     // Feed data to all raw outputs (e.g. rtl_tcp)
     for (void **iter = demod->raw_handler ? demod->raw_handler->elems : NULL; iter && *iter; ++iter) {

@@ -784,6 +784,14 @@ int run_slice_and_mirror(RunCtx &r)
         HIP_TRY(hipEventRecord(b->ev[6], r.st));
     HIP_TRY(stream_wait(b, r.st));
     b->pkg_bytes = pkg_bytes;
+    if (b->arena_growth > 1) { // (see arena_growth: a grown stride is given back when the captures stopped needing it)
+        uint64_t const slots = std::max<uint32_t>(1u, r.split ? r.n_order : r.n_streams);
+        b->calm_runs = pkg_bytes / slots < b->arena_stride / 16u ? b->calm_runs + 1 : 0;
+        if (b->calm_runs >= 8) {
+            b->arena_growth /= 4;
+            b->calm_runs = 0;
+        }
+    }
     b->evt_bytes = evt_bytes;
     b->pf_ran = lp.pf_counts != nullptr;
     b->events_counted = false;

@@ -220,7 +220,9 @@ struct r433_batch {
     PinBuf<uint32_t> h_pkg_off, h_rec_off; // per package: byte offset of its first event / of its record
 
     uint32_t arena_stride = 0;
-    uint32_t arena_growth = 1; // x4 after every arena overflow, kept for the engine's life: what this workload needs per sample
+    uint32_t arena_growth = 1; // x4 after every arena overflow: what this workload needs per sample; given back after eight runs in a
+                               // row that used less than a sixteenth of it on average (one dense batch must not tax the engine for good)
+    uint32_t calm_runs = 0;
     uint32_t frames_cap = 0;
     uint32_t n_streams = 0;
     uint32_t n_pkgs = 0, n_events = 0;
