@@ -40,7 +40,7 @@ class FlowCfg(C.Structure):
     _fields_ = [("sample_size", C.c_uint32), ("samp_rate", C.c_uint32), ("frame_samples", C.c_uint32),
                 ("fpdm", C.c_uint32), ("use_mag_est", C.c_uint32), ("enable_fm", C.c_uint32),
                 ("fm_low_pass", C.c_float), ("level_limit_db", C.c_float), ("min_level_db", C.c_float),
-                ("min_snr_db", C.c_float), ("auto_level", C.c_float)]
+                ("min_snr_db", C.c_float), ("auto_level", C.c_float), ("load_format", C.c_uint32)]
 
 
 class FlowOut(C.Structure):
@@ -124,11 +124,12 @@ def _ptr(a):
 
 
 def default_flow_cfg(sample_size=2, samp_rate=250000, fpdm=0, enable_fm=1, use_mag_est=0, fm_low_pass=0.0,
-                     level_limit_db=0.0, min_level_db=-12.1442, min_snr_db=9.0, auto_level=0.0, frame_samples=None):
+                     level_limit_db=0.0, min_level_db=-12.1442, min_snr_db=9.0, auto_level=0.0, frame_samples=None, load_format=0):
+    """load_format 1 / 2: the capture is an am.s16 / fm.s16 file (sample_size 2)"""
     if frame_samples is None:
         frame_samples = 262144 // sample_size
     return FlowCfg(sample_size, samp_rate, frame_samples, fpdm, use_mag_est, enable_fm, fm_low_pass,
-                   level_limit_db, min_level_db, min_snr_db, auto_level)
+                   level_limit_db, min_level_db, min_snr_db, auto_level, load_format)
 
 
 def _blob_bytes(b):

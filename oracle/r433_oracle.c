@@ -1339,6 +1339,11 @@ int orc_flow_run(orc_flow_cfg const *cfg, void const *iq, size_t n_bytes, r433_d
             else {
                 memcpy(fmb, env, sizeof(uint16_t) * n); /* union aliasing */
             }
+            /* "Handle special input formats" (src/r_flow.c:212-225): the file's words over the demodulated buffer */
+            if (cfg->load_format == 1 && ss == 2)
+                memcpy(am, src, sizeof(int16_t) * n);
+            else if (cfg->load_format == 2 && ss == 2)
+                memcpy(fmb, src, sizeof(int16_t) * n);
             if (out->env)
                 memcpy(out->env + done, env, sizeof(uint16_t) * n);
             if (out->am)

@@ -139,6 +139,7 @@ typedef struct orc_flow_cfg {
     float min_level_db;     /* -Y minlevel, default -12.1442 */
     float min_snr_db;       /* -Y minsnr, default 9 */
     float auto_level;       /* -Y autolevel > 0 */
+    uint32_t load_format;   /* 0: IQ; 1 / 2: the samples are an am.s16 / fm.s16 file (file_info S16_AM / S16_FM, src/r_flow.c:212-225) */
 } orc_flow_cfg;
 
 typedef struct orc_blob {

@@ -254,3 +254,23 @@ def test_am_s16_fm_s16_input_files():
     from tests.emu import host
     from tests import s16_input_case
     s16_input_case.check(lambda iq, devs, fmt, fm: host.emu_run(iq, 2, 250000, devs, fpdm=0, taps=True, enable_fm=fm, input_format=fmt))
+
+
+def test_oracle_am_s16_fm_s16_against_reference():
+    """the restatement's load_format (what the fuzzer checks such input against) pinned to the unmodified reference"""
+    if not po.have_ref():
+        pytest.skip("oracle/_ref/libr433ref.so not present")
+    from tests import s16_input_case
+    for fmt, words in s16_input_case.captures():
+        devs, pk, npk, ev, nev, taps = s16_input_case.reference_records(fmt, words, 1)
+        cfg = po.default_flow_cfg(2, 250000, fpdm=0, load_format=fmt)
+        opk, oev, base = b"", b"", 0
+        for s, w in enumerate(words):
+            o = po.oracle_flow(w.view(np.uint8), devs, cfg, stream_index=s, pkg_base=base, taps=True)
+            if w.size:
+                assert np.array_equal(o["am"], taps[s][0]) and np.array_equal(o["fm"], taps[s][1])
+            opk += o["packages"]
+            oev += o["events"]
+            base += o["n_packages"]
+        assert base == npk and po.strip_ret_pos(opk) == pk
+        assert po.events_normalize(oev) == po.events_normalize(po.canonical_events(ev))

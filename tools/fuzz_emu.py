@@ -134,14 +134,18 @@ def one_case(seed, run=None):
             devs = None
     caps = [make_capture(rng, ss, rate) for _ in range(int(rng.integers(1, 4)))]
     split = int(rng.choice([0, 0, 4096, 8192, 20000]))
+    load_format = 0
+    if ss == 2 and rng.random() < 0.12:  # the same bytes taken for an am.s16 / fm.s16 file (any int16 word, negative AM included)
+        load_format = int(rng.integers(1, 3))
     if BIG and ss == 2 and rng.random() < 0.25:
         caps = [long_ook(rng, rate)] + caps[:1]
         split = int(rng.choice([1, 1, 65536, 200000]))  # 1 = R433_SPLIT_AUTO
         kw.pop("frame_samples", None) if kw.get("frame_samples", 65536) < 2048 else None
     blind = 1 if split and rng.random() < 0.5 else 0  # R433_DEBUG_SPLIT_BLIND
     form = (0, 4096, 32768)[seed % 3]  # the launch's own choice / R433_DEBUG_ONE_WAVE / R433_DEBUG_PAIR: both forms of the detection kernel
-    g = run(caps, ss, rate, devs, fpdm=fpdm, taps=True, enable_fm=enable_fm, split=split, debug=blind | form, **kw)
-    cfg = po.default_flow_cfg(ss, rate, fpdm=fpdm, enable_fm=enable_fm, **kw)
+    g = run(caps, ss, rate, devs, fpdm=fpdm, taps=True, enable_fm=enable_fm, split=split, debug=blind | form,
+            **(dict(kw, input_format=2 + load_format) if load_format else kw))
+    cfg = po.default_flow_cfg(ss, rate, fpdm=fpdm, enable_fm=enable_fm, load_format=load_format, **kw)
     pk, ev, base = b"", b"", 0
     for s, a in enumerate(caps):
         o = po.oracle_flow(a, devs, cfg, stream_index=s, pkg_base=base, taps=True)
