@@ -315,6 +315,8 @@ int run_plan(RunCtx &r)
             || (rc = b->d_pkg_base.ensure(r.n_slots)) || (rc = b->h_state.ensure(r.n_slots)) || (rc = b->d_order.ensure(r.n_slots))
             || (rc = b->d_segs.ensure(r.n_slots)) || (rc = b->d_wg.ensure(r.n_slots)))
         return rc;
+    if (r.split) // a slot no workgroup wrote reads as one that failed, whatever the memory held before (seg_fail = -1)
+        HIP_TRY(hipMemsetAsync(b->d_state.p, 0xff, (size_t)r.n_slots * sizeof(StreamState), r.st));
     return 0;
 }
 
@@ -367,8 +369,9 @@ void plan_workgroups(RunCtx const &r, SegDesc const *segs, uint32_t n, std::vect
     std::vector<std::pair<uint64_t, uint32_t>> order; // (cost, entry)
     for (uint32_t i = 0; i < n;) {
         SegDesc const &d = segs[i];
-        bool const twin = i + 1 < n && !(d.flags & (SEG_FIRST | SEG_ODD)) && (segs[i + 1].flags & SEG_ODD) && segs[i + 1].capture == d.capture
-                && segs[i + 1].start == d.start && segs[i + 1].end == d.end;
+        // (R433_DEBUG_ONE_WAVE: workgroups of one wavefront run one slot each -- no twins then)
+        bool const twin = !(b->debug_flags & R433_DEBUG_ONE_WAVE) && i + 1 < n && !(d.flags & (SEG_FIRST | SEG_ODD)) && (segs[i + 1].flags & SEG_ODD)
+                && segs[i + 1].capture == d.capture && segs[i + 1].start == d.start && segs[i + 1].end == d.end;
         uint64_t cost = 0;
         if (r.tiles_cap && d.capture < r.quiet_below.size()) {
             uint32_t const *tm = b->h_tile_max.p + (size_t)d.capture * r.tiles_cap;

@@ -4,6 +4,9 @@
 // 20-instruction x86-64 context switch.  A rendezvous parks the calling fiber; the scheduler resumes
 // fibers round-robin, so after one full round every live fiber has reached the same rendezvous and
 // the values deposited in the (double-buffered) slot array can be read by all of them.
+#include <map>
+#include <mutex>
+#include <vector>
 #include <hip/hip_runtime.h>
 
 #include <sys/mman.h>
@@ -186,18 +189,66 @@ void launch(dim3 grid, dim3 block, std::function<void()> const &body)
 } // namespace emu
 
 // ---- runtime stubs ----
+// Device memory is not zeroed, and a block that was freed comes back with what its last owner left in it: a fresh block
+// is poisoned (0xA5), a freed one is kept by size class and handed out again AS IT IS.  (A slot nobody ran must not be
+// read: with poison alone a stale detector state looked invalid and hid exactly that.)
+namespace {
+std::mutex g_heap_lock;
+std::map<size_t, std::vector<void *>> g_heap_free; // size class -> blocks
+std::map<void *, size_t> g_heap_class;             // live or cached block -> its size class
+size_t heap_class(size_t n)
+{
+    size_t c = 256;
+    while (c < n)
+        c *= 2;
+    return c;
+}
+} // namespace
+
 hipError_t hipMalloc(void **p, size_t n)
 {
+    size_t const c = heap_class(n);
+    {
+        std::lock_guard<std::mutex> g(g_heap_lock);
+        auto it = g_heap_free.find(c);
+        if (it != g_heap_free.end() && !it->second.empty()) {
+            *p = it->second.back();
+            it->second.pop_back();
+            return hipSuccess;
+        }
+    }
     void *q = nullptr;
-    if (posix_memalign(&q, 256, n ? n : 256) != 0)
+    if (posix_memalign(&q, 256, c) != 0)
         return hipErrorOutOfMemory;
-    memset(q, 0xA5, n); // device memory is not zeroed
+    memset(q, 0xA5, c);
+    {
+        std::lock_guard<std::mutex> g(g_heap_lock);
+        g_heap_class[q] = c;
+    }
     *p = q;
     return hipSuccess;
 }
-hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+hipError_t hipFree(void *p)
+{
+    if (!p)
+        return hipSuccess;
+    std::lock_guard<std::mutex> g(g_heap_lock);
+    auto it = g_heap_class.find(p);
+    if (it == g_heap_class.end()) {
+        free(p);
+        return hipSuccess;
+    }
+    std::vector<void *> &cache = g_heap_free[it->second];
+    if (it->second > (size_t(64) << 20) || cache.size() >= 4) { // keep the cache small: the large arenas go back to the system
+        g_heap_class.erase(it);
+        free(p);
+        return hipSuccess;
+    }
+    cache.push_back(p);
+    return hipSuccess;
+}
 hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
-hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+hipError_t hipHostFree(void *p) { return hipFree(p); }
 hipError_t hipMemcpy(void *d, void const *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void *d, void const *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }

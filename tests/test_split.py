@@ -78,3 +78,21 @@ def test_split_cs16_fsk_and_autolevel(default_devices):
     pk, ev, base = _oracle([iq], devs, cfg)
     g = host.emu_run([iq], 2, 250000, devs, split=50000, auto_level=1.0)
     assert g["split"]["segments"] > 1 and g["packages"][0] == pk and g["events"][0] == ev
+
+
+def test_every_variant_is_run_in_every_form(default_devices):
+    """The odd variant of a piece sits in the slot behind its twin: a launch of one-wavefront workgroups (R433_DEBUG_ONE_WAVE)
+    must run it as a workgroup of its own.  (It did not once: the stitch then read whatever the slot's memory held -- on the
+    emulator poison, which reads as "failed" and only costs rounds; on the GPU the state of an earlier run.)  Same records and
+    the same number of pieces run again in all three forms."""
+    from tests.emu import host
+    devs = default_devices[0][:40]
+    caps = [long_capture(11), long_capture(12, sigma=1.0)]
+    cfg = po.default_flow_cfg(2, 250000)
+    pk, ev, base = _oracle(caps, devs, cfg)
+    reruns = {}
+    for name, flag in (("triple", 0), ("one wavefront", 4096), ("pair", 32768)):
+        g = host.emu_run(caps, 2, 250000, devs, split=8192, debug=flag)
+        assert g["packages"][0] == pk and g["events"][0] == ev, name
+        reruns[name] = g["split"]["pieces_rerun"]
+    assert reruns["one wavefront"] == reruns["triple"] == reruns["pair"], reruns

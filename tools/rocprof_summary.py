@@ -10,6 +10,33 @@ def main(db, out=None):
     lines.append(f"{'calls':>6} {'total_us':>12} {'avg_us':>12} {'pct':>7}  kernel   (durations are in microseconds)")
     for name, calls, total, avg, pct in cur:
         lines.append(f"{calls:>6} {total:>12.1f} {avg:>12.2f} {pct:>7.2f}  {name}")
+    # the dominant kernel dispatch by dispatch: alone on the device, or with kernels of other queues running beside it
+    # (under rocprofv3 a host -> device copy is a blit kernel, __amd_rocclr_copyBuffer, that takes CUs away)
+    try:
+        import re
+        rows = list(c.execute("select name, start, end from kernels order by start"))
+        top = c.execute("select name from top_kernels limit 1").fetchone()[0]
+        mine = [r for r in rows if r[0] == top]
+        alone, beside = [], {}
+        for k in mine:
+            who = set()
+            for r in rows:
+                if r is not k and min(r[2], k[2]) - max(r[1], k[1]) > 0.02 * (k[2] - k[1]):
+                    who.add(re.search(r"(k_\w+|__amd_\w+|\w+)", r[0].replace("void ", "").replace("r433::(anonymous namespace)::", "")).group(0))
+            if who:
+                beside.setdefault(", ".join(sorted(who)), []).append((k[2] - k[1]) / 1e3)
+            else:
+                alone.append((k[2] - k[1]) / 1e3)
+        lines.append("")
+        import re
+        m = re.search(r"k_\w+(<[^(]*>)?", top)
+        lines.append(f"{m.group(0) if m else top}: dispatch by dispatch")
+        if alone:
+            lines.append(f"  {len(alone):>4} dispatches with nothing else on the device: mean {sum(alone) / len(alone):.2f} us (min {min(alone):.2f}, max {max(alone):.2f})")
+        for who, d in beside.items():
+            lines.append(f"  {len(d):>4} dispatches beside [{who}]: mean {sum(d) / len(d):.2f} us (min {min(d):.2f}, max {max(d):.2f})")
+    except (sqlite3.Error, TypeError) as e:
+        lines.append(f"(no per-dispatch split: {e})")
     try:
         cur = c.execute("select name, min(vgpr_count), min(sgpr_count), min(lds_size), min(scratch_size), min(grid_x), min(workgroup_x) "
                         "from kernels group by name")
