@@ -131,8 +131,10 @@ int r433_batch_set_split(r433_batch *b, uint32_t segment_samples);
  * detection kernels take turns instead of sharing the compute units -- a launch fills every SIMD by itself, two of them
  * side by side only stretch each other -- while everything after detection (slicers, record copies) still overlaps the
  * next engine's detection.  on = 2: the turn lasts until the slicer kernels of the pass are done as well (they, too, fill
- * the chip by themselves; record copies and the host replay still overlap the next engine's kernels).  Off by default: a
- * lone engine has nobody to wait for. */
+ * the chip by themselves; record copies and the host replay still overlap the next engine's kernels).  on = 3: until the
+ * records are on the host -- nothing of two passes overlaps on the device; for profiling (under rocprofv3 a copy is a blit
+ * kernel that takes compute units from the kernel beside it; outside the profiler copies run on the SDMA engines and level 2
+ * is the faster setting).  Off by default: a lone engine has nobody to wait for. */
 int r433_batch_set_exclusive_detect(r433_batch *b, int on);
 /* of the last run: wavefront slots planned (segments incl. parity variants), pieces run again after a dropped cut */
 int r433_batch_split_stats(r433_batch *b, uint32_t *segments, uint32_t *pieces_rerun);

@@ -764,7 +764,7 @@ int run_slice_and_mirror(RunCtx &r)
     }
     if (b->profiling)
         HIP_TRY(hipEventRecord(b->ev[5], r.st));
-    if (r.turn.owns_lock()) { // exclusive level 2: the kernels of this pass are done before the next engine's begin
+    if (r.turn.owns_lock() && b->exclusive_detect < 3) { // exclusive level 2: the kernels of this pass are done before the next engine's begin
         HIP_TRY(stream_wait(b, r.st));
         r.turn.unlock();
     }
@@ -786,6 +786,8 @@ int run_slice_and_mirror(RunCtx &r)
     if (b->profiling)
         HIP_TRY(hipEventRecord(b->ev[6], r.st));
     HIP_TRY(stream_wait(b, r.st));
+    if (r.turn.owns_lock()) // exclusive level 3: the record copies, too, have the device to themselves
+        r.turn.unlock();
     b->pkg_bytes = pkg_bytes;
     if (b->arena_growth > 1) { // (see arena_growth: a grown stride is given back when the captures stopped needing it)
         uint64_t const slots = std::max<uint32_t>(1u, r.split ? r.n_order : r.n_streams);

@@ -330,7 +330,7 @@ int r433_batch_set_exclusive_detect(r433_batch *b, int on)
 {
     if (!b)
         return fail(R433_EINVAL, "null batch");
-    b->exclusive_detect = on < 0 ? 0 : on > 2 ? 2 : on;
+    b->exclusive_detect = on < 0 ? 0 : on > 3 ? 3 : on;
     return 0;
 }
 

@@ -201,7 +201,7 @@ struct r433_batch {
     // split captures (r433_batch_set_split)
     uint32_t split_samples = R433_SPLIT_AUTO;
     uint32_t debug_flags = 0; // r433_batch_set_debug
-    int exclusive_detect = 0; // r433_batch_set_exclusive_detect: 1 the detection kernel, 2 the slicer kernels as well
+    int exclusive_detect = 0; // r433_batch_set_exclusive_detect: 1 the detection kernel, 2 the slicer kernels as well, 3 the record copies too
     bool logic_on = false;         // r433_batch_enable_logic_dump
     DevBuf<uint8_t> d_logic;
     PinBuf<uint8_t> h_logic;

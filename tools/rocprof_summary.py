@@ -15,7 +15,8 @@ def main(db, out=None):
     try:
         import re
         rows = list(c.execute("select name, start, end from kernels order by start"))
-        top = c.execute("select name from top_kernels limit 1").fetchone()[0]
+        tops = [r[0] for r in c.execute("select name from top_kernels")]
+        top = next((n for n in tops if "r433::" in n), tops[0])  # the library's heaviest kernel (under the profiler copies are kernels too)
         mine = [r for r in rows if r[0] == top]
         alone, beside = [], {}
         for k in mine:
