@@ -164,14 +164,15 @@ __global__ __launch_bounds__(256) void k_cf32_to_cs16(float const *in, uint64_t 
 // Mean raw envelope of every 2048-sample tile (as a sum), ESTIMATED from an eighth of it: where a long capture may be cut
 // into independently processed segments -- tiles that carry no more energy than the noise floor -- and how heavy a
 // segment is.  A heuristic only (every cut is verified after the fact), so it must not cost a second pass over the
-// stream: eight 64-byte lines per tile, evenly spread from its first line to its last, four lanes to a line, scaled back to the whole tile.
+// stream: four 128-byte lines per tile (one full-width request each), evenly spread from its first line to its last, eight lanes to a
+// line, scaled back to the whole tile.
 template <int KIND> __global__ __launch_bounds__(64) void k_tile_max(uint8_t const *iq, uint64_t stride_bytes,
         uint32_t const *stream_bytes, uint32_t uniform_bytes, uint32_t tiles_cap, uint32_t n_items, uint32_t *tile_sum)
 {
     constexpr int SS = KIND == ENV_MAG_CS16 ? 4 : 2;
-    constexpr uint32_t kLines = 2048u * SS / 64u; // 64-byte lines of a tile
-    constexpr uint32_t kTaken = 8;
-    // two tiles per workgroup: lanes 0..31 the first, 32..63 the second
+    constexpr uint32_t kLines = 2048u * SS / 128u; // 128-byte lines of a tile
+    constexpr uint32_t kTaken = 4;
+    // two tiles per workgroup: lanes 0..31 the first, 32..63 the second; eight lanes to a line (one 128-byte request)
     uint32_t const item = min(blockIdx.x * 2u + (threadIdx.x >> 5), n_items - 1u); // (an odd count: the last half workgroup repeats the last tile)
     uint32_t const s = item / tiles_cap, t = item % tiles_cap;
     uint32_t const lane = threadIdx.x & 31u;
@@ -181,10 +182,10 @@ template <int KIND> __global__ __launch_bounds__(64) void k_tile_max(uint8_t con
     bool const whole = start + 2048u <= my_n; // whole tiles only: nobody cuts next to the ragged end of a capture
     if (whole) {
         uint8_t const *base = iq + (uint64_t)s * stride_bytes + start * SS;
-        // the first and the last line of the tile are among the eight: whatever crosses into a tile shows in it (a burst that
+        // the first and the last line of the tile are among the four: whatever crosses into a tile shows in it (a burst that
         // starts behind the last line taken would otherwise leave the tile looking quiet, and a cut behind such a tile cannot
         // be started from: the new piece establishes its carries and its floor on that tile)
-        uint4 const w = *(uint4 const *)(base + (uint64_t)((lane >> 2) * (kLines - 1u) / (kTaken - 1u)) * 64u + (lane & 3u) * 16u);
+        uint4 const w = *(uint4 const *)(base + (uint64_t)((lane >> 3) * (kLines - 1u) / (kTaken - 1u)) * 128u + (lane & 7u) * 16u);
         if (SS == 2)
             acc = env_one<KIND>(w.x & 0xffffu) + env_one<KIND>(w.x >> 16) + env_one<KIND>(w.y & 0xffffu) + env_one<KIND>(w.y >> 16)
                     + env_one<KIND>(w.z & 0xffffu) + env_one<KIND>(w.z >> 16) + env_one<KIND>(w.w & 0xffffu) + env_one<KIND>(w.w >> 16);

@@ -234,7 +234,7 @@ int run_plan_split(RunCtx &r, uint32_t split_samples)
         std::vector<uint32_t> cuts;
         uint32_t pos = seg_len;
         while (n > seg_len && pos + seg_len / 2 < n) {
-            // The tile sums are taken from a subsample (eight lines of a tile, k_tile_max): a burst that starts behind the
+            // The tile sums are taken from a subsample (four 128-byte lines of a tile, k_tile_max): a burst that starts behind the
             // last line of the tile in front of the cut goes unseen there, and that tile is the one the new piece
             // establishes its filter carries and its floor on.  A cut whose own first tile is quiet too cannot have that
             // (anything longer than the space between two lines shows in the next tile's first line): such cuts first.

@@ -317,7 +317,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
     int &s_pover = *(int *)(s_env + 2 * kPitch16 + 2 * kChunk + 8); // producer -> consumer: a filter carry was refused (det.overflow codes 2, 3)
 
     int const lane = (int)threadIdx.x & 63;
-    int const wave = (int)threadIdx.x >> 6;
+    int const wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6); // (a scalar: the role branches below are scalar branches)
     constexpr bool solo = FORM == 1; // one wavefront does both halves
     uint8_t *const s_am = s_tiles, *const s_fm = s_tiles + (solo ? 1 : 2) * (64 * kPitchOut);
     // am.s16 / fm.s16 input files (RUN_AM_IS_INPUT / RUN_FM_IS_INPUT; the launch adds the room): the tile's words as they came
@@ -334,7 +334,12 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
     // workgroup = one capture, or one piece of a split capture (in both parity variants: consumers 1 and 2 of a triple)
     uint32_t const wg = p.wg_slot ? p.wg_slot[blockIdx.x] : blockIdx.x;
     bool const idle = FORM == 3 && role == 2 && !(wg >> 31); // a triple whose piece has one variant only: the third wavefront just keeps the barriers
-    uint32_t const s = (wg & 0x7fffffffu) + (FORM == 3 && role == 2 && !idle ? 1u : 0u);
+    // (read back through a lane: the slot differs between the wavefronts of a triple, so the compiler takes it -- and the capture,
+    // the piece's bounds, every pointer made from them -- for per-lane values; in vector registers they cost the three-wavefront
+    // forms 25 spilled registers, 50 MB of scratch written back per config-3 pass)
+    // (The builtin, not uni(): same instruction, but at this register pressure the allocation is a coin toss -- 16 bytes of
+    // scratch per lane this way, 188 through the inlined helper.  tools/kres.sh after every change of this kernel.)
+    uint32_t const s = (uint32_t)__builtin_amdgcn_readfirstlane((int)((wg & 0x7fffffffu) + (FORM == 3 && role == 2 && !idle ? 1u : 0u)));
     uint32_t const cap = p.segs ? p.segs[s].capture : s;
     uint32_t const my_bytes = p.stream_bytes ? p.stream_bytes[cap] : p.uniform_bytes;
     uint32_t const my_n = my_bytes / SS;
