@@ -159,6 +159,8 @@ int r433_batch_debug_state(r433_batch *b, void *host_buf, size_t bytes);
 #define R433_DEBUG_TWO_PASS_SLICER 2u  /* count + write slicer passes instead of staging slots */
 #define R433_DEBUG_SPLIT_TRACE 4u      /* stderr trace of dropped cuts */
 #define R433_DEBUG_DISPATCH_TRACE 32u   /* stderr trace of the ordered replay: index / levels / commit times, the slowest decoders */
+#define R433_DEBUG_NO_ORDER 64u         /* large grids in capture order instead of heaviest first (A/B timing) */
+#define R433_DEBUG_FORCE_ORDER 128u     /* heaviest first whatever the size of the grid (tests) */
 #define R433_DEBUG_ONE_STRETCH 16u     /* the slicer fan-out over all packages at once, however many (A/B timing) */
 #define R433_DEBUG_SMALL_STRETCH 8u    /* slicer fan-out three packages at a time (what batches over 1536 packages do 1024 at a time; tests) */
 #define R433_DEBUG_SKIP_DETECT 256u

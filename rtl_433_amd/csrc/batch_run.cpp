@@ -545,6 +545,8 @@ int run_stitch(RunCtx &r, StreamParams const &sp)
 }
 
 // envelope, filters, pulse detection: packages per slot in the arena (grown and repeated if it overflows)
+constexpr uint32_t kOrderFrom = 2048; // captures in a grid from which on their order is worth a look (1536 pairs fit the chip at once)
+
 int run_detect(RunCtx &r)
 {
     r433_batch *const b = r.b;
@@ -569,6 +571,16 @@ int run_detect(RunCtx &r)
         b->last_segments = r.n_planned;
         b->last_redone = 0;
         std::vector<uint32_t> wgs; // (outlives the copy below: the stream is waited for before this scope ends)
+        if (!r.split && (r.n_streams >= kOrderFrom || (b->debug_flags & R433_DEBUG_FORCE_ORDER)) && !(b->debug_flags & R433_DEBUG_NO_ORDER)) {
+            // several rounds of workgroups: the heavy captures first (k_capture_weight; the order is made on the device)
+            if ((rc = b->d_wg.ensure(2 * (size_t)r.n_streams)))
+                return rc;
+            launch_capture_order(r.env_kind(), r.d_iq, r.stride_bytes, r.d_lens(), (uint32_t)r.stride_bytes, r.n_streams,
+                    b->d_wg.p + r.n_streams, b->d_wg.p, r.st);
+            HIP_TRY(hipGetLastError());
+            sp.wg_slot = b->d_wg.p;
+            sp.n_wgs = r.n_streams;
+        }
         if (r.split) {
             HIP_TRY(hipMemcpyAsync(b->d_segs.p, r.segs.data(), r.segs.size() * sizeof(SegDesc), hipMemcpyHostToDevice, r.st));
             sp.segs = b->d_segs.p;

@@ -188,6 +188,9 @@ void launch_analyze(uint8_t const *arena, uint32_t arena_stride, uint32_t const 
 int launch_dump(int format, uint32_t sample_size, void const *d_in, void *d_out, uint64_t n_out, hipStream_t st);
 void launch_convert(int input_format, void const *d_in, uint64_t in_stride_bytes, void *d_out, uint64_t out_stride_bytes,
         uint64_t row_in_bytes, uint32_t n_rows, hipStream_t st);
+// heaviest captures first: weight[n_streams] (scratch), order[n_streams] = capture indices by guessed weight, descending
+void launch_capture_order(int kind, void const *d_iq, uint64_t stride_bytes, uint32_t const *stream_bytes, uint32_t uniform_bytes,
+        uint32_t n_streams, uint32_t *weight, uint32_t *order, hipStream_t st);
 void launch_tile_max(int kind, void const *d_iq, uint64_t stride_bytes, uint32_t const *stream_bytes, uint32_t uniform_bytes,
         uint32_t n_streams, uint32_t tiles_cap, uint32_t *tile_max, hipStream_t st);
 void launch_frame_sums(int kind, void const *d_iq, uint64_t stride_bytes, uint32_t const *stream_bytes, uint32_t uniform_bytes,

@@ -2093,7 +2093,8 @@ void launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st)
     // (profiles/r03_b_pair_vs_single.txt).  RUN_ONE_WAVE / RUN_PAIR force either form (A/B timing, tests).
     bool const pair = (p.flags & RUN_PAIR) || (!(p.flags & RUN_ONE_WAVE) && !(p.n_streams > 1536u && p.n_streams <= 2304u));
     // split captures come with their workgroup list: a producer and (where a piece has both parity variants) two consumers
-    bool const triple = p.wg_slot != nullptr && !(p.flags & RUN_ONE_WAVE);
+    // (a workgroup list without pieces is only an order: launch_capture_order)
+    bool const triple = p.wg_slot != nullptr && p.segs != nullptr && !(p.flags & RUN_ONE_WAVE);
     dim3 grid(p.wg_slot ? p.n_wgs : p.n_streams), block(triple ? 192 : pair ? 128 : 64);
     uint32_t const lds = (pair || triple ? 4u : 2u) * 64u * (uint32_t)kPitchOut // the tile buffers (s_tiles)
             + ((p.flags & (RUN_AM_IS_INPUT | RUN_FM_IS_INPUT)) ? 64u * (uint32_t)kPitch16 : 0u); // + s_raw

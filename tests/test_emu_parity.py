@@ -274,3 +274,19 @@ def test_oracle_am_s16_fm_s16_against_reference():
             base += o["n_packages"]
         assert base == npk and po.strip_ret_pos(opk) == pk
         assert po.events_normalize(oev) == po.events_normalize(po.canonical_events(ev))
+
+
+def test_heaviest_captures_first(default_devices):
+    """Large grids hand their captures out heaviest first (k_capture_weight + k_order_by_weight, forced here for a small one):
+    every capture still lands in its own slot -- records and taps as in capture order, for both workgroup forms."""
+    from tests.emu import host
+    devs = default_devices[0][:30]
+    caps = [synth.noise_cu8(81, 30000, 2.0), synth.ook_stream(82, 65536)[0], np.zeros(0, dtype=np.uint8), synth.ook_stream(83, 20000)[0],
+            synth.fsk_stream_cu8(84, 50001), synth.ook_stream(85, 65536)[0], synth.random_cu8(86, 777)]
+    cfg = po.default_flow_cfg(2, 250000)
+    pk, ev, _ = _oracle_batch(caps, devs, cfg)
+    for flags in (128, 128 | 4096, 128 | 32768):
+        g = host.emu_run(caps, 2, 250000, devs, taps=True, debug=flags)
+        assert g["packages"][0] == pk and g["events"][0] == ev, flags
+    plain = host.emu_run(caps, 2, 250000, devs, taps=True)
+    assert all(np.array_equal(a, b) for a, b in zip(g["taps"], plain["taps"]))

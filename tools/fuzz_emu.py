@@ -143,6 +143,8 @@ def one_case(seed, run=None):
         kw.pop("frame_samples", None) if kw.get("frame_samples", 65536) < 2048 else None
     blind = 1 if split and rng.random() < 0.5 else 0  # R433_DEBUG_SPLIT_BLIND
     form = (0, 4096, 32768)[seed % 3]  # the launch's own choice / R433_DEBUG_ONE_WAVE / R433_DEBUG_PAIR: both forms of the detection kernel
+    if seed % 4 == 1:
+        form |= 128  # R433_DEBUG_FORCE_ORDER: the workgroups take the captures heaviest first (a list made on the device)
     g = run(caps, ss, rate, devs, fpdm=fpdm, taps=True, enable_fm=enable_fm, split=split, debug=blind | form,
             **(dict(kw, input_format=2 + load_format) if load_format else kw))
     cfg = po.default_flow_cfg(ss, rate, fpdm=fpdm, enable_fm=enable_fm, load_format=load_format, **kw)
