@@ -203,8 +203,8 @@ template <int KIND> __global__ __launch_bounds__(64) void k_tile_max(uint8_t con
 // ---- heaviest captures first (grids of several rounds of workgroups) ----
 // A grid of more captures than the chip holds at once is handed out in index order; what is still running when the list
 // runs dry is the tail.  Handing out the heavy captures first shortens it (8192 bench captures: 5.66 ms as they come, 5.38 ms
-// heaviest first, 5.87 ms lightest first; tools/order_probe.py).  The weight of a capture is guessed from two 16-byte looks
-// per tile (1.6 % of its bytes): how many of them are well above the quietest one.  A guess only: whatever order comes out,
+// heaviest first, 5.87 ms lightest first; tools/order_probe.py).  The weight of a capture is guessed from a few looks at it
+// (a 16-byte look every 4096 samples): how many of them are well above the quietest one.  A guess only: whatever order comes out,
 // every capture is walked in full and lands in its own slot.
 template <int KIND> __global__ __launch_bounds__(64) void k_capture_weight(uint8_t const *iq, uint64_t stride_bytes,
         uint32_t const *stream_bytes, uint32_t uniform_bytes, uint32_t *weight)
@@ -212,11 +212,12 @@ template <int KIND> __global__ __launch_bounds__(64) void k_capture_weight(uint8
     constexpr int SS = KIND == ENV_MAG_CS16 ? 4 : 2;
     uint32_t const s = blockIdx.x, lane = threadIdx.x;
     uint32_t const my_n = (stream_bytes ? stream_bytes[s] : uniform_bytes) / SS;
-    uint32_t const looks = my_n / 1024u; // one per half tile
+    constexpr uint32_t kApart = 4096; // samples between two looks (a look pulls a whole 128-byte line: 3 % of a cu8 capture this way)
+    uint32_t const looks = my_n / kApart;
     uint8_t const *base = iq + (uint64_t)s * stride_bytes;
     uint32_t lo = 0xffffffffu;
     for (uint32_t k = lane; k < looks; k += 64) {
-        uint4 const w = *(uint4 const *)(base + (uint64_t)k * 1024u * SS);
+        uint4 const w = *(uint4 const *)(base + (uint64_t)k * kApart * SS);
         uint32_t e = SS == 2 ? env_one<KIND>(w.x & 0xffffu) + env_one<KIND>(w.x >> 16) + env_one<KIND>(w.y & 0xffffu) + env_one<KIND>(w.y >> 16)
                              : env_one<KIND>(w.x) + env_one<KIND>(w.y);
         lo = min(lo, e);
@@ -225,7 +226,7 @@ template <int KIND> __global__ __launch_bounds__(64) void k_capture_weight(uint8
         lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, 64));
     uint32_t heavy = 0;
     for (uint32_t k = lane; k < looks; k += 64) { // (the same lines again: they sit in the cache)
-        uint4 const w = *(uint4 const *)(base + (uint64_t)k * 1024u * SS);
+        uint4 const w = *(uint4 const *)(base + (uint64_t)k * kApart * SS);
         uint32_t e = SS == 2 ? env_one<KIND>(w.x & 0xffffu) + env_one<KIND>(w.x >> 16) + env_one<KIND>(w.y & 0xffffu) + env_one<KIND>(w.y >> 16)
                              : env_one<KIND>(w.x) + env_one<KIND>(w.y);
         heavy += e > 4u * lo + 64u ? 1u : 0u;
@@ -233,7 +234,7 @@ template <int KIND> __global__ __launch_bounds__(64) void k_capture_weight(uint8
     for (int o = 32; o > 0; o >>= 1)
         heavy += (uint32_t)__shfl_xor((int)heavy, o, 64);
     if (lane == 0)
-        weight[s] = min(heavy + (looks >> 4), 255u); // (a long quiet capture still outweighs a short one)
+        weight[s] = min(heavy * 4u + (looks >> 2), 255u); // (a long quiet capture still outweighs a short one)
 }
 
 // counting sort of the captures by weight, heaviest first: one workgroup (the list is a few thousand entries)

@@ -20,8 +20,8 @@ WORKLOADS = {
                 "k_wave<2,true,true>, 1024 captures x 65536 cu8 samples (tools/kbench.py, all decoders), one launch"),
     "config3": ([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "3", "--quick", "--steps", "2", "--warmup", "1"], ("k_wave<4", "k_tile_max", "k_frame_sums"), 4 * (64 << 20),
                 "every kernel that reads the stream in one pass of bench.py --config 3 (one 64 Mi-sample cs16 stream): the cut-planning estimate k_tile_max and k_wave<4,...> over the verified segments, all launches"),
-    "config4": ([sys.executable, os.path.join(ROOT, "tools", "kbench.py"), "--reps", "2", "--nodevs", "--streams", "8192"], "k_wave<2", 2 * 8192 * 65536,
-                "k_wave<2,true,true>, one launch of 8192 captures x 65536 cu8 samples (what bench.py --config 4 launches eight times per step)"),
+    "config4": ([sys.executable, os.path.join(ROOT, "tools", "kbench.py"), "--reps", "2", "--nodevs", "--streams", "8192"], ("k_wave<2", "k_capture_weight"), 2 * 8192 * 65536,
+                "k_wave<2,true,true> and the look at the captures that orders its grid (k_capture_weight), one launch of 8192 captures x 65536 cu8 samples (what bench.py --config 4 launches eight times per step, and the default bench once per step)"),
     "config5": ([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "5", "--quick", "--steps", "2", "--warmup", "1"], ("k_wave<2", "k_tile_max", "k_frame_sums"), 2 * (256 << 20),
                 "every kernel that reads the stream in one pass of bench.py --config 5 (one 256 Mi-sample 2 MS/s cu8 stream, -Y autolevel): k_frame_sums (the levels of every frame have to be known before detection), k_tile_max, k_wave<2,...> over the segments"),
 }
@@ -63,7 +63,7 @@ def main():
             continue
         n_disp = len(got["FETCH_SIZE"])
         if key in ("config2", "config4"):
-            per = n_disp  # every dispatch is one launch of the workload
+            per = sum(1 for n, _, _ in got["FETCH_SIZE"] if "k_wave" in n)  # every k_wave dispatch is one launch of the workload
         else:
             per = 3  # bench.py --config 3 / 5 --steps 2 --warmup 1: three passes over the stream
         fetch_kb = sum(v for _, _, v in got["FETCH_SIZE"]) / per
