@@ -58,7 +58,6 @@ enum : uint32_t {
 };
 
 enum : uint32_t {
-    RUN_CONTINUE = 1u, // resume from StreamState instead of a reset flow
     RUN_NOFLUSH = 2u,  // do not issue the end-of-input flush call
     RUN_ENV_RAW16 = 4u, // filters-only launches: the input is a u16 envelope (2 B/sample), not IQ (baseband_low_pass_filter's x_buf)
     // profiling aids (env R433_DEBUG_FLAGS, never set by the product path): stop after a phase
