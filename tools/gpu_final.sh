@@ -23,5 +23,9 @@ import json,sys
 d=json.load(open('$OUT/bench_c$c.json')); print('config $c:', d['value'], d['unit'], d['ms_per_step'], d.get('roofline',{}).get('frac'), d.get('parity'))"; done
 echo "== CLI drop-in"
 timeout 600 tools/cli_bench.sh 1024 $OUT 2>&1 | tail -3
+echo "== the C pipeline host"
+timeout 300 bash tools/pipeline_host_bench.sh 8192 2>&1 | tail -9 | tee $OUT/pipeline_host.txt
+echo "== probes: PCIe link, a pass beside a copy, capture order inside a grid"
+{ timeout 120 python tools/pcie_probe.py; timeout 120 python tools/overlap_probe.py; timeout 120 python tools/order_probe.py 8192; } 2>&1 | grep -v amdgpu.ids | tee $OUT/probes.txt
 echo "== fuzz (GPU, 8000 cases)"
 timeout 1500 python tools/fuzz_emu.py --gpu 8000 90000 2>&1 | tail -1 | tee $OUT/fuzz.txt
