@@ -170,6 +170,7 @@ int r433_batch_debug_state(r433_batch *b, void *host_buf, size_t bytes);
 #define R433_DEBUG_NO_PRIO 16384u     /* the consumer wavefront keeps the default issue priority (A/B timing) */
 #define R433_DEBUG_PAIR 32768u        /* a producer / consumer pair per capture also in launches of more than 1280 captures */
 #define R433_DEBUG_ONE_WAVE 4096u /* one wavefront per capture instead of a producer / consumer pair: same results, for A/B timing */
+#define R433_DEBUG_STATIC_SLICE 65536u /* slicer workgroups take their packages at fixed strides instead of heaviest first from a shared cursor (A/B timing) */
 #define R433_DEBUG_NO_TRAIN_ENGINE 2048u /* in-package legs through the older per-leg code: same results, for A/B timing */
 int r433_batch_set_debug(r433_batch *b, uint32_t flags);
 int r433_batch_get_timing(r433_batch *b, r433_batch_timing *t);

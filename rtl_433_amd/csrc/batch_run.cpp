@@ -627,7 +627,8 @@ int run_slice_and_mirror(RunCtx &r)
             || (rc = b->d_rec_bytes.ensure(max_pkgs)) || (rc = b->d_rec_off.ensure(max_pkgs))
             || (rc = b->d_pkg_bytes.ensure(max_pkgs)) || (rc = b->d_pkg_off.ensure(max_pkgs))
             || (rc = b->d_sizes.ensure((size_t)max_pkgs * std::max<uint32_t>(n_devs, 1)))
-            || (rc = b->d_dev_off.ensure((size_t)max_pkgs * std::max<uint32_t>(n_devs, 1))))
+            || (rc = b->d_dev_off.ensure((size_t)max_pkgs * std::max<uint32_t>(n_devs, 1)))
+            || (rc = b->d_pkg_order.ensure(max_pkgs)) || (rc = b->d_slice_cursor.ensure(std::max<size_t>(b->rows.size() / 64, 1))))
         return rc;
 
     launch_directory(b->d_arena.p, b->arena_stride, b->d_state.p, r.split ? b->d_order.p : nullptr, r.n_order, b->d_pkg_base.p,
@@ -652,6 +653,11 @@ int run_slice_and_mirror(RunCtx &r)
     lp.pkg_bytes = b->d_pkg_bytes.p;
     lp.pkg_off = b->d_pkg_off.p;
     lp.max_pkgs = max_pkgs;
+    if (!(b->debug_flags & R433_DEBUG_STATIC_SLICE)) {
+        lp.draw = 1;
+        lp.pkg_order = b->d_pkg_order.p;
+        lp.cursor = b->d_slice_cursor.p;
+    }
     bool placed = false; // the event records are in d_events already (large batches: stretch by stretch)
     lp.pkg_begin = 0;
     lp.pkg_end = max_pkgs;

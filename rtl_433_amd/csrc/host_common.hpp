@@ -212,6 +212,7 @@ struct r433_batch {
     PinBuf<StreamState> h_state;
     uint32_t last_segments = 0, last_redone = 0;
     DevBuf<uint32_t> d_dir_stream, d_dir_off, d_rec_bytes, d_rec_off, d_sizes, d_dev_off, d_pkg_bytes, d_pkg_off;
+    DevBuf<uint32_t> d_pkg_order, d_slice_cursor; // the sizing pass of the slicers: packages heaviest first, a cursor per chunk of devices
     DevBuf<uint8_t> d_pkg_blob, d_events, d_stage, d_converted;
     DevBuf<r433_analysis> d_analysis;
     std::vector<uint32_t> conv_bytes;

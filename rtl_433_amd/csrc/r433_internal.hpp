@@ -156,6 +156,10 @@ struct SliceParams {
     uint32_t pkg_begin, pkg_end; // the packages of this launch: [pkg_begin, min(pkg_end, *n_pkgs)); staging slots count from pkg_begin
     uint8_t const *pf_tables;   // pre-filter (r433_batch_probe_prefilter), or nullptr
     uint32_t *pf_counts;        // [orig dev][5]: records the filter dropped, by failure code
+    // the sizing pass draws its items from a cursor, the heavy packages first (k_slice; launch_slice_count fills both arrays)
+    uint32_t draw;              // 0: fixed strides
+    uint32_t *pkg_order;        // the packages of this launch by pulse count, descending
+    uint32_t *cursor;           // [n_rows / 64] next entry of pkg_order per chunk of devices
 };
 
 // `order` (may be null = identity) lists the wavefront slots (whole captures or the chosen segments of split

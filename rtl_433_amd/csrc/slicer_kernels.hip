@@ -58,7 +58,34 @@ template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
     uint8_t const *const pf_tab = (p.pf_tables && my_pf >= 0) ? p.pf_tables + (uint64_t)my_pf * kPfTable : nullptr;
     uint32_t dropped0 = 0, dropped1 = 0, dropped2 = 0, dropped3 = 0, dropped4 = 0;
 
-    for (uint32_t pkg = p.pkg_begin + blockIdx.x / chunks; pkg < n_pkgs; pkg += gridDim.x / chunks) {
+    // Which package next.  The placing pass takes fixed strides (a copy per record: even work).  The sizing pass is a lane per
+    // device walking the package's pulses, and its items differ by two orders of magnitude (a 1200-pulse package under a PCM
+    // slicer against a short one that fails the first timing test): at fixed strides the launch lasted eight times the mean
+    // life of its wavefronts (SQ_WAVE_CYCLES / SQ_BUSY_CYCLES: 1.6 wavefronts resident per SIMD, profiles/r03_slice_pmc.txt).
+    // So the workgroups of a chunk of devices DRAW their packages from the chunk's cursor over the packages sorted by pulse
+    // count (k_pkg_order, which also rewinds the cursors): every chunk's long items begin at once, whoever is free takes the
+    // next, and a chunk whose list has run dry lets its later workgroups go at once, so the chunks with the expensive slicers
+    // end up with more of the chip.  8192 bench packages x 335 decoders: 3.70 -> 3.04 ms; a launch of 1024 lasts as long as its
+    // longest item either way (0.53 ms).  One cursor over (chunk, package) -- the whole chip on one chunk at a time, a workgroup
+    // changing devices as it goes -- was slower (3.24 ms; 0.62 ms for 1024): the expensive chunks' long items then begin late.
+    bool const drawn = !PLACE && p.draw != 0;
+    uint32_t const n_mine = n_pkgs > p.pkg_begin ? n_pkgs - p.pkg_begin : 0u;
+    for (uint32_t it = blockIdx.x / chunks;; it += gridDim.x / chunks) {
+        uint32_t pkg;
+        if (drawn) {
+            uint32_t i = 0;
+            if (lane == 0)
+                i = atomicAdd(&p.cursor[chunk], 1u);
+            i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+            if (i >= n_mine)
+                break;
+            pkg = p.pkg_order[i];
+        }
+        else {
+            pkg = p.pkg_begin + it;
+            if (pkg >= n_pkgs)
+                break;
+        }
         uint8_t const *rec = p.arena + (uint64_t)p.dir_stream[pkg] * p.arena_stride + p.dir_off[pkg];
         uint32_t const type = ((uint32_t const *)rec)[2];
         uint32_t const num = min(((uint32_t const *)rec)[3], (uint32_t)R433_PD_MAX_PULSES);
@@ -193,6 +220,37 @@ template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
     }
 }
 
+// The packages [pkg_begin, n) by pulse count, descending: a counting sort in one workgroup (a launch has a few thousand
+// packages; pulse counts go up to 1200, five to a bucket).  Also rewinds the cursors of the sizing pass that follows.
+__global__ __launch_bounds__(256) void k_pkg_order(uint8_t const *arena, uint32_t arena_stride, uint32_t const *dir_stream,
+        uint32_t const *dir_off, uint32_t const *n_pkgs_ptr, uint32_t max_pkgs, uint32_t pkg_begin, uint32_t pkg_end,
+        uint32_t *order, uint32_t *cursor, uint32_t chunks)
+{
+    __shared__ uint32_t count[256], first[256];
+    uint32_t const n_pkgs = min(min(*n_pkgs_ptr, max_pkgs), pkg_end);
+    auto weight = [&](uint32_t pkg) -> uint32_t {
+        uint32_t const num = ((uint32_t const *)(arena + (uint64_t)dir_stream[pkg] * arena_stride + dir_off[pkg]))[3];
+        return min(num / 5u, 255u);
+    };
+    count[threadIdx.x] = 0;
+    for (uint32_t c = threadIdx.x; c < chunks; c += 256)
+        cursor[c] = 0;
+    __syncthreads();
+    for (uint32_t pkg = pkg_begin + threadIdx.x; pkg < n_pkgs; pkg += 256)
+        atomicAdd(&count[weight(pkg)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int w = 255; w >= 0; --w) {
+            first[w] = run;
+            run += count[w];
+        }
+    }
+    __syncthreads();
+    for (uint32_t pkg = pkg_begin + threadIdx.x; pkg < n_pkgs; pkg += 256)
+        order[atomicAdd(&first[weight(pkg)], 1u)] = pkg;
+}
+
 // Where each device's records of a package begin inside the package's stretch of the event stream: the exclusive prefix
 // of sizes[pkg][.] in registration order, once per package (every (package, 64 devices) item of the placing pass needs
 // one entry of it; computed inside that pass it was six dependent load + scan rounds per item, most of the pass).
@@ -268,6 +326,9 @@ uint32_t slice_grid(uint32_t grid_pkgs, uint32_t n_rows)
 // (grid_pkgs: the packages of THIS launch, p.pkg_end - p.pkg_begin or fewer)
 void launch_slice_count(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st)
 {
+    if (p.draw)
+        hipLaunchKernelGGL(k_pkg_order, dim3(1), dim3(256), 0, st, p.arena, p.arena_stride, p.dir_stream, p.dir_off, p.n_pkgs, p.max_pkgs,
+                p.pkg_begin, p.pkg_end, p.pkg_order, p.cursor, p.n_rows / 64 ? p.n_rows / 64 : 1u);
     if (p.stage)
         hipLaunchKernelGGL(k_slice<M_STAGE>, dim3(slice_grid(grid_pkgs, p.n_rows)), dim3(64), 0, st, p);
     else

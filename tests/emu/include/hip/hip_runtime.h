@@ -176,7 +176,7 @@ static inline uint32_t __builtin_amdgcn_mbcnt_hi(uint32_t mask, uint32_t add)
     return add + (uint32_t)__builtin_popcount(m);
 }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
-static inline int __mul24(int a, int b) { return (int)((uint32_t)((a << 8) >> 8) * (uint32_t)((b << 8) >> 8)); }
+static inline int __mul24(int a, int b) { return (int)((uint32_t)((int)((uint32_t)a << 8) >> 8) * (uint32_t)((int)((uint32_t)b << 8) >> 8)); }
 static inline long long clock64() { return 0; }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
