@@ -11,6 +11,18 @@ std::mutex g_detect_turn;
 // ---- r433_batch_run, stage by stage --------------------------------------------------------------
 namespace {
 
+// R433_TRACE_LEGS=1: one stderr line per stage of a pass with the monotonic clock in milliseconds (the clock Python's
+// time.monotonic() reads), so that a host which keeps several engines in flight can lay its own stamps beside them
+// (tools/leg_timeline.py).  Off: one read of a static flag per stamp.
+void leg_stamp(r433_batch const *b, char const *what)
+{
+    static int const on = getenv("R433_TRACE_LEGS") != nullptr;
+    if (on) {
+        double const ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        fprintf(stderr, "r433-leg %p %s %.3f\n", (void const *)b, what, ms);
+    }
+}
+
 // What one r433_batch_run call carries from stage to stage.
 struct RunCtx {
     std::unique_lock<std::mutex> turn{g_detect_turn, std::defer_lock}; // exclusive_detect: this pass's turn on the detection kernel
@@ -554,8 +566,10 @@ int run_detect(RunCtx &r)
     // the calling thread waits for the detection kernel below anyway (it needs the package count): holding the turn until
     // then keeps two engines' detection kernels from running side by side
     std::unique_lock<std::mutex> &turn = r.turn;
+    leg_stamp(b, "enter");
     if (b->exclusive_detect) {
         turn.lock();
+        leg_stamp(b, "turn");
         if (b->profiling) // the time spent waiting for the turn is not the kernel's
             HIP_TRY(hipEventRecord(b->ev[0], r.st));
     }
@@ -600,6 +614,7 @@ int run_detect(RunCtx &r)
         HIP_TRY(hipMemcpyAsync(b->h_scal.p, b->d_scal.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, r.st));
         HIP_TRY(stream_wait(b, r.st));
         r.total_pkgs = b->h_scal.p[0];
+        leg_stamp(b, "detected");
         if (!b->h_scal.p[1])
             break;
         if (attempt >= 6 || b->arena_stride > (1u << 28))
@@ -785,6 +800,7 @@ int run_slice_and_mirror(RunCtx &r)
     if (r.turn.owns_lock() && b->exclusive_detect < 3) { // exclusive level 2: the kernels of this pass are done before the next engine's begin
         HIP_TRY(stream_wait(b, r.st));
         r.turn.unlock();
+        leg_stamp(b, "sliced");
     }
     if (pkg_bytes)
         HIP_TRY(hipMemcpyAsync(b->h_pkg_blob.p, b->d_pkg_blob.p, pkg_bytes, hipMemcpyDeviceToHost, r.st));
@@ -806,6 +822,7 @@ int run_slice_and_mirror(RunCtx &r)
     HIP_TRY(stream_wait(b, r.st));
     if (r.turn.owns_lock()) // exclusive level 3: the record copies, too, have the device to themselves
         r.turn.unlock();
+    leg_stamp(b, "mirrored");
     b->pkg_bytes = pkg_bytes;
     if (b->arena_growth > 1) { // (see arena_growth: a grown stride is given back when the captures stopped needing it)
         uint64_t const slots = std::max<uint32_t>(1u, r.split ? r.n_order : r.n_streams);
