@@ -153,7 +153,8 @@ int r433_batch_set_profiling(r433_batch *b, int on);
 /* Debugging aid: raw per-capture kernel state of the last run (n_streams records; returns the record size).
  * With R433_DEBUG_TIMING (r433_batch_set_debug) the detection kernel leaves per-phase clock ticks in it (tools/kbench.py). */
 int r433_batch_debug_state(r433_batch *b, void *host_buf, size_t bytes);
-/* Development switches, off unless asked for here (no environment variable changes what the library computes).
+/* Development switches, off unless asked for here (no environment variable changes what the library computes;
+ * R433_TRACE_LEGS=1 only makes r433_batch_run print the stages of a pass with the monotonic clock to stderr).
  * The first three never change results; SKIP_* leave the results of a run INCOMPLETE (kernel timing experiments). */
 #define R433_DEBUG_SPLIT_BLIND 1u      /* split captures at fixed distances instead of where they look idle (tests) */
 #define R433_DEBUG_TWO_PASS_SLICER 2u  /* count + write slicer passes instead of staging slots */
