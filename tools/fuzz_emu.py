@@ -145,6 +145,10 @@ def one_case(seed, run=None):
     form = (0, 4096, 32768)[seed % 3]  # the launch's own choice / R433_DEBUG_ONE_WAVE / R433_DEBUG_PAIR: both forms of the detection kernel
     if seed % 4 == 1:
         form |= 128  # R433_DEBUG_FORCE_ORDER: the workgroups take the captures heaviest first (a list made on the device)
+    if seed % 5 == 2:
+        form |= 8  # R433_DEBUG_SMALL_STRETCH: the slicer fan-out three packages at a time (cursors rewound per stretch)
+    if seed % 7 == 3:
+        form |= 65536  # R433_DEBUG_STATIC_SLICE: slicer workgroups at fixed strides instead of drawing from the cursors
     g = run(caps, ss, rate, devs, fpdm=fpdm, taps=True, enable_fm=enable_fm, split=split, debug=blind | form,
             **(dict(kw, input_format=2 + load_format) if load_format else kw))
     cfg = po.default_flow_cfg(ss, rate, fpdm=fpdm, enable_fm=enable_fm, load_format=load_format, **kw)
