@@ -39,14 +39,20 @@ static void quiet_log(log_level_t level, char const *src, char const *msg, void 
 static void take_message(r_device *decoder, data_t *data)
 {
     r433p *h = decoder->output_ctx;
-    if (h->cap - h->len < 8192) {
-        h->cap  = h->cap ? h->cap * 2 : 65536;
+    char *line = data_print_jsons_dup(data); /* grows until the whole document fits: never a truncated line */
+    if (!line)
+        abort();
+    size_t const n = strlen(line);
+    if (h->cap - h->len < n + 2) {
+        while (h->cap - h->len < n + 2)
+            h->cap = h->cap ? h->cap * 2 : 65536;
         h->text = realloc(h->text, h->cap);
         if (!h->text)
             abort();
     }
-    size_t n = data_print_jsons(data, h->text + h->len, h->cap - h->len - 2);
-    h->len += n < h->cap - h->len - 2 ? n : strlen(h->text + h->len);
+    memcpy(h->text + h->len, line, n);
+    free(line);
+    h->len += n;
     h->text[h->len++] = '\n';
     h->text[h->len]   = '\0';
     h->messages += 1;

@@ -114,6 +114,8 @@ static struct {
     hip_engine engines[HIP_ENGINES];
     hip_engine *cur;
     unsigned long eng_clock;
+    size_t probe_devs;  /* the decoder set the process-wide probe memory of the library was filled from */
+    void *probe_first;
     uint8_t *stage; /* pinned */
     size_t stage_cap, stage_len;
     size_t staged_total; /* bytes of samples this process has taken so far (engine_prefilter) */
@@ -526,6 +528,14 @@ static void engine_ensure(r_cfg_t *cfg, r433_flow_cfg const *fc)
     }
     r433_batch_destroy(slot->eng);
     memset(slot, 0, sizeof(*slot));
+    /* another set of decoders than the engines so far were made for (decoders registered or freed in between): what the
+       pre-filter probe remembers about decoder objects may describe objects that are gone */
+    if (H.probe_devs != demod->r_devs.len || H.probe_first != first) {
+        if (H.probe_first)
+            r433_prefilter_forget();
+        H.probe_devs  = demod->r_devs.len;
+        H.probe_first = first;
+    }
     size_t n              = demod->r_devs.len;
     r433_dev_timing *rows = calloc(n ? n : 1, sizeof(*rows));
     if (!rows)

@@ -172,6 +172,7 @@ int r433_batch_debug_state(r433_batch *b, void *host_buf, size_t bytes);
 #define R433_DEBUG_PAIR 32768u        /* a producer / consumer pair per capture also in launches of more than 1280 captures */
 #define R433_DEBUG_ONE_WAVE 4096u /* one wavefront per capture instead of a producer / consumer pair: same results, for A/B timing */
 #define R433_DEBUG_STATIC_SLICE 65536u /* slicer workgroups take their packages at fixed strides instead of heaviest first from a shared cursor (A/B timing) */
+#define R433_DEBUG_NO_LAZY 262144u /* the detection kernel filters every tile, also those that provably cannot move the detector: same results, for A/B timing */
 #define R433_DEBUG_NO_TRAIN_ENGINE 2048u /* in-package legs through the older per-leg code: same results, for A/B timing */
 int r433_batch_set_debug(r433_batch *b, uint32_t flags);
 int r433_batch_get_timing(r433_batch *b, r433_batch_timing *t);
@@ -246,6 +247,11 @@ int r433_batch_decoded(r433_batch *b, int const **per_package, uint32_t *count);
  * (~50 000, outside account_event: no statistics move); a decoder that keeps state between calls must not let that state
  * decide its length test.  Returns the number of decoders with at least one provable refusal. */
 int r433_batch_probe_prefilter(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices);
+/* What the decoders answered is remembered for the life of the process (several engines over the same decoder objects ask
+ * once), keyed by the decoder object, its decode_fn / decode_ctx pointers, protocol number, line code, timings and name.  A
+ * host that frees decoders, or changes what lies behind a decode_ctx, calls this before the next probe: everything known
+ * is forgotten (engines keep the tables they already have until they are probed again). */
+void r433_prefilter_forget(void);
 /* on = 0 turns the learned tables off again (records flow as without a probe), 1 back on */
 int r433_batch_set_prefilter(r433_batch *b, int on);
 /* of the last run: records dropped on the device, counts[device * 5 + code] with code = -(decode_fn return) in 0..4 */

@@ -345,7 +345,7 @@ StreamParams stream_params(RunCtx const &r)
     sp.n_streams = r.n_planned;
     sp.frame_samples = b->cfg.frame_samples;
     sp.flags = b->cfg.input_format == R433_IN_S16_AM ? RUN_AM_IS_INPUT : b->cfg.input_format == R433_IN_S16_FM ? RUN_FM_IS_INPUT : 0u;
-    sp.flags |= b->debug_flags & (RUN_DBG_SKIP_DETECT | RUN_DBG_SKIP_FILTERS | RUN_DBG_TIMING | RUN_NO_TRAIN_ENGINE | RUN_ONE_WAVE | RUN_NO_ROLE_SWAP | RUN_NO_PRIO | RUN_PAIR); // r433_batch_set_debug
+    sp.flags |= b->debug_flags & (RUN_DBG_SKIP_DETECT | RUN_DBG_SKIP_FILTERS | RUN_DBG_TIMING | RUN_NO_TRAIN_ENGINE | RUN_ONE_WAVE | RUN_NO_ROLE_SWAP | RUN_NO_PRIO | RUN_PAIR | RUN_NO_LAZY); // r433_batch_set_debug
     sp.det = b->det;
     sp.use_mag = (int)b->cfg.use_mag_est;
     sp.enable_fm = (int)b->cfg.enable_fm;
@@ -745,8 +745,10 @@ int run_slice_and_mirror(RunCtx &r)
                 HIP_TRY(hipMemcpyAsync(b->h_scal.p, b->d_scal.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, r.st));
                 HIP_TRY(stream_wait(b, r.st));
                 size_t const total = b->h_scal.p[3];
-                if (total + 16 <= b->d_events.cap || total > 0xf0000000ull || round >= 2)
+                if (total + 16 <= b->d_events.cap || total > 0xf0000000ull)
                     break;
+                if (round >= 2) // sizes are a function of the packages: a third round cannot differ from the second
+                    return fail(R433_EOVERFLOW, "event records (%zu bytes) do not fit the buffer sized for them (%zu)", total, b->d_events.cap);
                 want = total + total / 8 + 16;
             }
             placed = true;

@@ -241,6 +241,11 @@ void r433_batch_destroy(r433_batch *b)
     b->d_tile_max.release();
     b->d_order.release();
     b->d_wg.release();
+    b->d_pkg_order.release();
+    b->d_slice_cursor.release();
+    b->d_pf_tables.release();
+    b->d_pf_counts.release();
+    b->h_pf_counts.release();
     b->d_segs.release();
     b->h_tile_max.release();
     b->h_state.release();

@@ -14,6 +14,7 @@
 #include <climits>
 #include <csetjmp>
 #include <map>
+#include <string>
 #include <tuple>
 #include <csignal>
 
@@ -133,17 +134,20 @@ struct Fence {
     void ask_run(r433_r_device *dev, unsigned rows, unsigned from, unsigned to, unsigned step, int *out)
     {
         uint16_t *head = (uint16_t *)bits;
-        head[0] = (uint16_t)rows;
-        head[1] = (uint16_t)rows;
         volatile unsigned cur = from; // (lives across the jump)
+        g_asks.fetch_add((to - from + step - 1) / step, std::memory_order_relaxed); // (once per run, whatever faults)
         if (sigsetjmp(t_jump, 0) != 0) {
             out[(cur - from) / step] = INT_MIN;
             cur = cur + step;
         }
         t_armed = 1;
-        g_asks.fetch_add((to - from + step - 1) / step, std::memory_order_relaxed);
         for (; cur < to; cur = cur + step) {
             unsigned const c = cur;
+            // the whole head before every question: a decoder may have written to the readable words before it refused
+            // (or faulted).  Decoders that allocate before their first look at the bitbuffer would leak on a fault: none
+            // of the reference's does; document it for third-party ones.
+            head[0] = (uint16_t)rows;
+            head[1] = (uint16_t)rows;
             head[2] = (uint16_t)c;
             out[(c - from) / step] = dev->decode_fn(dev, bits);
         }
@@ -159,9 +163,25 @@ std::mutex g_probe_lock; // signal dispositions are the process's
 struct ProbeKey {
     void const *dev, *fn, *ctx;
     int verbose;
+    // ... and what tells one decoder from another that later lives at the same addresses (a decoder freed and another
+    // registered in its place; flex decoders, which share one decode_fn): its number, line code, timings and name.  What sits
+    // BEHIND decode_ctx cannot be seen from here: a host that changes it calls r433_prefilter_forget.
+    unsigned protocol_num, modulation;
+    uint32_t timing[6];
+    std::string name;
+    static ProbeKey of(r433_r_device const *d)
+    {
+        ProbeKey k{d, (void const *)d->decode_fn, d->decode_ctx, d->verbose, d->protocol_num, d->modulation, {0, 0, 0, 0, 0, 0},
+                std::string(d->name ? d->name : "")};
+        float const t[6] = {d->short_width, d->long_width, d->reset_limit, d->gap_limit, d->sync_width, d->tolerance};
+        memcpy(k.timing, t, sizeof(t));
+        return k;
+    }
     bool operator<(ProbeKey const &o) const
     {
-        return std::tie(dev, fn, ctx, verbose) < std::tie(o.dev, o.fn, o.ctx, o.verbose);
+        return std::tie(dev, fn, ctx, verbose, protocol_num, modulation, timing[0], timing[1], timing[2], timing[3], timing[4], timing[5], name)
+                < std::tie(o.dev, o.fn, o.ctx, o.verbose, o.protocol_num, o.modulation, o.timing[0], o.timing[1], o.timing[2], o.timing[3],
+                        o.timing[4], o.timing[5], o.name);
     }
 };
 std::map<ProbeKey, std::vector<uint8_t>> g_known;
@@ -346,7 +366,7 @@ int r433_batch_probe_prefilter(r433_batch *b, r433_r_device *const *devices, uin
         if (!dev || !dev->decode_fn || dev->verbose || b->timing[d].priority != lowest)
             continue;
         eligible[d] = 1;
-        keys[d] = ProbeKey{dev, (void const *)dev->decode_fn, dev->decode_ctx, dev->verbose};
+        keys[d] = ProbeKey::of(dev);
         if (g_known.find(keys[d]) == g_known.end()) {
             bool twice = false; // (one decoder object registered twice is asked once)
             for (uint32_t o : ask_list)
@@ -413,6 +433,12 @@ int r433_batch_probe_prefilter(r433_batch *b, r433_r_device *const *devices, uin
         HIP_TRY(hipMemcpy(b->d_rows.p, b->rows.data(), b->rows.size() * sizeof(DevRow), hipMemcpyHostToDevice));
     b->pf_on = filtered > 0;
     return filtered;
+}
+
+void r433_prefilter_forget(void)
+{
+    std::lock_guard<std::mutex> guard(g_probe_lock);
+    g_known.clear();
 }
 
 int r433_batch_set_prefilter(r433_batch *b, int on)

@@ -71,6 +71,7 @@ enum : uint32_t {
     RUN_PAIR = 32768u,        // development: a producer / consumer pair per capture whatever the launch size
     RUN_ONE_WAVE = 4096u, // development: one wavefront per capture does phases A+B and C in turn (A/B timing, same results)
     RUN_NO_TRAIN_ENGINE = 2048u, // development: in-package legs through the older per-leg code (A/B timing, same results)
+    RUN_NO_LAZY = 262144u,       // development: every tile filtered, also the ones that provably cannot move the detector (A/B timing, same results)
 };
 
 struct StreamParams {

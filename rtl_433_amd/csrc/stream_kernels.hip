@@ -54,6 +54,9 @@ constexpr int kRows = kTile / kRow;
 constexpr int kPitch16 = kChunk * 2 + 16;  // LDS pitch of a chunk of 16-bit samples: conflict-free b128 per lane
 constexpr int kPitch32 = kChunk * 4 + 16;
 constexpr int kFloorWindow = 1024;          // samples a later segment of a split capture walks to find its noise floor
+constexpr int kVirtual = 4 * kChunk;        // samples at the start of a filtered tile that follows unfiltered ones: bounds only
+constexpr int kHead = 512;                  // ... and how far into the next tile a tile looks before it goes unfiltered (one row)
+constexpr int kQuietTile = (int)0x80000000, kPostQuiet = 0x40000000;
 constexpr int kPitchOut = kChunk * 2;       // filtered samples: time-linear, read by sample index (the padded pitch buys
                                              // nothing there and 8 wavefronts' LDS must fit one CU: 8 x 20 KB = 160 KB)
 
@@ -73,6 +76,13 @@ __device__ __forceinline__ int wave_sum(int v)
 {
     for (int o = 32; o > 0; o >>= 1)
         v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ int wave_max(int v)
+{
+    for (int o = 32; o > 0; o >>= 1)
+        v = max(v, __shfl_xor(v, o, 64));
     return v;
 }
 
@@ -315,6 +325,12 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
     // producer -> consumer, per buffer: the establishing tile could not be proven
     auto st_pflag = [&](int buf) -> int & { return *(int *)(s_env + buf * kPitch16 + 2 * kChunk + 8); };
     int &s_pover = *(int *)(s_env + 2 * kPitch16 + 2 * kChunk + 8); // producer -> consumer: a filter carry was refused (det.overflow codes 2, 3)
+    // Lazy tiles (see `lazy_cfg` below).  producer -> consumer, per buffer: how the tile comes -- kQuietTile | bound: no
+    // samples at all, only an upper bound of its filtered envelope; kPostQuiet | bound: filtered samples from sample
+    // kVirtual on, a bound for the ones before; 0: as ever.
+    auto st_desc = [&](int buf) -> int & { return *(int *)(s_env + (3 + buf) * kPitch16 + 2 * kChunk + 8); };
+    // either role -> both, by the parity of the barrier that will publish it: run the capture again with every tile filtered
+    auto st_retry = [&](int parity) -> int & { return *(int *)(s_env + (5 + parity) * kPitch16 + 2 * kChunk + 8); };
 
     int const lane = (int)threadIdx.x & 63;
     int const wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6); // (a scalar: the role branches below are scalar branches)
@@ -329,8 +345,13 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                                           : (wave ^ ((p.flags & RUN_NO_ROLE_SWAP) ? 0 : (int)(blockIdx.x & 1u)));
     if (!solo && role != 0 && !(p.flags & RUN_NO_PRIO))
         __builtin_amdgcn_s_setprio(3);
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
         s_pover = 0;
+        st_desc(0) = st_desc(1) = 0;
+        st_retry(0) = st_retry(1) = 0;
+    }
+    if (!solo)
+        __syncthreads(); // (whichever wavefront produces may raise these flags in its first tile)
     // workgroup = one capture, or one piece of a split capture (in both parity variants: consumers 1 and 2 of a triple)
     uint32_t const wg = p.wg_slot ? p.wg_slot[blockIdx.x] : blockIdx.x;
     bool const idle = FORM == 3 && role == 2 && !(wg >> 31); // a triple whose piece has one variant only: the third wavefront just keeps the barriers
@@ -360,35 +381,89 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
     // the FSK ring (detect_device.hpp).
     DetLane det;
     DetCfg cfg = p.det; // min_high follows p.frame_min_high per frame when -Y autolevel is on
-    det_reset(det);
-    det.arena = p.arena + (uint64_t)s * p.arena_stride;
-    det.fsk_ring = p.fsk_ring + (uint64_t)s * R433_PD_MAX_PULSES; // HBM scratch, touched by lane 0 on FSK pulses only
-    det.arena_cap = p.arena_stride;
-    det.stream = cap;
-    det.writer = lane == 0;
-    det.cursor = 0;
-    det.ook_base = 0;
-    det.n_pkgs = 0;
-    det.overflow = 0;
-    uint32_t frame = seg_start / F;
-    uint64_t input_pos = (uint64_t)frame * F;
-    int dc = (int)(seg_start - frame * F);
-    int flen = (int)min(my_n - frame * F, F); // only meaningful when the segment starts inside a frame
-    if (!seg_first)
-        det.lead_in = 1025; // saturated for good after the first 1025 idle samples of a capture
-    if (p.frame_min_high) // -Y autolevel: the level of the frame the segment starts in
-        cfg.min_high = p.frame_min_high[(uint64_t)cap * p.frames_cap + min(frame, p.frames_cap - 1)];
-
+    uint32_t frame;
+    uint64_t input_pos;
+    int dc, flen;
     // ---- filter carries across tiles (wave-uniform) ----
-    int carry_ya = 0, carry_xa = 0; // AM low-pass: y[-1], x[-1]
-    int carry_yf = 0, carry_ff = 0; // FM low-pass: y[-1], discriminator[-1]
-    int carry_i = 0, carry_q = 0;   // last IQ sample, centred
-    if (SEAM && p.seam_init) { // a frame that continues a stream: filter_state_t / demodfm_state_t of the caller
-        carry_ya = p.seam_init[0], carry_xa = p.seam_init[1];
-        carry_yf = p.seam_init[2], carry_ff = p.seam_init[3];
-        carry_i = p.seam_init[4], carry_q = p.seam_init[5];
-    }
-    int seam_end[4] = {carry_ya, carry_xa, carry_yf, carry_ff}; // SEAM: the carries after the last sample
+    int carry_ya, carry_xa; // AM low-pass: y[-1], x[-1]
+    int carry_yf, carry_ff; // FM low-pass: y[-1], discriminator[-1]
+    int carry_i, carry_q;   // last IQ sample, centred
+    int seam_end[4];        // SEAM: the carries after the last sample
+
+    // ---- Lazy tiles.  A tile whose raw envelope -- with the 128 samples before it and the first row of the tile after it --
+    // stays below every level at which the detector could start, hold or end a pulse (quiet_bound) cannot change the state
+    // machine beyond what counting does: the filtered envelope is a convex mix of the raw one (a + 2b <= 1, floor), so 96
+    // samples into such a stretch it is below that level too, a pulse that was open has ended, its debounce is over, and the
+    // detector idles or counts a gap.  The producer then skips both filters and the discriminator (4/5 of its instructions go
+    // with them) and hands over a bound instead of samples; the consumer counts -- the gap, or the steps of the noise floor,
+    // which it evaluates lazily anyway (resolve_low) and now carries across such tiles.  The filter carries stay exact
+    // through a tile of identical samples (digital silence: iterate the one map to its fixed point); after any other quiet
+    // tile they are established again over the next filtered tile's first kVirtual samples (two tracks, as every chunk's
+    // are), which the consumer still takes by their bound.  What cannot be carried exactly -- a floor walk that does not meet
+    // in the samples it has, carries that do not settle, |am - low| out of the +-1 regime -- raises st_retry and the whole
+    // capture runs again with every tile filtered: nothing is ever published from an assumption.
+    // Off for split captures (their pieces are verified against each other by the host), the function seam, taps, the logic
+    // dump, sample files that are not IQ, filters outside the FAST class, frames that are not whole tiles.
+    bool const lazy_cfg = !SEAM && FAST && FORM != 3 && !p.segs && !p.tap_env && !p.tap_am && !p.logic && F % (uint32_t)kTile == 0
+            && !(p.flags & (RUN_NO_LAZY | RUN_DBG_SKIP_FILTERS | RUN_DBG_SKIP_DETECT | RUN_AM_IS_INPUT | RUN_FM_IS_INPUT | RUN_ENV_RAW16));
+    bool lazy = lazy_cfg;        // this attempt
+    int attempts = 0, n_quiet = 0;
+    uint32_t sums_done = tile_first; // tiles whose frame sums are in p.frame_sums (a second attempt must not add them again)
+    int retry_slot = 0;          // parity of the barrier the running tile ends at
+    // producer side
+    bool carry_known = true;     // carry_ya / carry_yf are the exact filter states (the other four always are)
+    bool prev_quiet = false;     // the tile before this one went by unfiltered
+    int prev_bound = 0;          // ... and no filtered sample of it exceeded this
+    int tail_max = 0;            // raw envelope maximum over the last 128 samples before the tile
+    uint32_t carry_w = 0;        // the last sample as it came (all samples of a tile equal to it: a constant tile)
+    // consumer side: pending steps of the noise floor (see resolve_low)
+    int lz_n = 0, lz_from = 0, lz_min = 0x7fffffff, lz_max = -0x7fffffff;
+    bool lz_carried = false;     // some of them over samples that never were filtered: only a two-sided walk can settle them
+    bool lz_fail = false;
+    int p_fail = 0, p_over = 0;  // producer side of seg_fail / det.overflow
+
+    auto init_run = [&]() {
+        // ---- detector: wave-uniform.  Every lane carries the same scalar state and takes the same
+        // branches, in the fast paths and in the general step alike; lane 0 alone touches the arena and
+        // the FSK ring (detect_device.hpp).
+        cfg = p.det;
+        det_reset(det);
+        det.arena = p.arena + (uint64_t)s * p.arena_stride;
+        det.fsk_ring = p.fsk_ring + (uint64_t)s * R433_PD_MAX_PULSES; // HBM scratch, touched by lane 0 on FSK pulses only
+        det.arena_cap = p.arena_stride;
+        det.stream = cap;
+        det.writer = lane == 0;
+        det.cursor = 0;
+        det.ook_base = 0;
+        det.n_pkgs = 0;
+        det.overflow = 0;
+        frame = seg_start / F;
+        input_pos = (uint64_t)frame * F;
+        dc = (int)(seg_start - frame * F);
+        flen = (int)min(my_n - frame * F, F); // only meaningful when the segment starts inside a frame
+        if (!seg_first)
+            det.lead_in = 1025; // saturated for good after the first 1025 idle samples of a capture
+        if (p.frame_min_high) // -Y autolevel: the level of the frame the segment starts in
+            cfg.min_high = p.frame_min_high[(uint64_t)cap * p.frames_cap + min(frame, p.frames_cap - 1)];
+        carry_ya = carry_xa = carry_yf = carry_ff = carry_i = carry_q = 0;
+        if (SEAM && p.seam_init) { // a frame that continues a stream: filter_state_t / demodfm_state_t of the caller
+            carry_ya = p.seam_init[0], carry_xa = p.seam_init[1];
+            carry_yf = p.seam_init[2], carry_ff = p.seam_init[3];
+            carry_i = p.seam_init[4], carry_q = p.seam_init[5];
+        }
+        seam_end[0] = carry_ya, seam_end[1] = carry_xa, seam_end[2] = carry_yf, seam_end[3] = carry_ff;
+        seg_fail = seg_init_low = seg_init_high = 0;
+        carry_known = true;
+        prev_quiet = false;
+        prev_bound = 0;
+        tail_max = 0;
+        carry_w = SS == 2 ? 0x8080u : 0u; // the centred (0, 0) the discriminator starts from
+        lz_n = lz_from = 0;
+        lz_min = 0x7fffffff, lz_max = -0x7fffffff;
+        lz_carried = lz_fail = false;
+        p_fail = p_over = 0;
+        n_quiet = 0;
+    };
 
     // profiling aid (RUN_DBG_TIMING): shader-clock ticks per phase, returned in unused StreamState slots
 #ifdef R433_KERNEL_TIMING // a development build (python -m rtl_433_amd.build --timing): the counters cost registers in the hot loops
@@ -458,9 +533,33 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
             pf[k] = v;
         }
     };
-    if (role == 0)
-        issue_loads(tile_first);
-    int p_fail = 0, p_over = 0; // producer side of seg_fail / det.overflow
+    // lazy tiles look one row past their end: row 0 of the tile after the one in `pf`
+    uint4 hd[SS == 2 ? 1 : 2];
+    auto issue_head = [&](uint32_t tile) {
+#pragma unroll
+        for (int k = 0; k < (SS == 2 ? 1 : 2); ++k) {
+            uint64_t const off = ((uint64_t)tile * kTile + (uint64_t)lane * 8) * SS + (uint64_t)k * 16;
+            uint4 v = make_uint4(0, 0, 0, 0); // (past the capture: as loud as can be for cu8, and nothing to look at anyway)
+            if (tile < n_tiles && off + 16 <= p.stride_bytes)
+                v = *(uint4 const *)(iq + off);
+            hd[k] = v;
+        }
+    };
+    // raw envelope of one sample as it came
+    auto env_of = [&](uint32_t w) -> int {
+        if (SS == 2)
+            return (int)(p.use_mag ? env_mag_cu8(w & 0xffu, (w >> 8) & 0xffu) : env_amp_cu8(w & 0xffu, (w >> 8) & 0xffu));
+        return (int)env_mag_cs16((int)(int16_t)(w & 0xffffu), (int)(int16_t)(w >> 16));
+    };
+    // No filtered sample at or below this can start, hold or end a pulse, whatever the detector's levels are: the threshold is
+    // (low + min(high, max)) / 2 with low >= -1 (the floor follows samples that are >= 0) and high >= min_high at every sample
+    // (src/pulse_detect.c:283,300-304,332-334,362-363), thr - thr / 8 grows with thr.  -1: no such level.
+    auto quiet_bound = [&](int min_high) -> int {
+        int thr = (int)(int16_t)((-1 + min(min_high, p.det.max_high)) / 2);
+        if (p.det.fixed_high != 0)
+            thr = (int)(int16_t)p.det.fixed_high;
+        return thr > 0 ? thr - (int)(int16_t)(thr / 8) - 1 : -1;
+    };
 
     // ======================================= the producer: phases A and B of one tile =======================================
     auto produce = [&](uint32_t tile, int buf) {
@@ -468,6 +567,164 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
         int const n_t = (int)min((uint32_t)kTile, seg_end - t0); // valid samples in it
         bool const warm = !seg_first && tile == tile_first;      // the establishing tile of a later segment
         uint8_t *const p_am = s_am + buf * (64 * kPitchOut), *const p_fm = s_fm + buf * (64 * kPitchOut);
+        int p_retry = 0;
+        bool const post_q = lazy && prev_quiet;  // the tile before went by unfiltered: this one's first kVirtual samples are taken by their bound
+        bool const est = lazy && !carry_known;   // ... and left the two filter states unknown: every lane warms up from extremes
+        int vbound = 0;                          // bound of those kVirtual samples
+
+        // ================= lazy tiles: a first pass over the registers, raw envelope only =================
+        if (lazy) {
+            int lmax = 0, row0 = 0, rlast = 0;
+            uint32_t lsum = 0, diff = 0;
+            uint32_t const refw = SS == 2 ? carry_w * 0x10001u : carry_w;
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) {
+                int rmax = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    uint32_t w;
+                    if (SS == 2) {
+                        uint32_t const ww[4] = {pf[r].x, pf[r].y, pf[r].z, pf[r].w};
+                        if ((j & 1) == 0)
+                            diff |= ww[j >> 1] ^ refw;
+                        w = (ww[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+                    }
+                    else {
+                        uint32_t const ww[8] = {pf[2 * r].x, pf[2 * r].y, pf[2 * r].z, pf[2 * r].w, pf[2 * r + 1].x, pf[2 * r + 1].y, pf[2 * r + 1].z, pf[2 * r + 1].w};
+                        w = ww[j];
+                        diff |= w ^ refw;
+                    }
+                    int const e = env_of(w);
+                    rmax = max(rmax, e);
+                    lsum += (uint32_t)e;
+                }
+                lmax = max(lmax, rmax);
+                if (r == 0)
+                    row0 = rmax;
+                if (r == kRows - 1)
+                    rlast = rmax;
+            }
+            int hmax = 0; // the first row of the tile after this one
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                uint32_t w;
+                if (SS == 2) {
+                    uint32_t const ww[4] = {hd[0].x, hd[0].y, hd[0].z, hd[0].w};
+                    w = (ww[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+                }
+                else {
+                    uint32_t const ww[8] = {hd[0].x, hd[0].y, hd[0].z, hd[0].w, hd[SS == 2 ? 0 : 1].x, hd[SS == 2 ? 0 : 1].y, hd[SS == 2 ? 0 : 1].z, hd[SS == 2 ? 0 : 1].w};
+                    w = ww[j];
+                }
+                hmax = max(hmax, env_of(w));
+            }
+            int E = quiet_bound(p.det.min_high);
+            if (p.frame_min_high) { // -Y autolevel: the lowest level among the frames the stretch touches
+                uint32_t const fl = p.frames_cap - 1;
+                int const *const mh = p.frame_min_high + (uint64_t)cap * p.frames_cap;
+                E = min(min(quiet_bound(mh[min(t0 ? (t0 - 1u) / F : 0u, fl)]), quiet_bound(mh[min(t0 / F, fl)])), quiet_bound(mh[min((t0 + (uint32_t)kTile) / F, fl)]));
+            }
+            bool const quiet = uni((int)(n_t == kTile && tail_max <= E && !__ballot(lmax > E || hmax > E))) != 0;
+            if (post_q) // (the head rule of the tile before this one: these samples are below its level)
+                vbound = max(prev_bound, wave_max(lane < kVirtual / 8 ? row0 : 0));
+            if (!quiet) {
+                tail_max = wave_max(lane >= 64 - 128 / 8 ? rlast : 0);
+            }
+            else {
+                int const qmax = wave_max(lmax);
+                bool const constant = !__ballot(diff != 0u); // every sample of the tile is the sample before it again
+                if (p.frame_sums && seg_primary && tile >= sums_done) { // (a tile lies in one frame: F is a multiple of the tile)
+                    int const part = wave_sum((int)lsum);
+                    uint32_t const f = t0 / F;
+                    if (lane == 0 && f < p.frames_cap)
+                        atomicAdd(&p.frame_sums[(uint64_t)cap * p.frames_cap + f], (uint32_t)part);
+                }
+                sums_done = max(sums_done, tile + 1u);
+                // the four carries that are plain samples: the last sample, its envelope, its discriminator value
+                uint32_t const w7 = SS == 2 ? pf[kRows - 1].w >> 16 : pf[2 * kRows - 1].w;
+                uint32_t const w6 = SS == 2 ? pf[kRows - 1].w & 0xffffu : pf[2 * kRows - 1].z;
+                int f_last = 0;
+                if (FM) {
+                    int ci, cq, pi_, pq_;
+                    if (SS == 2) {
+                        ci = (int)(w7 & 0xffu) - 128, cq = (int)((w7 >> 8) & 0xffu) - 128;
+                        pi_ = (int)(w6 & 0xffu) - 128, pq_ = (int)((w6 >> 8) & 0xffu) - 128;
+                        f_last = atan2_q15(cq * pi_ - ci * pq_, ci * pi_ + cq * pq_);
+                    }
+                    else {
+                        ci = (int)(int16_t)(w7 & 0xffffu), cq = (int)(int16_t)(w7 >> 16);
+                        pi_ = (int)(int16_t)(w6 & 0xffffu), pq_ = (int)(int16_t)(w6 >> 16);
+                        long long const dot = (long long)ci * pi_ + (long long)cq * pq_;
+                        long long const crs = (long long)cq * pi_ - (long long)ci * pq_;
+                        f_last = atan2_q31((int)crs, (int)dot);
+                    }
+                    f_last = __builtin_amdgcn_readlane(f_last, 63);
+                }
+                uint32_t const last_w = (uint32_t)__builtin_amdgcn_readlane((int)w7, 63);
+                int const x_last = uni(env_of(last_w));
+                if (uni((int)(carry_known && constant)) != 0) {
+                    // Every step of the tile is the same map of the state (but the first, which still sees the sample before
+                    // the tile): iterate to its fixed point -- at once where the silence has lasted, some hundred steps
+                    // right after a burst.  An exact state stays exact.
+                    int y = uni(carry_ya);
+                    y = (mul24(kLpfA, y) + mul24(kLpfB, x_last + uni(carry_xa))) >> 14;
+                    int const k2 = mul24(kLpfB, 2 * x_last);
+                    for (int n = 1; n < kTile; ++n) {
+                        int const y2 = (mul24(kLpfA, y) + k2) >> 14;
+                        if (y2 == y)
+                            break;
+                        y = y2;
+                    }
+                    carry_ya = y;
+                    if (FM && SS == 2) {
+                        int yf = uni(carry_yf);
+                        yf = (int)(int16_t)((mul24(p.a16, yf) + mul24(p.b16, f_last + uni(carry_ff))) >> 14);
+                        int const kf = mul24(p.b16, 2 * f_last);
+                        for (int n = 1; n < kTile; ++n) {
+                            int const y2 = (int)(int16_t)((mul24(p.a16, yf) + kf) >> 14);
+                            if (y2 == yf)
+                                break;
+                            yf = y2;
+                        }
+                        carry_yf = yf;
+                    }
+                    else if (FM) {
+                        int yf = uni(carry_yf);
+                        yf = (int)((p.a32 * (long long)yf + p.b32 * ((long long)f_last + uni(carry_ff))) >> 30);
+                        long long const kf = p.b32 * (2ll * f_last);
+                        for (int n = 1; n < kTile; ++n) {
+                            int const y2 = (int)((p.a32 * (long long)yf + kf) >> 30);
+                            if (y2 == yf)
+                                break;
+                            yf = y2;
+                        }
+                        carry_yf = yf;
+                    }
+                }
+                else {
+                    carry_known = false;
+                }
+                carry_xa = x_last;
+                carry_ff = f_last;
+                carry_w = SS == 2 ? last_w & 0xffffu : last_w;
+                if (SS == 2) {
+                    carry_i = (int)(last_w & 0xffu) - 128;
+                    carry_q = (int)((last_w >> 8) & 0xffu) - 128;
+                }
+                else {
+                    carry_i = (int)(int16_t)(last_w & 0xffffu);
+                    carry_q = (int)(int16_t)(last_w >> 16);
+                }
+                tail_max = qmax;
+                prev_quiet = true;
+                prev_bound = qmax;
+                if (lane == 0)
+                    st_desc(buf) = kQuietTile | qmax;
+                issue_loads(tile + 1);
+                issue_head(tile + 2);
+                return;
+            }
+        }
 
         // ================= phase A: envelope + discriminator, 8 samples per lane and row =================
         long long const t_tile = now();
@@ -537,6 +794,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
             }
             // the row's last sample is the next row's (or tile's) predecessor
             int const last_w = __builtin_amdgcn_readlane((int)wd[7], 63);
+            carry_w = (uint32_t)last_w;
             if (SS == 2) {
                 carry_i = (last_w & 0xff) - 128;
                 carry_q = ((last_w >> 8) & 0xff) - 128;
@@ -570,6 +828,8 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
             }
         }
         issue_loads(tile + 1); // in flight while phase B runs
+        if (lazy)
+            issue_head(tile + 2);
         wave_sync();
         if (p.flags & RUN_DBG_SKIP_FILTERS)
             return;
@@ -578,7 +838,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
         int const cs = lane * kChunk;                       // chunk start inside the tile
         int const cnt = max(0, min(kChunk, n_t - cs));      // valid samples of my chunk
         int const first = max(0, lane - kWarmChunks);       // first chunk I read
-        bool const from_carry = lane <= kWarmChunks && !warm; // my warm-up reaches the tile start: exact carry
+        bool const from_carry = lane <= kWarmChunks && !warm && !est; // my warm-up reaches the tile start: exact carry
         // chunks at which a frame (= a push_sdr_flow call) starts
         unsigned long long const fs_mask = __ballot((t0 + (uint32_t)cs) % F == 0);
         Track16<FAST> ta, tf16;
@@ -600,6 +860,11 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                 xa1 = (int)*(uint16_t const *)(s_env + (first - 1) * kPitch16 + (kChunk - 1) * 2);
                 ff1 = SS == 2 ? (int)*(int16_t const *)(s_f + (first - 1) * G::f_pitch + (kChunk - 1) * 2)
                               : *(int const *)(s_f + (first - 1) * G::f_pitch + (kChunk - 1) * 4);
+            }
+            else if (est) { // after unfiltered tiles: the samples before the tile are known, the two filter states are not --
+                xa1 = carry_xa; // but the envelope's lies between zero and the bound of the tile before
+                ff1 = carry_ff;
+                ta.lo = 0, ta.hi = prev_bound;
             }
         }
         ta.ok = tf16.ok = tf32.ok = 1;
@@ -742,6 +1007,10 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                 sf.ident = 0;
             }
         }
+        if (est && lane < kWarmChunks) { // no history to warm up on: what the tracks say, proven or not (the consumer takes
+            sa.start_known = sf.start_known = true; // the first kVirtual samples by their bound); nobody waits for these lanes
+            sa.ident = sf.ident = 0;
+        }
         // the fixed-point argument needs a feedback coefficient in [0, 1]: monotone map, slope <= 1
         sa.ident &= ta.ok;
         sf.ident &= SS == 2 ? (tf16.ok & (int)(p.a16 >= 0 && p.a16 <= 16384)) : (tf32.ok & (int)(p.a32 >= 0 && p.a32 <= (1ll << 30)));
@@ -760,6 +1029,8 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                 if (round > 64) { // cannot happen in a regular tile (the first open lane settles every round)
                     if (warm)
                         p_fail |= 8; // a stall reaching back past the establishing tile: the carry is not provable here
+                    else if (lazy)
+                        p_retry = 1; // (carries that do not settle after unfiltered tiles: the capture runs again, every tile filtered)
                     else
                         p_over = 2;
                     break;
@@ -804,8 +1075,12 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                         rerun = true;
                     }
                 }
-                if (__ballot(bad))
-                    p_over = 3; // refuse the result (the host reports it)
+                if (__ballot(bad)) {
+                    if (lazy)
+                        p_retry = 1;
+                    else
+                        p_over = 3; // refuse the result (the host reports it)
+                }
                 if (__ballot(rerun)) {
                     CNT(15, 1); // resolve rounds with an exact re-run
                     // exact re-run of my chunk from the proven carry
@@ -886,6 +1161,17 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
         carry_yf = __builtin_amdgcn_readlane(sf.y_end, 63);
         carry_xa = __builtin_amdgcn_readlane(xa1, 63);
         carry_ff = __builtin_amdgcn_readlane(ff1, 63);
+        if (lazy) {
+            carry_known = true;
+            prev_quiet = false;
+            if (post_q && lane < kVirtual / kChunk) // the consumer never looks at these samples
+                cmax = vbound, cmin = 0;
+            if (lane == 0) {
+                st_desc(buf) = post_q ? (kPostQuiet | vbound) : 0;
+                if (p_retry)
+                    st_retry(retry_slot) = 1;
+            }
+        }
         st_cmax(buf, lane) = (short)max(cmax, -32768); // (an empty chunk keeps its sentinels, clamped to 16 bits)
         st_cmin(buf, lane) = (short)min(cmin, 32767);
         if (p_over && lane == 0)
@@ -902,7 +1188,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
             return; // the consumer walks the floor over this tile
         }
         // per-frame envelope sums (u32, wraps like the reference's accumulator, baseband.c:39-44)
-        if (p.frame_sums && seg_primary) {
+        if (p.frame_sums && seg_primary && tile >= sums_done) {
             uint32_t const f_first = t0 / F, f_last = (t0 + (uint32_t)n_t - 1) / F;
             uint32_t const my_frame = (t0 + (uint32_t)cs) / F;
             for (uint32_t f = f_first; f <= f_last; ++f) {
@@ -911,6 +1197,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                     atomicAdd(&p.frame_sums[(uint64_t)cap * p.frames_cap + f], (uint32_t)part);
             }
         }
+        sums_done = max(sums_done, tile + 1u);
         wave_sync();
 
         if (p.tap_am && seg_primary) {
@@ -933,6 +1220,78 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
         tick(0, t_tile);
     };
 
+
+    // The consumer's side of an unfiltered stretch: n samples from the tile's first on, none of which, filtered, exceeds qmax.
+    // The detector idles (the steps of its noise floor are counted, see resolve_low) or counts a gap, whose end-of-package
+    // count may fall here (src/pulse_detect.c:441-468: no sample value enters but through `am > threshold`, which is false).
+    auto quiet_span = [&](uint32_t t0, int n, int qmax) {
+        int q = 0;
+        while (q < n) {
+            if (dc == 0) { // a new frame == a new push_sdr_flow call
+                flen = (int)min(my_n - (t0 + (uint32_t)q), F);
+                if (p.frame_min_high)
+                    cfg.min_high = uni(p.frame_min_high[(uint64_t)cap * p.frames_cap + min(frame, p.frames_cap - 1)]);
+                det_call_entry(det, cfg, flen, 0);
+            }
+            int const lim = min(n, q + (flen - dc));
+            int const st = uni(det.state), low = uni(det.low);
+            if (st == ST_IDLE) {
+                int const l_lo = min(low, min(lz_min, 0)) - 1;
+                int const l_hi = max(low, max(lz_max, qmax)) + 1;
+                int thr = (int)(int16_t)((l_lo + min(cfg.min_high, cfg.max_high)) / 2);
+                if (cfg.fixed_high != 0)
+                    thr = (int)(int16_t)cfg.fixed_high;
+                int const hys = (int)(int16_t)(thr / 8);
+                if (l_hi - l_lo >= 1000 || qmax > thr + hys) { // steps of more than one, or (never: quiet_bound) a pulse could start
+                    lz_fail = true;
+                    return;
+                }
+                int const cnt = lim - q;
+                lz_n += cnt;
+                lz_min = min(lz_min, 0);
+                lz_max = max(lz_max, qmax);
+                lz_carried = true;
+                det.lead_in = min(1025, uni(det.lead_in) + cnt);
+                q += cnt;
+                dc += cnt;
+            }
+            else if (st == ST_GAP) {
+                int thr = (int)(int16_t)((low + min(uni(det.high), cfg.max_high)) / 2);
+                if (cfg.fixed_high != 0)
+                    thr = (int)(int16_t)cfg.fixed_high;
+                int const hys = (int)(int16_t)(thr / 8);
+                if (qmax > thr + hys) {
+                    lz_fail = true;
+                    return;
+                }
+                int const lim_eop = 10 * min(max(uni(det.max_pulse), cfg.per_ms), 10 * cfg.per_ms);
+                int const togo = uni(det.eop_spurious) ? 0 : max(0, lim_eop - uni(det.run));
+                int const cnt = min(togo, lim - q);
+                det.run = uni(det.run) + cnt;
+                q += cnt;
+                dc += cnt;
+                if (q < lim) { // the count ends the package at this sample; the idle state then looks at the sample again
+                    int const r = det_step(det, cfg, 0, 0, flen, dc, input_pos, frame);
+                    if (r) {
+                        det_call_entry(det, cfg, flen, dc);
+                    }
+                    else {
+                        q += 1;
+                        dc += 1;
+                    }
+                }
+            }
+            else { // (never: a pulse cannot be open 32 samples into such a stretch)
+                lz_fail = true;
+                return;
+            }
+            if (dc == flen) { // the end of a frame (no logic dump with lazy tiles)
+                input_pos += (uint64_t)flen;
+                frame += 1;
+                dc = 0;
+            }
+        }
+    };
 
     // ======================================= the consumer: phase C of one tile =======================================
     auto consume = [&](uint32_t tile, int buf) {
@@ -981,8 +1340,25 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
             return;
         }
 
+        int vq = 0; // samples at the start of the tile that come as a bound instead of samples
+        if (lazy) {
+            int const desc = uni(st_desc(buf));
+            if (desc & (kQuietTile | kPostQuiet)) {
+                bool const whole = (desc & kQuietTile) != 0;
+                vq = whole ? n_t : min(kVirtual, n_t);
+                quiet_span(t0, vq, desc & 0xffff);
+                if (whole)
+                    n_quiet += 1;
+                if (lz_fail || whole) {
+                    if (lz_fail && lane == 0)
+                        st_retry(retry_slot) = 1;
+                    return;
+                }
+            }
+        }
+
         // ================= phase C: pulse detector =================
-        int i = (p.flags & RUN_DBG_SKIP_DETECT) ? n_t : 0;
+        int i = (p.flags & RUN_DBG_SKIP_DETECT) ? n_t : vq;
         int loaded = -1;           // block whose samples the lanes hold
         int am_l = 0, fm_l = 0;    // my sample of that block
         int a64_l = 0, f64_l = 0;  // am / 64, fm / 64 (C division) for the level and carrier averages
@@ -1008,13 +1384,56 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
         // only counted; when the exact value is needed (a pulse may start, the tile ends) the last 128
         // samples are walked from both extremes of the right parity and must meet -- else the whole
         // stretch is walked.  lz_n pending steps start at lz_from; lz_min/lz_max bound their samples.
-        int lz_n = 0, lz_from = 0, lz_min = 0x7fffffff, lz_max = -0x7fffffff;
+        // (lz_n, lz_from, lz_min, lz_max live across tiles: over unfiltered tiles the steps stay pending -- lz_carried --,
+        // and only a two-sided walk over filtered samples of a later tile can settle them)
         auto resolve_low = [&](int upto) {
             if (lz_n == 0)
                 return;
             int lo_est = det.low;
             bool done = false;
-            if (lz_n > 160) {
+            if (lz_carried) {
+                // The walk from the first pending step is not to be had.  Both extremes of the right parity over the filtered
+                // samples before `upto` -- the last 128, then up to 384 -- must meet; else the capture runs again.
+                int const avail = uni(upto - vq);
+                bool met = false;
+                for (int W = 128; avail > 0; W = 384) {
+                    int const w0 = upto - min(W, avail);
+                    int const par = (det.low + (lz_n - (upto - w0))) & 1;
+                    int a = min(det.low, lz_min) - 1, b = max(det.low, lz_max) + 1;
+                    a += (a ^ par) & 1;
+                    b -= (b ^ par) & 1;
+                    for (int j0 = uni(w0); j0 < upto; j0 += 64) {
+                        int const v = j0 + lane < upto ? ld16(c_am, j0 + lane) : 0;
+                        int const cntj = uni(min(64, upto - j0));
+                        if (cntj == 64) {
+#pragma unroll 8
+                            for (int u = 0; u < 64; ++u) {
+                                int const x = __builtin_amdgcn_readlane(v, u);
+                                a += x > a ? 1 : -1;
+                                b += x > b ? 1 : -1;
+                            }
+                        }
+                        else {
+                            for (int u = 0; u < cntj; ++u) {
+                                int const x = __builtin_amdgcn_readlane(v, u);
+                                a += x > a ? 1 : -1;
+                                b += x > b ? 1 : -1;
+                            }
+                        }
+                    }
+                    if (uni(a) == uni(b)) {
+                        lo_est = a;
+                        met = true;
+                    }
+                    if (met || W == 384 || avail <= 128)
+                        break;
+                }
+                if (!met)
+                    lz_fail = true;
+                lz_carried = false;
+                done = true;
+            }
+            else if (lz_n > 160) {
                 int const w0 = upto - 128;
                 int const par = (det.low + (w0 - lz_from)) & 1;
                 int a = min(det.low, lz_min) - 1, b = max(det.low, lz_max) + 1;
@@ -1061,6 +1480,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
             lz_n = 0;
             lz_min = 0x7fffffff;
             lz_max = -0x7fffffff;
+            lz_carried = false;
         };
         // Every lane holds the same detector state, but the general step and call entry are per-lane-looking code;
         // after them, pin what the fast paths loop on to SGPRs so that those loops run on the scalar unit with
@@ -1094,7 +1514,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
             frame += 1;
             dc = 0;
         };
-        while (i < n_t) {
+        while (i < n_t && !lz_fail) {
             CNT(0, 1); // outer iterations
             long long const t_it = now();
             int const st_it = det.state;
@@ -1460,6 +1880,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                 CNT(2 + (st & 3), 1); // legs by state
                 if (st == ST_IDLE) {
                     if (det.lead_in <= 1024) { // no pulse can start during the lead-in (pulse_detect.c:310)
+                        resolve_low(i0); // (pending steps here: only after an unfiltered stretch shorter than the lead-in)
                         k = min(e, i0 + (1025 - det.lead_in));
                         det.lead_in += k - i0;
                         int lo_est = det.low; // idle arm, pulse_detect.c:326-334
@@ -1928,33 +2349,81 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
             tick(5, t_fast);
         }
         long long const t_res = now();
-        resolve_low(n_t);
+        if (!lz_fail)
+            resolve_low(n_t);
+        if (lz_fail && lane == 0)
+            st_retry(retry_slot) = 1;
         tick(6, t_res); // the samples leave LDS with the tile
     };
 
     // tile t + 1 is produced while tile t is consumed; one barrier per tile hands a buffer over and takes one back.  The two
     // roles are two loops: what one role keeps across tiles is dead in the other's loop (registers, scalar and vector).
-    if constexpr (solo) {
-        for (uint32_t tile = tile_first; tile < tile_end; ++tile) {
-            produce(tile, 0);
+    // (Lazy tiles: either role may find that the capture cannot be carried exactly across its unfiltered tiles and raises
+    // st_retry in the slot of the barrier its tile ends at; both roles read that slot behind that barrier -- nobody writes it
+    // before the barrier after the next -- and start the capture over with every tile filtered.)
+    for (;;) {
+        init_run();
+        bool again = false;
+        if constexpr (solo) {
+            issue_loads(tile_first);
+            if (lazy)
+                issue_head(tile_first + 1u);
+            for (uint32_t tile = tile_first; tile < tile_end; ++tile) {
+                produce(tile, 0);
+                wave_sync();
+                if (!SEAM)
+                    consume(tile, 0);
+                if (lazy) {
+                    wave_sync();
+                    if (uni(st_retry(0))) {
+                        again = true;
+                        break;
+                    }
+                }
+            }
+        }
+        else if (role == 0) {
+            issue_loads(tile_first);
+            if (lazy)
+                issue_head(tile_first + 1u);
+            for (uint32_t it = tile_first; it <= tile_end; ++it) {
+                retry_slot = (int)(it & 1u);
+                if (it < tile_end)
+                    produce(it, (int)(it & 1u));
+                __syncthreads();
+                if (lazy && uni(st_retry((int)(it & 1u)))) {
+                    again = true;
+                    break;
+                }
+            }
+        }
+        else {
+            for (uint32_t it = tile_first; it <= tile_end; ++it) {
+                retry_slot = (int)(it & 1u);
+                if (it > tile_first && !idle)
+                    consume(it - 1, (int)((it - 1) & 1u));
+                __syncthreads();
+                if (lazy && uni(st_retry((int)(it & 1u)))) {
+                    again = true;
+                    break;
+                }
+            }
+        }
+        if (!again)
+            break;
+        if (!solo)
+            __syncthreads(); // everybody has seen the flag
+        if (threadIdx.x == 0) {
+            st_retry(0) = st_retry(1) = 0;
+            st_desc(0) = st_desc(1) = 0;
+            s_pover = 0;
+        }
+        lazy = false;
+        attempts += 1;
+        if (solo)
             wave_sync();
-            if (!SEAM)
-                consume(tile, 0);
-        }
-    }
-    else if (role == 0) {
-        for (uint32_t it = tile_first; it <= tile_end; ++it) {
-            if (it < tile_end)
-                produce(it, (int)(it & 1u));
+        else
             __syncthreads();
-        }
-    }
-    else {
-        for (uint32_t it = tile_first; it <= tile_end; ++it) {
-            if (it > tile_first && !idle)
-                consume(it - 1, (int)((it - 1) & 1u));
-            __syncthreads();
-        }
     }
     if ((!solo && role == 0) || idle)
         return; // the consumer wavefronts report
@@ -1987,6 +2456,8 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
         S.overflow = det.overflow;
         S.input_pos = input_pos;
         S.frame = frame;
+        S.fm_xr = n_quiet;  // (statistics, r433_batch_debug_state: tiles that went by unfiltered; attempts beyond the first)
+        S.fm_xi = attempts;
         if (timing) {
             S.lpf_y = (int)(s_tk[0] >> 6), S.lpf_x = (int)(s_tk[1] >> 6), S.fm_xr = (int)(s_tk[2] >> 6), S.fm_xi = (int)(s_tk[3] >> 6);
             S.fm_xf = (int)(s_tk[4] >> 6), S.fm_yf = (int)(s_tk[5] >> 6), S.state = (int)(s_tk[6] >> 6), S.run = (int)s_tk[7];
