@@ -419,7 +419,9 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
     // consumer side: pending steps of the noise floor (see resolve_low)
     int lz_n = 0, lz_from = 0, lz_min = 0x7fffffff, lz_max = -0x7fffffff;
     bool lz_carried = false;     // some of them over samples that never were filtered: only a two-sided walk can settle them
-    bool lz_fail = false;
+    int lzc_min = 0x7fffffff, lzc_max = -0x7fffffff; // ... and the bounds of those samples alone
+    int lz_fail = 0;             // why the capture has to run again (the codes of r433_batch_debug_state: 4.. the consumer's)
+    int retry_why = 0;
     int p_fail = 0, p_over = 0;  // producer side of seg_fail / det.overflow
 
     auto init_run = [&]() {
@@ -460,7 +462,9 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
         carry_w = SS == 2 ? 0x8080u : 0u; // the centred (0, 0) the discriminator starts from
         lz_n = lz_from = 0;
         lz_min = 0x7fffffff, lz_max = -0x7fffffff;
-        lz_carried = lz_fail = false;
+        lz_carried = false;
+        lzc_min = 0x7fffffff, lzc_max = -0x7fffffff;
+        lz_fail = 0;
         p_fail = p_over = 0;
         n_quiet = 0;
     };
@@ -1077,7 +1081,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                 }
                 if (__ballot(bad)) {
                     if (lazy)
-                        p_retry = 1;
+                        p_retry = 2;
                     else
                         p_over = 3; // refuse the result (the host reports it)
                 }
@@ -1169,7 +1173,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
             if (lane == 0) {
                 st_desc(buf) = post_q ? (kPostQuiet | vbound) : 0;
                 if (p_retry)
-                    st_retry(retry_slot) = 1;
+                    st_retry(retry_slot) = p_retry;
             }
         }
         st_cmax(buf, lane) = (short)max(cmax, -32768); // (an empty chunk keeps its sentinels, clamped to 16 bits)
@@ -1243,13 +1247,15 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                     thr = (int)(int16_t)cfg.fixed_high;
                 int const hys = (int)(int16_t)(thr / 8);
                 if (l_hi - l_lo >= 1000 || qmax > thr + hys) { // steps of more than one, or (never: quiet_bound) a pulse could start
-                    lz_fail = true;
+                    lz_fail = l_hi - l_lo >= 1000 ? 4 : 8;
                     return;
                 }
                 int const cnt = lim - q;
                 lz_n += cnt;
                 lz_min = min(lz_min, 0);
                 lz_max = max(lz_max, qmax);
+                lzc_min = min(lzc_min, 0);
+                lzc_max = max(lzc_max, qmax);
                 lz_carried = true;
                 det.lead_in = min(1025, uni(det.lead_in) + cnt);
                 q += cnt;
@@ -1261,7 +1267,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                     thr = (int)(int16_t)cfg.fixed_high;
                 int const hys = (int)(int16_t)(thr / 8);
                 if (qmax > thr + hys) {
-                    lz_fail = true;
+                    lz_fail = 8;
                     return;
                 }
                 int const lim_eop = 10 * min(max(uni(det.max_pulse), cfg.per_ms), 10 * cfg.per_ms);
@@ -1282,7 +1288,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                 }
             }
             else { // (never: a pulse cannot be open 32 samples into such a stretch)
-                lz_fail = true;
+                lz_fail = 16;
                 return;
             }
             if (dc == flen) { // the end of a frame (no logic dump with lazy tiles)
@@ -1351,7 +1357,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                     n_quiet += 1;
                 if (lz_fail || whole) {
                     if (lz_fail && lane == 0)
-                        st_retry(retry_slot) = 1;
+                        st_retry(retry_slot) = lz_fail;
                     return;
                 }
             }
@@ -1399,7 +1405,12 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                 for (int W = 128; avail > 0; W = 384) {
                     int const w0 = upto - min(W, avail);
                     int const par = (det.low + (lz_n - (upto - w0))) & 1;
-                    int a = min(det.low, lz_min) - 1, b = max(det.low, lz_max) + 1;
+                    // where the floor can be at w0: between the extremes of what it has seen up to there -- the bound of the
+                    // unfiltered samples and the chunks of this tile that begin before w0 (lz_min / lz_max also cover chunks
+                    // behind the window, the signal that made the tile worth filtering among them)
+                    bool const mine = lane >= (vq >> 5) && lane < ((w0 + kChunk - 1) >> 5);
+                    int const seen_hi = wave_max(mine ? my_cmax : -0x7fffffff), seen_lo = -wave_max(mine ? -my_cmin : -0x7fffffff);
+                    int a = min(det.low, min(lzc_min, seen_lo)) - 1, b = max(det.low, max(lzc_max, seen_hi)) + 1;
                     a += (a ^ par) & 1;
                     b -= (b ^ par) & 1;
                     for (int j0 = uni(w0); j0 < upto; j0 += 64) {
@@ -1421,6 +1432,9 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                             }
                         }
                     }
+#ifdef R433_EMU_DEBUG_LAZY
+                    if (lane == 0) fprintf(stderr, "resolve carried: t0 %u upto %d vq %d W %d w0 %d lz_n %d low %d lz_min %d lz_max %d -> a %d b %d\n", t0, upto, vq, W, w0, lz_n, det.low, lz_min, lz_max, a, b);
+#endif
                     if (uni(a) == uni(b)) {
                         lo_est = a;
                         met = true;
@@ -1429,8 +1443,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                         break;
                 }
                 if (!met)
-                    lz_fail = true;
-                lz_carried = false;
+                    lz_fail = avail > 0 ? 32 : 64;
                 done = true;
             }
             else if (lz_n > 160) {
@@ -1481,6 +1494,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
             lz_min = 0x7fffffff;
             lz_max = -0x7fffffff;
             lz_carried = false;
+            lzc_min = 0x7fffffff, lzc_max = -0x7fffffff;
         };
         // Every lane holds the same detector state, but the general step and call entry are per-lane-looking code;
         // after them, pin what the fast paths loop on to SGPRs so that those loops run on the scalar unit with
@@ -2352,7 +2366,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
         if (!lz_fail)
             resolve_low(n_t);
         if (lz_fail && lane == 0)
-            st_retry(retry_slot) = 1;
+            st_retry(retry_slot) = lz_fail;
         tick(6, t_res); // the samples leave LDS with the tile
     };
 
@@ -2375,7 +2389,8 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                     consume(tile, 0);
                 if (lazy) {
                     wave_sync();
-                    if (uni(st_retry(0))) {
+                    if (int const why = uni(st_retry(0))) {
+                        retry_why |= why;
                         again = true;
                         break;
                     }
@@ -2391,7 +2406,8 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                 if (it < tile_end)
                     produce(it, (int)(it & 1u));
                 __syncthreads();
-                if (lazy && uni(st_retry((int)(it & 1u)))) {
+                if (int const why = lazy ? uni(st_retry((int)(it & 1u))) : 0) {
+                    retry_why |= why;
                     again = true;
                     break;
                 }
@@ -2403,7 +2419,8 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                 if (it > tile_first && !idle)
                     consume(it - 1, (int)((it - 1) & 1u));
                 __syncthreads();
-                if (lazy && uni(st_retry((int)(it & 1u)))) {
+                if (int const why = lazy ? uni(st_retry((int)(it & 1u))) : 0) {
+                    retry_why |= why;
                     again = true;
                     break;
                 }
@@ -2458,6 +2475,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
         S.frame = frame;
         S.fm_xr = n_quiet;  // (statistics, r433_batch_debug_state: tiles that went by unfiltered; attempts beyond the first)
         S.fm_xi = attempts;
+        S.fm_xf = retry_why; // 1, 2 filter carries after unfiltered tiles; 4 floor steps of more than one; 32, 64 the floor walks did not meet / had no samples
         if (timing) {
             S.lpf_y = (int)(s_tk[0] >> 6), S.lpf_x = (int)(s_tk[1] >> 6), S.fm_xr = (int)(s_tk[2] >> 6), S.fm_xi = (int)(s_tk[3] >> 6);
             S.fm_xf = (int)(s_tk[4] >> 6), S.fm_yf = (int)(s_tk[5] >> 6), S.state = (int)(s_tk[6] >> 6), S.run = (int)s_tk[7];
