@@ -9,8 +9,10 @@ Workloads (BASELINE.json `configs`, recipes in SURVEY.md 8d):
                         decoders fanned out.  One step = one pass of the hot path over --batches (8) such batches PER GPU,
                         submitted together: the 8192 captures start in pinned HOST memory, cross PCIe, run through k_wave
                         (IQ -> packages; one grid, so the scheduler fills the SIMDs a finished capture leaves idle with the
-                        next batch's captures), the slicer fan-out, the record copy back to pinned host memory and the replay
-                        of every bitbuffer into the registered decode_fn plugins in reference order.  Three DISTINCT sets of
+                        next batch's captures), the slicer fan-out (with the device-side pre-filter), the record copy back
+                        to pinned host memory and the ordered replay of every bitbuffer into the REAL decode_fn of the
+                        reference's 335 default decoders (dropin/_build/libr433plugins.so), whose JSON lines are the
+                        output.  Three DISTINCT sets of
                         batches rotate (no step re-reads the input of the step before it); steps are software-pipelined over
                         three engines / HIP streams.  Weak scaling: every rank has its own batches, the only collective is
                         the gather of per-rank records to rank 0.
@@ -21,11 +23,14 @@ Workloads (BASELINE.json `configs`, recipes in SURVEY.md 8d):
   --config 5            configs[4]: one 2 MS/s cu8 stream, OOK + FSK bursts over a stepping noise floor, -Y autolevel and a
                         -Y filter, all decoders; reports the latency-per-burst histogram.
 
-`value` (config 2) is whole-job samples / wall time from bytes of IQ in pinned host memory to decoder callbacks on the
-host (H2D is inside the timed region); the rate of the same pipeline with the inputs already resident in
-HBM is measured in the same process and reported next to it (`hbm_resident`), as are the reference on one core
-(`cpu_baseline`), on all cores as independent processes (`cpu_baseline_nproc`), and both sides with the reference's REAL
-decoders (`real_decoders`).  Configs 3, 4 and 5 keep their inputs resident (their lines say so in `data`).
+`value` (config 2) is whole-job samples / wall time from bytes of IQ in pinned host memory to decoded events (JSON lines)
+on the host (H2D is inside the timed region); the rate of the same pipeline with the inputs already
+resident in HBM is measured in the same process and reported next to it (`hbm_resident`), as are the unmodified reference
+with the same real decoders on one core (`cpu_baseline`; its JSON lines for batch 0 are compared with the GPU path's by
+sha256: `parity_detail`), the reference with a checksum decode_fn on one core and on all cores as independent processes
+(every bitbuffer checked: `cpu_baseline_checksum_decode_fn`, `cpu_baseline_nproc`), one-pass variants of the replay
+(`real_decoders`) and short passes of the single-stream workloads (`other_configs`: configs[2] and configs[4]).
+Configs 3, 4 and 5 keep their inputs resident (their lines say so in `data`).
 
 Prints ONE JSON line on rank 0.
 """
@@ -45,7 +50,19 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")  # separate rocprofv3 --pmc pass (tools/pmc_run.sh)
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")  # separate rocprofv3 --pmc pass (tools/pmc_run.sh)
+PMC_ISSUE = os.path.join(ROOT, "profiles", "r04_pmc_issue.json")      # ... and the instruction counters of the same build
+
+
+def _issue_note():
+    """What `bound by instruction issue` means in numbers: the committed SQ counter pass of this build (not this run)."""
+    try:
+        return json.load(open(PMC_ISSUE))
+    except Exception:
+        return None
+
+
+ISSUE_NOTE = _issue_note()
 METRIC = "IQ Msamples/sec end-to-end (cu8 -> decoded events)"
 
 
@@ -167,6 +184,45 @@ def cpu_baseline_config2(host_iq, devs_expected, gpu_digest, gpu_events, reps=3)
     return one, many, parity
 
 
+def cpu_baseline_real_decoders(host_iq, reps=2):
+    """The unmodified reference (oracle/_ref) with its REAL decoders over the batch, one thread; what the decoders report
+    comes back as the JSON lines of the reference's own printer (the text the GPU path's replay is compared with)."""
+    from oracle import pyoracle as po
+    if not po.have_ref():
+        return None, None
+    n_streams, n_samples = host_iq.shape[0], host_iq.shape[1] // 2
+    ref = po.Ref(call_real=True, record=False)
+    ref.set_digest_mode(0)
+    ref.text_mode(True)
+    best, text = None, b""
+    for _ in range(reps):
+        ref.clear()
+        ref.take_text()
+        t0 = time.perf_counter()
+        for s in range(n_streams):
+            ref.run(host_iq[s], 2, 250000, 433920000, fpdm=0, stream_index=s)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        text = ref.take_text()
+    ref.close()
+    return dict(value=round(n_streams * n_samples / best / 1e6, 2), unit="Msamples/s", cores=1, kind="reference",
+                sample=f"the same {n_streams} x {n_samples}-sample batch (batch 0 of the run), all 335 default decoders with their real decode_fn, "
+                       f"best of {reps}, single thread (the reference has no other)"), text
+
+
+def other_configs_summary(args):
+    """configs[2] and configs[4] (one long cs16 FSK stream; one 2 MS/s mixed stream with -Y autolevel) as short passes in
+    the same process: their detection time, roofline fraction and record parity against the reference on a prefix."""
+    out = {}
+    for cfg_no, n_samples in ((3, 16 << 20), (5, 32 << 20)):
+        a = argparse.Namespace(**vars(args))
+        a.config, a.stream_samples, a.steps, a.warmup, a.quick, a.no_cpu_baseline = cfg_no, n_samples, 3, 1, True, True
+        r = run_stream(a, dict(rank=0, world=1, local_rank=0, dist=None), parity_prefix=True)
+        out[f"config{cfg_no}"] = {k: r[k] for k in ("value", "unit", "ms_per_step", "roofline", "breakdown_ms", "packages_per_step", "parity") if k in r}
+        out[f"config{cfg_no}"]["workload"] = r["config"]["workload"]
+    return out
+
+
 def real_decoders_leg(host_iq, d_iq, devs, threads, local_rank, reps=2, pipe_steps=12):
     """Both sides with the reference's REAL decoders (src/devices/*.c, taken from oracle/_ref/libr433ref.so): the GPU
     path replays its bitbuffers into their decode_fn, the CPU side is the reference as it is.  Some decoders keep
@@ -195,15 +251,18 @@ def real_decoders_leg(host_iq, d_iq, devs, threads, local_rank, reps=2, pipe_ste
             o.decode_events = o.decode_ok = o.decode_messages = 0
             for k in range(5):
                 o.decode_fails[k] = 0
+    from rtl_433_amd import plugins
     eng = BatchEngine(flow_cfg(2, 250000), devs)
     if DEBUG_FLAGS:
         eng.set_debug(DEBUG_FLAGS)
+    stateless = plugins.stateless_flags(plain)
     best, decoded, d2h, seen = {}, {}, {}, {}
     t0 = time.perf_counter()
     tables = eng.probe_prefilter(plain)
     probe_s = time.perf_counter() - t0
-    for mode in ("ordered", "single", "ordered_prefilter"):
-        eng.set_prefilter(1 if mode == "ordered_prefilter" else 0)
+    for mode in ("ordered", "single", "ordered_prefilter", "ordered_prefilter_stateless"):
+        eng.set_prefilter(1 if mode.startswith("ordered_prefilter") else 0)
+        eng.set_stateless(stateless if mode.endswith("stateless") else None)
         for _ in range(reps + 1):
             zero()
             torch.cuda.synchronize()
@@ -216,25 +275,6 @@ def real_decoders_leg(host_iq, d_iq, devs, threads, local_rank, reps=2, pipe_ste
         d2h[mode] = ev_bytes + len(eng.packages()[0])
         seen[mode] = stats()
     eng.close()
-    # the same three-engine pipeline as the headline, real decoders behind the ordered replay, pre-filter on
-    rd_engines = int(os.environ.get("R433_BENCH_RD_ENGINES", "3"))
-    pipe = Pipeline(lambda: flow_cfg(2, 250000), devs, plain, threads, rd_engines, local_rank, ordered=True)
-    for e in pipe.engines:
-        e.probe_prefilter(plain)
-    pinned = torch.from_numpy(host_iq).pin_memory()
-    d_bufs = [torch.empty_like(d_iq) for _ in range(pipe.n_eng)]
-
-    def leg(k):
-        return dict(src=None, h2d_from=pinned, d_buf=d_bufs[k % pipe.n_eng])
-    pipe.run(max(3, rd_engines), leg)  # every engine has had its first pass (buffers) before the timed region
-    zero()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    pipe.run(pipe_steps, leg)
-    torch.cuda.synchronize()
-    piped = (time.perf_counter() - t0) / pipe_steps
-    piped_stats = stats()
-    pipe.close()
     cpu_best, cpu_events = None, 0
     for _ in range(reps):
         ref.clear()
@@ -247,24 +287,23 @@ def real_decoders_leg(host_iq, d_iq, devs, threads, local_rank, reps=2, pipe_ste
         cpu_best = dt if cpu_best is None else min(cpu_best, dt)
         cpu_events = ev
     ref.close()
-    one = seen["ordered"]  # (the harness counts its own calls on its own device copies: the three GPU replays are what compare)
     rate = lambda t: round(n_streams * n_samples / t / 1e6, 2)
-    return dict(gpu=dict(value=rate(best["ordered_prefilter"]), unit="Msamples/s", host_threads=threads,
-                         note="one pass, not pipelined, inputs resident: GPU leg with the device-side pre-filter + ordered replay into the real "
-                              "decode_fn of every decoder (a decoder stays on one thread, outputs committed in reference order)"),
-                gpu_no_prefilter=dict(value=rate(best["ordered"]), unit="Msamples/s", note="the same with every record crossing to the host"),
+    return dict(gpu=dict(value=rate(best["ordered_prefilter_stateless"]), unit="Msamples/s", host_threads=threads,
+                         note="one pass of ONE batch, not pipelined, inputs resident: GPU leg with the device-side pre-filter + ordered replay into the "
+                              "real decode_fn of every decoder, the decoders the host declared stateless spread over the threads "
+                              "(the headline is this as a three-engine pipeline over grids of 8 batches)"),
+                gpu_decoders_on_one_thread_each=dict(value=rate(best["ordered_prefilter"]), unit="Msamples/s",
+                                                     note="the same with every decoder's calls kept on one thread (no host knowledge about the plugins)"),
+                gpu_no_prefilter=dict(value=rate(best["ordered"]), unit="Msamples/s", note="... and with every record crossing to the host"),
                 gpu_single_thread=dict(value=rate(best["single"]), unit="Msamples/s", note="no pre-filter, the replay on one thread"),
-                gpu_pipelined=dict(value=rate(piped), unit="Msamples/s", steps=pipe_steps, engines=rd_engines,
-                                   note="pinned host -> H2D -> kernels (pre-filter on) -> D2H -> ordered replay into the real decoders, three engines"),
                 prefilter=dict(decoders_with_table=int(tables), probe_s=round(probe_s, 2),
                                d2h_bytes_per_step_before=int(d2h["ordered"]), d2h_bytes_per_step_after=int(d2h["ordered_prefilter"]),
-                               statistics_equal=bool(seen["ordered"] == seen["ordered_prefilter"] == seen["single"]),
-                               pipelined_statistics_equal=bool(piped_stats == [(a * pipe_steps, b * pipe_steps, c * pipe_steps, tuple(x * pipe_steps for x in f))
-                                                                                for a, b, c, f in one])),
+                               statistics_equal=bool(seen["ordered"] == seen["ordered_prefilter"] == seen["single"] == seen["ordered_prefilter_stateless"])),
                 cpu=dict(value=rate(cpu_best), unit="Msamples/s", cores=1, kind="reference"),
-                decoded_events=dict(gpu=int(decoded["ordered_prefilter"]), gpu_no_prefilter=int(decoded["ordered"]),
+                decoded_events=dict(gpu=int(decoded["ordered_prefilter_stateless"]), gpu_no_prefilter=int(decoded["ordered"]),
                                     gpu_single_thread=int(decoded["single"]), cpu=int(cpu_events),
-                                    equal=bool(decoded["ordered"] == cpu_events == decoded["single"] == decoded["ordered_prefilter"])),
+                                    equal=bool(decoded["ordered"] == cpu_events == decoded["single"] == decoded["ordered_prefilter"]
+                                               == decoded["ordered_prefilter_stateless"])),
                 sample=f"one batch: the same {n_streams} x {n_samples}-sample captures, 335 default decoders, best of {reps}")
 
 
@@ -305,6 +344,7 @@ class Pipeline:
         self.on_host_leg = on_host_leg
         self.ordered = ordered  # the replay for decoders that keep state between calls (r433_batch_dispatch_ordered)
         self.stagger = 0.0
+        self.replay_s = []  # the library's replay call alone, per host leg
 
     def gpu_leg(self, k, src, lens=None, h2d_from=None, d_buf=None):
         self.torch.cuda.set_device(self.local_rank)
@@ -317,10 +357,12 @@ class Pipeline:
 
     def host_leg(self, k, n_pkgs):
         e = self.engines[k % self.n_eng]
+        t0 = time.perf_counter()
         if self.ordered:
             e.dispatch_ordered(self.rdev_arr, None, self.threads)
         else:
             e.dispatch(self.rdev_arr, n_threads=self.threads)
+        self.replay_s.append(time.perf_counter() - t0)
         if self.on_host_leg:
             self.on_host_leg(k, e, n_pkgs)
 
@@ -353,6 +395,31 @@ class Pipeline:
         for e in self.engines:
             e.close()
         self.pool.shutdown()
+
+
+def cpu_quota():
+    """CPUs this process may really use: the affinity mask, cut by the container's CFS quota (cgroup v2 cpu.max, v1
+    cfs_quota_us).  The GPU boxes of this pool show 256 logical CPUs and a quota of 16: threads beyond it only get throttled
+    (nr_throttled in cpu.stat; whole replay passes stalled for 40-60 ms with 64 threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
+def replay_threads(world):
+    """host threads of the ordered replay per rank: one and a half per CPU the quota grants (they wait on memory), at most 64"""
+    return max(1, min(64, (cpu_quota() * 3 // 2) // max(1, world)))
 
 
 def timed(dist, torch, fn):
@@ -389,18 +456,18 @@ def run_batched(args, ctxd):
     dev = torch.device("cuda", local_rank)
     strong = args.config == 4
     n_samples = 65536
-    threads = args.threads or max(1, min(32, (os.cpu_count() or 1) // max(1, world)))
+    threads = args.threads or replay_threads(world)
     procs = max(1, min(32, (os.cpu_count() or 1) // max(1, world)))
     devs, protocols, names = load_device_table()
     ctx = _lib.DigestCtx(0, 0)
     rdev_arr, rdev_objs = make_rdevices(devs, digest_plugin_addr(), C.addressof(ctx), names, protocols)
-    plug = None
-    if strong:
-        # configs[3]: the job is decoded events on rank 0 -- the reference's REAL decoders behind the replay
-        # (dropin/_build/libr433plugins.so: the reference's sources as plugins), their JSON lines gathered
-        from rtl_433_amd import plugins
-        plug = plugins.Plugins()
-        assert len(plug.devices) == len(devs), "the plugin library registers another decoder set than the device table"
+    # The job is decoded events: the reference's REAL decoders behind the replay (dropin/_build/libr433plugins.so: the
+    # reference's sources as plugins, unchanged behind r_device.decode_fn), what they report as JSON lines printed by the
+    # reference's own data_print_jsons -- that text is what the ranks gather and what is compared with the reference.
+    from rtl_433_amd import plugins
+    plug = plugins.Plugins()
+    assert len(plug.devices) == len(devs), "the plugin library registers another decoder set than the device table"
+    stateless = plugins.stateless_flags(plug.devices)  # what this host knows about its plugins (r433_batch_set_stateless)
 
     if strong:
         total = args.list_len
@@ -432,25 +499,24 @@ def run_batched(args, ctxd):
     records = {}
 
     def on_host_leg(k, e, n_pkgs):
-        # what leaves a rank: its package records and the checksum of every bitbuffer its decoders were handed
-        records["last"] = (n_pkgs, int(ctx.events), int(ctx.sum))
+        # what leaves a rank: the JSON lines its decoders produced for this launch's captures, in capture order
+        text, n_msg = plug.take()
+        st = records.setdefault("acc", [0, 0, 0, 0, [], 0, 0])
+        if k % per_step == 0:
+            st[0], st[1], st[3], st[4], st[5], st[6] = 0, 0, 0, [], 0, 0  # a new pass: what is gathered is the last pass
+        st[0] += n_pkgs
+        st[1] += n_msg
         if strong:
-            text, n_msg = plug.take()  # the JSON lines of this launch's captures, in capture order
-            st = records.setdefault("acc", [0, 0, 0, 0, []])
-            st[0] += n_pkgs
-            st[1] += n_msg
             st[3] ^= fnv64(e.packages()[0])
-            if k % per_step == 0:
-                st[4] = []  # a new pass over the list: what is gathered is the last pass
-            st[4].append(text)
-        ctx.sum = 0
-        ctx.events = 0
+        st[4].append(text)
+        pk_b, _, ev_b, ev_n = e.sizes()
+        st[5] += ev_n          # bitbuffers that crossed to the host (the pre-filter keeps the provably refused ones on the device)
+        st[6] += pk_b + ev_b   # bytes of records copied back
 
-    pipe = Pipeline(lambda: flow_cfg(2, 250000), devs, plug.devices if strong else rdev_arr, threads, max(2, args.engines), local_rank,
-                    on_host_leg, ordered=strong)
-    if strong:
-        for e in pipe.engines:  # records a decoder provably refuses on their head stay on the device (statistics unchanged)
-            e.probe_prefilter(plug.devices)
+    pipe = Pipeline(lambda: flow_cfg(2, 250000), devs, plug.devices, threads, max(2, args.engines), local_rank, on_host_leg, ordered=True)
+    for e in pipe.engines:
+        e.set_stateless(stateless)
+        e.probe_prefilter(plug.devices)  # records a decoder provably refuses on their head stay on the device (statistics unchanged)
 
     d_bufs = None if strong else [torch.empty_like(batches[0]) for _ in range(max(2, args.engines))]
 
@@ -466,14 +532,10 @@ def run_batched(args, ctxd):
 
     def gather_records():
         """The one collective of the path: per-rank records to rank 0 (RCCL over xGMI), variable length."""
-        if strong:
-            npk, nmsg, dsum, pkh, texts = records.get("acc", [0, 0, 0, 0, []])
-            payload = shard.pack_rank_record(first, npk, nmsg, dsum, pkh, b"".join(texts))
-        else:
-            e = pipe.engines[(args.steps - 1) % pipe.n_eng]
-            pk, npk = e.packages()
-            payload = shard.pack_rank_record(rank * n_streams, npk, records["last"][1], records["last"][2], len(pk), pk)
-        got = shard.gather_rank_records(payload, dist is not None, dst=0, device=dev, tail="text" if strong else "packages")
+        npk, nmsg, dsum, pkh, texts, nbits, nbytes = records.get("acc", [0, 0, 0, 0, [], 0, 0])
+        records["sent"] = (nbits, nbytes)
+        payload = shard.pack_rank_record(first if strong else rank * n_streams, npk, nmsg, nbits, pkh if strong else nbytes, b"".join(texts))
+        got = shard.gather_rank_records(payload, dist is not None, dst=0, device=dev, tail="text")
         if rank == 0:
             gathered.update(got)
 
@@ -493,26 +555,22 @@ def run_batched(args, ctxd):
         gather_records()  # inside the timed region: the event gather is part of the job
         return out
 
+    pipe.replay_s.clear()
     elapsed, (det_ms, tot_ms, disp_s, n_pkgs) = timed(dist, torch, timed_region)
+    replay_ms = float(np.mean(pipe.replay_s)) * 1e3 if pipe.replay_s else 0.0
 
     result = None
     if rank == 0:
         per = gathered["per_rank"]
-        if strong:
-            import hashlib
-            samples_per_step = args.list_len * n_samples
-            tot_pk = sum(p["packages"] for p in per) // args.steps
-            tot_ev = sum(p["events"] for p in per) // args.steps
-            decoded_json = gathered["merged"]  # rank order = capture order: the single-process output
-            gathered_json = {"bytes": len(decoded_json), "lines": decoded_json.count(b"\n"),
-                             "sha256": hashlib.sha256(decoded_json).hexdigest(),
-                             "note": "JSON lines of the last pass over the list, every rank's decoded events in capture order; the same for every N"}
-        else:
-            samples_per_step = world * n_streams * n_samples
-            # the real per-rank package records, merged into the one canonical stream a single process would produce
-            tot_pk = sum(p["packages"] for p in per)
-            tot_ev = sum(p["events"] for p in per)
-            assert len(gathered["merged"]) == sum(len(p["pk"]) for p in per)
+        import hashlib
+        decoded_json = gathered["merged"]  # rank order = capture order: the single-process output
+        gathered_json = {"bytes": len(decoded_json), "lines": decoded_json.count(b"\n"), "sha256": hashlib.sha256(decoded_json).hexdigest(),
+                         "note": ("JSON lines of the last pass over the list, every rank's decoded events in capture order; the same for every N" if strong else
+                                  "JSON lines of the last step, every rank's decoded events in capture order (the ranks have their own batches)")}
+        tot_pk = sum(p["packages"] for p in per)
+        tot_msg = sum(p["events"] for p in per)
+        tot_bits = sum(p["digest"] for p in per)
+        samples_per_step = args.list_len * n_samples if strong else world * n_streams * n_samples
         value = samples_per_step * args.steps / elapsed / 1e6
         live_det_ms = float(np.mean(det_ms))  # HIP events on the launching stream, over the launches of the timed region
         det_s = live_det_ms / 1e3
@@ -523,8 +581,8 @@ def run_batched(args, ctxd):
                     "records gathered on rank 0") if strong else \
                    (f"configs[1]: batches of {n_batch} synthetic 250 kS/s cu8 OOK bursts x {n_samples} samples (every third capture a "
                     f"protocol-valid transmission of one of 12 real protocols, the others random payloads), all {len(devs)} default -R "
-                    f"decoders fanned out; a step = {args.batches} such batches per GPU submitted together (one detection grid of "
-                    f"{n_streams} captures), from pinned host memory to decoder callbacks on the host")
+                    f"decoders fanned out and their real decode_fn called; a step = {args.batches} such batches per GPU submitted together "
+                    f"(one detection grid of {n_streams} captures), from pinned host memory to decoded events (JSON lines) on the host")
         result = {
             "metric": METRIC, "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
@@ -533,7 +591,7 @@ def run_batched(args, ctxd):
                      "synthetic (resident in HBM when the timed region starts: --resident, the run rocprofv3 watches; three distinct inputs rotate)" if args.resident else
                      "synthetic (in pinned host memory when the timed region starts: every step's H2D copy is timed; three distinct inputs rotate)"),
             "config": {"workload": workload, "streams_per_launch": n_streams, "samples_per_stream": n_samples,
-                       "sample_rate": 250000, "decoders": len(devs), "host_dispatch_threads": threads,
+                       "sample_rate": 250000, "decoders": len(devs), "host_dispatch_threads": threads, "host_cpus": {"logical": os.cpu_count(), "cfs_quota": cpu_quota()},
                        "launches_per_step_per_gpu": per_step if strong else args.batches,
                        **({} if strong else {"captures_per_batch": n_batch, "batches_per_step_per_gpu": args.batches,
                                               "note": f"the {args.batches} launches of {n_batch} captures of a step are issued as ONE grid of {n_streams} workgroups"}),
@@ -541,18 +599,22 @@ def run_batched(args, ctxd):
             "roofline": {"bound": "hbm", "kernel": "k_wave<2> (IQ -> packages)", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": pmc_traffic("config2" if not strong else "config4", alg_bytes, det_s),
+                         "issue": ISSUE_NOTE,
                          "note": "achieved = 2 B/sample x samples of one launch / the kernel's mean launch duration over the timed region (HIP events on "
-                                 "the launching stream; the engines of the pipeline take turns on the kernels of a pass); the kernel is bound by wavefront "
-                                 "instruction issue, not by HBM (DESIGN.md 3.1)"},
+                                 "the launching stream; the engines of the pipeline take turns on the kernels of a pass).  `traffic` is NOT measured in "
+                                 "this run: it is the HBM byte count of the committed counter pass (profiles/, tools/pmc_run.sh) over this run's kernel "
+                                 "time.  The kernel is bound by wavefront instruction issue, not by HBM: see `issue` (DESIGN.md 3.1)"},
             "breakdown_ms": {"k_wave_timed_region": round(live_det_ms, 3), "k_wave_alone": round(solo_det_ms, 3), "gpu_leg_alone_incl_d2h": round(solo_tot_ms, 3),
                              "gpu_leg_overlapped": round(float(np.mean(tot_ms)), 3),
-                             "host_dispatch": round(float(np.mean(disp_s)) * 1e3, 3), "engines": pipe.n_eng},
+                             "host_dispatch": round(float(np.mean(disp_s)) * 1e3, 3), "host_replay_call": round(replay_ms, 3), "engines": pipe.n_eng},
             "kernel_only": {"value": round(n_streams * n_samples / (live_det_ms * 1e-3) / 1e6, 1), "unit": "Msamples/s"},
-            "packages_per_step": int(tot_pk), "events_per_step": int(tot_ev),
+            "packages_per_step": int(tot_pk), "decoded_messages_per_step": int(tot_msg), "bitbuffers_to_host_per_step": int(tot_bits),
+            "d2h_bytes_per_step_per_gpu": int(records["sent"][1]),
+            "decoders_behind_the_path": "the reference's real decode_fn (dropin/_build/libr433plugins.so), ordered multi-threaded replay, "
+                                        f"device-side pre-filter on, {int(sum(stateless))} of {len(stateless)} decoders declared stateless by the host",
+            "decoded_events_gathered": gathered_json,
             "gathered": [{k: v for k, v in p.items() if k != "pk"} for p in per],
         }
-        if strong:
-            result["decoded_events_gathered"] = gathered_json
     pipe_for_extra = pipe
 
     # ---- secondary measurements of the same run (rank 0, N = 1, the default workload only) ----
@@ -566,18 +628,39 @@ def run_batched(args, ctxd):
                                       "ms_per_step": round(el / k_res * 1e3, 3), "k_wave_ms": round(float(np.mean(det_res)), 3),
                                       "note": "the same pipeline without the H2D copy (inputs resident in HBM when the timed region starts)"}
     if rank == 0 and world == 1 and not strong and not args.quick:
-        # one more pass for the parity digest of batch 0
+        # Parity on one batch (the bounded sample the CPU legs run), two ways: (1) the decoded events -- the JSON lines of the
+        # real decoders behind the GPU path against those of the unmodified reference over the same captures; (2) every
+        # bitbuffer -- a checksum decode_fn on both sides (pre-filter off: the checksum wants every record).
+        import hashlib
+        e0 = pipe.engines[0]
+        pipe.on_host_leg = None
+        plug.take()
+        pipe.gpu_leg(0, src=batches[0][:n_batch])
+        e0.dispatch_ordered(plug.devices, None, threads)
+        gpu_text, gpu_msgs = plug.take()
+        e0.set_prefilter(0)
         ctx.sum = 0
         ctx.events = 0
-        pipe.on_host_leg = None
-        pipe.host_leg(0, pipe.gpu_leg(0, src=batches[0][:n_batch])[0])  # one batch: the bounded sample the CPU legs run
+        pipe.gpu_leg(0, src=batches[0][:n_batch])
+        e0.dispatch(rdev_arr, n_threads=threads)
+        e0.set_prefilter(1)
         gpu_digest, gpu_events = int(ctx.sum), int(ctx.events)
         if not args.no_cpu_baseline:
             try:
                 one, many, parity = cpu_baseline_config2(host_batches[0][:n_batch], devs, gpu_digest, gpu_events)
-                result["cpu_baseline"] = one
+                result["cpu_baseline_checksum_decode_fn"] = one
                 result["cpu_baseline_nproc"] = many
-                result["parity"] = parity
+                real, cpu_text = cpu_baseline_real_decoders(host_batches[0][:n_batch])
+                result["cpu_baseline"] = real if real else one
+                js = {"gpu_sha256": hashlib.sha256(gpu_text).hexdigest(), "gpu_lines": gpu_text.count(b"\n"),
+                      "cpu_sha256": hashlib.sha256(cpu_text).hexdigest() if cpu_text is not None else None,
+                      "cpu_lines": cpu_text.count(b"\n") if cpu_text is not None else None}
+                js["equal"] = bool(cpu_text is not None and gpu_text == cpu_text)
+                result["parity"] = ("decoded-json-sha256-match" if js["equal"] else "DECODED JSON MISMATCH" if cpu_text is not None else "decoded json not compared") \
+                    + "; bitbuffers: " + parity
+                result["parity_detail"] = {"decoded_json": js, "bitbuffers": parity,
+                                           "sample": f"batch 0: {n_batch} captures, the reference's real decoders on both sides (JSON lines of data_print_jsons); "
+                                                     "checksum decode_fn for the bitbuffers"}
             except Exception as e:  # the checker must not take the measurement down with it
                 result["cpu_baseline"] = None
                 result["parity"] = f"cpu baseline failed: {e}"
@@ -585,6 +668,10 @@ def run_batched(args, ctxd):
                 result["real_decoders"] = real_decoders_leg(host_batches[0][:n_batch], batches[0][:n_batch], devs, threads, local_rank)
             except Exception as e:
                 result["real_decoders"] = dict(error=str(e))
+            try:  # the other single-stream workloads of BASELINE.json under the same roof (short passes, inputs resident)
+                result["other_configs"] = other_configs_summary(args)
+            except Exception as e:
+                result["other_configs"] = dict(error=str(e))
     if rank == 0 and strong and world == 1 and not args.quick and host_first is not None:
         # parity of the first captures of the list, record for record, against the unmodified reference
         try:
@@ -705,8 +792,10 @@ def mixed_stream_config5(n_samples, seed=5):
     return out
 
 
-def run_stream(args, ctxd):
-    """configs 3 and 5: one long stream per GPU (a single stream does not shard across GPUs: replicas only)."""
+def run_stream(args, ctxd, parity_prefix=False):
+    """configs 3 and 5: one long stream per GPU (a single stream does not shard across GPUs: replicas only).
+    parity_prefix: the short form the default run appends (other_configs): the reference runs over the whole (shortened)
+    stream, whatever --quick / --no-cpu-baseline say."""
     import torch
 
     from oracle import pyoracle as po
@@ -714,7 +803,7 @@ def run_stream(args, ctxd):
     from rtl_433_amd.engine import BatchEngine, digest_plugin_addr, flow_cfg, load_device_table, make_rdevices
     rank, world, local_rank, dist = ctxd["rank"], ctxd["world"], ctxd["local_rank"], ctxd["dist"]
     devs, protocols, names = load_device_table()
-    threads = args.threads or max(1, min(32, (os.cpu_count() or 1) // max(1, world)))
+    threads = args.threads or replay_threads(world)
     if args.config == 3:
         n_samples = args.stream_samples or (64 << 20)
         ss, rate, freq = 4, 1024000, 868000000
@@ -806,7 +895,7 @@ def run_stream(args, ctxd):
                                               "histogram": {f"<{int(e)}" if e < 1e9 else "more": int(h) for e, h in zip(edges[1:], hist)},
                                               "note": "time from the stream being on the host (start of the pass) to the moment a burst's package has been through "
                                                       "every decoder; single-threaded replay in package order"}
-        if not args.no_cpu_baseline and not args.quick and po.have_ref():
+        if (parity_prefix or (not args.no_cpu_baseline and not args.quick)) and po.have_ref():
             try:
                 ref = po.Ref(record=False, **ref_kw)
                 if ref_levels:

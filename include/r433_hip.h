@@ -229,6 +229,15 @@ int r433_batch_dispatch_hooks(r433_batch *b, r433_r_device *const *devices, uint
  * and restored before it returns.  Returns the number of successful decode events. */
 int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices,
         r433_dispatch_hooks const *hooks, uint32_t n_threads);
+/* Decoders whose decode_fn is a function of its arguments alone -- it keeps nothing between calls and writes nothing but the
+ * bitbuffer it was handed and what it gives to output_fn / log_fn -- need not stay on one thread: with stateless[d] != 0 the
+ * ordered replay spreads the calls of decoder d over its threads in stretches of packages (statistics are added atomically,
+ * outputs committed in reference order as for every decoder).  One decoder's calls on one thread are what bounds the replay
+ * of a large batch (a TPMS decoder that searches every row of every bitbuffer: 0.6 M calls, 27 ms per 8192 captures), and
+ * of the reference's 335 default decoders only four keep state (secplus_v1, secplus_v2, ikea_sparsnas, arad_ms_meter:
+ * file-scope statics under src/devices).  Which decoders qualify is the HOST's knowledge about its plugins: the library
+ * cannot see it and the default is 0 for every decoder.  NULL: back to the default.  The flags stay with the engine. */
+int r433_batch_set_stateless(r433_batch *b, uint8_t const *stateless, uint32_t n_devices);
 /* per package of the last dispatch: the events its decoders reported (p_events) */
 int r433_batch_decoded(r433_batch *b, int const **per_package, uint32_t *count);
 

@@ -306,6 +306,18 @@ class Ref:
     def sink_count(self):
         return int(self.L.refh_sink_count())
 
+    def text_mode(self, on=True):
+        """Decoder messages (reference flow with call_real, and the plain devices) as JSON lines: take_text()."""
+        self.L.refh_text_mode.argtypes = [C.c_void_p, C.c_int]
+        self.L.refh_text_mode(self.h, int(on))
+
+    def take_text(self):
+        self.L.refh_take_text.restype = C.c_size_t
+        self.L.refh_take_text.argtypes = [C.POINTER(C.c_char_p)]
+        t = C.c_char_p()
+        n = self.L.refh_take_text(C.byref(t))
+        return C.string_at(t, n) if n else b""
+
     def add_rows(self, rows):
         """Register synthetic decoders (DEV_DTYPE timing rows, any modulation) after the devices registered so far."""
         rows = np.ascontiguousarray(rows, dtype=DEV_DTYPE)

@@ -262,11 +262,43 @@ void refh_add_rows(void *hv, r433_dev_timing const *rows, int n_rows)
  * replays bitbuffers produced elsewhere (bench.py's "real decoders" leg hands them to r433_batch_dispatch).  Their
  * output goes to a sink that counts and frees it.  Copies: the harness's own (recording) list is untouched. */
 static unsigned long g_sink_count;
+static int g_text_on; /* refh_text_mode: what decoders report is kept as JSON lines (the reference's own printer) */
+static blob g_text;
 static void sink_output(r_device *decoder, data_t *data)
 {
     (void)decoder;
+    if (g_text_on) {
+        char *line = data_print_jsons_dup(data);
+        if (line) {
+            blob_put(&g_text, line, strlen(line));
+            blob_put(&g_text, "\n", 1);
+            free(line);
+        }
+    }
     data_free(data);
     g_sink_count++;
+}
+
+/* on: every message a decoder hands out -- in the harness's own reference flow (call_real) and through the plain devices of
+ * refh_plain_devices alike -- is printed with data_print_jsons (src/data.c) into one buffer, a line per message, instead of
+ * going to the reference's output handlers: the text a host compares with what its own replay of the same decoders says. */
+void refh_text_mode(void *hv, int on)
+{
+    harness *h = hv;
+    g_text_on = on;
+    g_text.len = 0;
+    for (void **it = h->cfg->demod->r_devs.elems; it && *it; ++it)
+        ((r_device *)*it)->output_fn = on ? sink_output : data_acquired_handler;
+}
+
+/* the lines since the last call (valid until the next message) */
+size_t refh_take_text(char const **text)
+{
+    size_t const n = g_text.len;
+    if (text)
+        *text = g_text.data ? (char const *)g_text.data : "";
+    g_text.len = 0;
+    return n;
 }
 
 int refh_plain_devices(void *hv, r_device **out, int cap)

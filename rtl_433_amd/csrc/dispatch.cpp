@@ -385,64 +385,35 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
     bool const trace = (b->debug_flags & R433_DEBUG_DISPATCH_TRACE) != 0;
     auto const t_begin = std::chrono::steady_clock::now();
     auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+    struct CallEnd { // (declared first: runs after every other local has been given back)
+        bool on;
+        std::chrono::steady_clock::time_point t0;
+        ~CallEnd()
+        {
+            if (on)
+                fprintf(stderr, "r.dispatch: call returns after %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
+    } call_end{trace, t_begin};
     std::vector<double> dev_ms(trace ? n_devices : 0, 0.0);
 
-    // index: the events of every device, in package order (the stream is sorted by package, device, ordinal).  Built by
-    // the pool over package ranges of about equal bytes (h_pkg_off delimits a package's events): every thread counts its
-    // range per device, the counts are laid out device-major / range-minor, every thread fills its own slices.
     size_t const end = b->evt_bytes;
     uint32_t const *pkg_off = b->h_pkg_off.p;
-    unsigned const n_parts = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<uint32_t>(n_threads, 64), end / (256u << 10)));
-    std::vector<uint32_t> part_first(n_parts + 1, np);
-    part_first[0] = 0;
-    for (unsigned t = 1; t < n_parts; ++t) // the first package at or behind byte t / n_parts of the stream
-        part_first[t] = (uint32_t)(std::lower_bound(pkg_off, pkg_off + np, (uint32_t)(end / n_parts * t)) - pkg_off);
-    std::vector<uint32_t> part_count((size_t)n_parts * n_devices, 0);
     std::atomic<size_t> corrupt_at{SIZE_MAX};
     if (np && pkg_off[0] != 0)
         corrupt_at.store(0);
-    auto walk = [&](unsigned t, auto &&visit) {
-        size_t at = part_first[t] < np ? pkg_off[part_first[t]] : end;
-        size_t const stop = part_first[t + 1] < np ? pkg_off[part_first[t + 1]] : end;
-        while (at < stop) {
-            r433_evt_rec eh;
-            if (at + sizeof(eh) > stop) {
-                corrupt_at.store(at);
-                return;
-            }
-            memcpy(&eh, ev + at, sizeof(eh));
-            if (eh.dev >= n_devices || eh.pkg >= np || eh.total_bytes < sizeof(eh) || at + eh.total_bytes > stop) {
-                corrupt_at.store(at);
-                return;
-            }
-            visit(eh, at);
-            at += eh.total_bytes;
+    // one record of the stream at `at`, checked: false = the stream is corrupt there
+    auto record_at = [&](size_t at, size_t stop, r433_evt_rec &eh) -> bool {
+        if (at + sizeof(eh) > stop) {
+            corrupt_at.store(at);
+            return false;
         }
+        memcpy(&eh, ev + at, sizeof(eh));
+        if (eh.dev >= n_devices || eh.pkg >= np || eh.total_bytes < sizeof(eh) || at + eh.total_bytes > stop) {
+            corrupt_at.store(at);
+            return false;
+        }
+        return true;
     };
-    b->pool.run(n_parts, [&](unsigned t) {
-        uint32_t *mine = part_count.data() + (size_t)t * n_devices;
-        walk(t, [&](r433_evt_rec const &eh, size_t) { mine[eh.dev]++; });
-    });
-    if (corrupt_at.load() != SIZE_MAX || (np == 0 && end != 0))
-        return fail(R433_EHIP, "corrupt event stream at byte %zu", corrupt_at.load() == SIZE_MAX ? (size_t)0 : corrupt_at.load());
-    std::vector<uint32_t> dev_count(n_devices + 1, 0);
-    {
-        uint32_t run = 0;
-        for (uint32_t d = 0; d < n_devices; ++d) {
-            dev_count[d] = run;
-            for (unsigned t = 0; t < n_parts; ++t) {
-                uint32_t const c = part_count[(size_t)t * n_devices + d];
-                part_count[(size_t)t * n_devices + d] = run; // from a count to the slice's first slot
-                run += c;
-            }
-        }
-        dev_count[n_devices] = run;
-    }
-    std::vector<uint32_t> ev_off(dev_count[n_devices]);
-    b->pool.run(n_parts, [&](unsigned t) {
-        uint32_t *fill = part_count.data() + (size_t)t * n_devices;
-        walk(t, [&](r433_evt_rec const &eh, size_t at) { ev_off[fill[eh.dev]++] = (uint32_t)at; });
-    });
     std::vector<uint32_t> pkg_stream(np), pkg_type(np), pkg_start_ago(np);
     std::vector<uint8_t> skipped(np, 0); // hooks->package_filter said no: no decoder sees the package, no hook is called for it
     for (uint32_t p = 0; p < np; ++p) {
@@ -470,6 +441,24 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
         if (keep_log[d])
             devices[d]->log_fn = capture_log;
     }
+    struct PutBack { // whatever way this call ends, the decoders get their own output_fn / log_fn back
+        std::function<void()> fn;
+        bool done = false;
+        void now()
+        {
+            if (!done)
+                fn();
+            done = true;
+        }
+        ~PutBack() { now(); }
+    } put_back{[&]() {
+        for (uint32_t d = 0; d < n_devices; ++d) {
+            if (!devices[d])
+                continue;
+            devices[d]->output_fn = keep_out[d];
+            devices[d]->log_fn = keep_log[d];
+        }
+    }};
     std::vector<std::vector<Captured>> captured(n_threads);
     std::vector<std::atomic<int>> p_events(np);
     for (auto &x : p_events)
@@ -478,8 +467,116 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
     std::string err;
     std::mutex err_m;
 
+    // one bitbuffer to one decoder: what account_event does around decode_fn (src/pulse_slicer.c:26-66), on whichever thread
+    struct Tally {
+        unsigned n_ev = 0, n_ok = 0, n_msg = 0, fails[5] = {0, 0, 0, 0, 0};
+    };
+    auto call_one = [&](uint32_t dev, uint8_t const *rec, r433_evt_rec const &eh, r433_bitbuffer *bits, Tally &t) -> bool {
+        r433_r_device *rd = devices[dev];
+        inflate_bits(bits, rec, eh);
+        uint32_t used_rows = std::max<uint32_t>(eh.num_rows, eh.free_row);
+        g_current.stream = pkg_stream[eh.pkg];
+        g_current.package = eh.pkg;
+        g_current.device = dev;
+        g_current.ordinal = eh.ordinal;
+        g_current.package_type = pkg_type[eh.pkg];
+        g_current.start_ago = pkg_start_ago[eh.pkg];
+        g_capture.seq = 0;
+        int ret = 0;
+        if (rd && rd->decode_fn)
+            ret = rd->decode_fn(rd, bits);
+        t.n_ev += 1;
+        bool ok = true;
+        if (ret > 0) {
+            t.n_ok += 1;
+            t.n_msg += (unsigned)ret;
+            p_events[eh.pkg].fetch_add(ret, std::memory_order_relaxed);
+        }
+        else if (ret >= R433_DECODE_FAIL_SANITY) {
+            t.fails[-ret] += 1;
+        }
+        else {
+            std::lock_guard<std::mutex> g(err_m);
+            char buf[200];
+            snprintf(buf, sizeof(buf), "decoder \"%s\" gave invalid return value %d", rd && rd->name ? rd->name : "?", ret);
+            err = buf;
+            failed.store(1);
+            ok = false;
+        }
+        used_rows = std::max<uint32_t>(used_rows, std::max<uint32_t>(bits->num_rows, bits->free_row));
+        if (used_rows > R433_BITBUF_ROWS)
+            used_rows = R433_BITBUF_ROWS;
+        memset(bits->bb, 0, (size_t)used_rows * R433_BITBUF_COLS);
+        memset(bits, 0, offsetof(r433_bitbuffer, bb));
+        return ok;
+    };
+    auto book = [&](uint32_t dev, Tally const &t) { // (atomically: a stateless decoder's calls end on several threads)
+        r433_r_device *rd = devices[dev];
+        if (!rd || !t.n_ev)
+            return;
+        __atomic_fetch_add(&rd->decode_events, t.n_ev, __ATOMIC_RELAXED);
+        __atomic_fetch_add(&rd->decode_ok, t.n_ok, __ATOMIC_RELAXED);
+        __atomic_fetch_add(&rd->decode_messages, t.n_msg, __ATOMIC_RELAXED);
+        for (int f = 0; f < 5; ++f)
+            __atomic_fetch_add(&rd->decode_fails[f], t.fails[f], __ATOMIC_RELAXED);
+    };
+
+    // (Tried and dropped: serving the stateless decoders in ONE pass over the stream, every thread a stretch of packages,
+    // every record to its decoder as it comes -- sequential reads instead of a cache miss per record.  It was twice as slow per
+    // call, 171 ns against 75-100: a package's records go to 277 different decoders in turn, half a megabyte of decoder
+    // code cycling through a 32 KB instruction cache, where the walk per decoder keeps one decoder's code and branch history
+    // hot.  So: the walk per decoder, in stretches for the stateless ones, with the next records prefetched.)
+    std::vector<uint32_t> dev_count(n_devices + 1, 0);
+    std::vector<uint32_t> ev_off;
+    {
+    // index: the events of every device, in package order (the stream is sorted by package, device, ordinal).  Built by
+    // the pool over package ranges of about equal bytes (h_pkg_off delimits a package's events): every thread counts its
+    // range per device, the counts are laid out device-major / range-minor, every thread fills its own slices.
+    unsigned const n_parts = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<uint32_t>(n_threads, 64), end / (256u << 10)));
+    std::vector<uint32_t> part_first(n_parts + 1, np);
+    part_first[0] = 0;
+    for (unsigned t = 1; t < n_parts; ++t) // the first package at or behind byte t / n_parts of the stream
+        part_first[t] = (uint32_t)(std::lower_bound(pkg_off, pkg_off + np, (uint32_t)(end / n_parts * t)) - pkg_off);
+    std::vector<uint32_t> part_count((size_t)n_parts * n_devices, 0);
+    auto walk = [&](unsigned t, auto &&visit) {
+        size_t at = part_first[t] < np ? pkg_off[part_first[t]] : end;
+        size_t const stop = part_first[t + 1] < np ? pkg_off[part_first[t + 1]] : end;
+        while (at < stop) {
+            r433_evt_rec eh;
+            if (!record_at(at, stop, eh))
+                return;
+            visit(eh, at);
+            at += eh.total_bytes;
+        }
+    };
+    b->pool.run(n_parts, [&](unsigned t) {
+        uint32_t *mine = part_count.data() + (size_t)t * n_devices;
+        walk(t, [&](r433_evt_rec const &eh, size_t) { mine[eh.dev]++; });
+    });
+    if (corrupt_at.load() != SIZE_MAX || (np == 0 && end != 0))
+        return fail(R433_EHIP, "corrupt event stream at byte %zu", corrupt_at.load() == SIZE_MAX ? (size_t)0 : corrupt_at.load());
+    {
+        uint32_t run = 0;
+        for (uint32_t d = 0; d < n_devices; ++d) {
+            dev_count[d] = run;
+            for (unsigned t = 0; t < n_parts; ++t) {
+                uint32_t const c = part_count[(size_t)t * n_devices + d];
+                part_count[(size_t)t * n_devices + d] = run; // from a count to the slice's first slot
+                run += c;
+            }
+        }
+        dev_count[n_devices] = run;
+    }
+    ev_off.resize(dev_count[n_devices]);
+    b->pool.run(n_parts, [&](unsigned t) {
+        uint32_t *fill = part_count.data() + (size_t)t * n_devices;
+        walk(t, [&](r433_evt_rec const &eh, size_t at) { ev_off[fill[eh.dev]++] = (uint32_t)at; });
+    });
+    }
+    b->n_events = dev_count[n_devices]; // (the index has walked and checked the whole stream: r433_batch_events need not count again)
+    b->events_counted = true;
     if (trace)
-        fprintf(stderr, "r.dispatch: index of %u records over %u packages %.3f ms\n", dev_count[n_devices], np, since(t_begin));
+        fprintf(stderr, "r.dispatch: engine %p index of %u records over %u packages %.3f ms\n", (void *)b, dev_count[n_devices], np, since(t_begin));
     for (uint32_t li = 0; li < b->prio_levels.size() && !failed.load(); ++li) {
         auto const t_level = std::chrono::steady_clock::now();
         uint32_t const level = b->prio_levels[li];
@@ -487,85 +584,69 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
         for (uint32_t d = 0; d < n_devices; ++d)
             if (b->timing[d].priority == level && dev_count[d + 1] > dev_count[d])
                 devs_of_level.push_back(d);
-        // heaviest decoders first: the pass ends when the last thread does
-        std::sort(devs_of_level.begin(), devs_of_level.end(), [&](uint32_t x, uint32_t y) {
-            return dev_count[x + 1] - dev_count[x] > dev_count[y + 1] - dev_count[y];
-        });
+        // Work items: a decoder's records in package order -- all of them for a decoder that may keep state between calls,
+        // stretches of them for one the host declared stateless (r433_batch_set_stateless).  Heaviest first: the pass ends
+        // when the last thread does.
+        struct Item {
+            uint32_t dev, first, last;
+        };
+        std::vector<Item> items;
+        // records per item of a stateless decoder: a third of a millisecond of a cheap decoder -- small enough that the pass ends
+        // with every thread busy (tests: R433_DEBUG_SMALL_STRETCH, a handful)
+        uint32_t const kStretch = (b->debug_flags & R433_DEBUG_SMALL_STRETCH) ? 5u : 6144u;
+        for (uint32_t d : devs_of_level) {
+            uint32_t const first = dev_count[d], last = dev_count[d + 1];
+            bool const split = d < b->stateless.size() && b->stateless[d] && last - first > kStretch + kStretch / 2;
+            if (!split) {
+                items.push_back({d, first, last});
+                continue;
+            }
+            uint32_t const parts = (last - first + kStretch - 1) / kStretch;
+            for (uint32_t k = 0; k < parts; ++k)
+                items.push_back({d, first + (uint32_t)((uint64_t)(last - first) * k / parts), first + (uint32_t)((uint64_t)(last - first) * (k + 1) / parts)});
+        }
+        std::stable_sort(items.begin(), items.end(), [](Item const &x, Item const &y) { return x.last - x.first > y.last - y.first; });
         // a package whose lower levels produced an event is closed for this level (src/r_api.c:442)
+        // (the lowest level sees every package: its own decoders' events do not close it)
         std::vector<uint8_t> open(np);
         for (uint32_t p = 0; p < np; ++p)
-            open[p] = !skipped[p] && p_events[p].load(std::memory_order_relaxed) == 0;
+            open[p] = !skipped[p] && (li == 0 || p_events[p].load(std::memory_order_relaxed) == 0);
         std::atomic<uint32_t> cursor{0};
-        uint32_t const nt = std::max<uint32_t>(1, std::min<uint32_t>(n_threads, (uint32_t)devs_of_level.size()));
+        uint32_t const nt = std::max<uint32_t>(1, std::min<uint32_t>(n_threads, (uint32_t)items.size()));
         b->pool.run(nt, [&](unsigned w) {
             r433_bitbuffer *bits = (r433_bitbuffer *)calloc(1, sizeof(r433_bitbuffer));
             g_capture.out = &captured[w];
             g_capture.level_rank = li;
             for (;;) {
                 uint32_t const k = cursor.fetch_add(1, std::memory_order_relaxed);
-                if (k >= devs_of_level.size() || failed.load(std::memory_order_relaxed))
+                if (k >= items.size() || failed.load(std::memory_order_relaxed))
                     break;
-                uint32_t const dev = devs_of_level[k];
-                r433_r_device *rd = devices[dev];
+                uint32_t const dev = items[k].dev;
                 auto const t_dev = std::chrono::steady_clock::now();
-                unsigned n_ev = 0, n_ok = 0, n_msg = 0, fails[5] = {0, 0, 0, 0, 0};
-                for (uint32_t e = dev_count[dev]; e < dev_count[dev + 1]; ++e) {
+                Tally t;
+                for (uint32_t e = items[k].first; e < items[k].last; ++e) {
                     uint8_t const *rec = ev + ev_off[e];
+                    if (e + 12 < items[k].last) // a decoder's records lie a package's worth of other decoders' apart: every one a cache miss
+                        __builtin_prefetch(ev + ev_off[e + 12]);
                     r433_evt_rec eh;
                     memcpy(&eh, rec, sizeof(eh));
                     if (!open[eh.pkg])
                         continue;
-                    inflate_bits(bits, rec, eh);
-                    uint32_t used_rows = std::max<uint32_t>(eh.num_rows, eh.free_row);
-                    g_current.stream = pkg_stream[eh.pkg];
-                    g_current.package = eh.pkg;
-                    g_current.device = dev;
-                    g_current.ordinal = eh.ordinal;
-                    g_current.package_type = pkg_type[eh.pkg];
-                    g_current.start_ago = pkg_start_ago[eh.pkg];
-                    g_capture.seq = 0;
-                    int ret = 0;
-                    if (rd && rd->decode_fn)
-                        ret = rd->decode_fn(rd, bits);
-                    n_ev += 1;
-                    if (ret > 0) {
-                        n_ok += 1;
-                        n_msg += (unsigned)ret;
-                        p_events[eh.pkg].fetch_add(ret, std::memory_order_relaxed);
-                    }
-                    else if (ret >= R433_DECODE_FAIL_SANITY) {
-                        fails[-ret] += 1;
-                    }
-                    else {
-                        std::lock_guard<std::mutex> g(err_m);
-                        char buf[200];
-                        snprintf(buf, sizeof(buf), "decoder \"%s\" gave invalid return value %d", rd && rd->name ? rd->name : "?", ret);
-                        err = buf;
-                        failed.store(1);
+                    if (!call_one(dev, rec, eh, bits, t))
                         break;
-                    }
-                    used_rows = std::max<uint32_t>(used_rows, std::max<uint32_t>(bits->num_rows, bits->free_row));
-                    if (used_rows > R433_BITBUF_ROWS)
-                        used_rows = R433_BITBUF_ROWS;
-                    memset(bits->bb, 0, (size_t)used_rows * R433_BITBUF_COLS);
-                    memset(bits, 0, offsetof(r433_bitbuffer, bb));
                 }
-                if (trace)
-                    dev_ms[dev] = since(t_dev);
-                if (rd) { // this thread is the only one that touches this decoder
-                    rd->decode_events += n_ev;
-                    rd->decode_ok += n_ok;
-                    rd->decode_messages += n_msg;
-                    for (int f = 0; f < 5; ++f)
-                        rd->decode_fails[f] += fails[f];
+                if (trace) {
+                    std::lock_guard<std::mutex> g(err_m);
+                    dev_ms[dev] += since(t_dev);
                 }
+                book(dev, t);
             }
             g_capture.out = nullptr;
             digest_publish();
             free(bits);
         });
         if (trace)
-            fprintf(stderr, "r.dispatch: level %u, %zu decoders on %u threads %.3f ms\n", level, devs_of_level.size(), nt, since(t_level));
+            fprintf(stderr, "r.dispatch: level %u, %zu decoders in %zu items on %u threads %.3f ms\n", level, devs_of_level.size(), items.size(), nt, since(t_level));
     }
     if (trace) {
         std::vector<uint32_t> by(n_devices);
@@ -580,12 +661,7 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
         fprintf(stderr, "\n");
     }
     auto const t_commit = std::chrono::steady_clock::now();
-    for (uint32_t d = 0; d < n_devices; ++d) {
-        if (!devices[d])
-            continue;
-        devices[d]->output_fn = keep_out[d];
-        devices[d]->log_fn = keep_log[d];
-    }
+    put_back.now();
 
     // commit: what the decoders handed out, in the order the single-threaded replay produces it
     std::vector<Captured> all;
@@ -657,6 +733,20 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
         return fail(R433_EDECODER, "%s", err.c_str());
     apply_prefilter_counts(b, devices, n_devices);
     return decoded;
+}
+
+int r433_batch_set_stateless(r433_batch *b, uint8_t const *stateless, uint32_t n_devices)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    if (!stateless) {
+        b->stateless.clear();
+        return 0;
+    }
+    if (n_devices != b->timing.size())
+        return fail(R433_EINVAL, "one flag for each of the %zu devices the engine was created with", b->timing.size());
+    b->stateless.assign(stateless, stateless + n_devices);
+    return 0;
 }
 
 int r433_batch_decoded(r433_batch *b, int const **per_package, uint32_t *count)

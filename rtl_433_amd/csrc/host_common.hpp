@@ -231,6 +231,7 @@ struct r433_batch {
     bool events_counted = false;
     std::vector<uint32_t> stream_samples; // per capture of the last run (as the detector saw them)
     std::vector<int> pkg_decoded; // per package: events its decoders reported in the last dispatch
+    std::vector<uint8_t> stateless; // per device: decode_fn keeps nothing between calls (r433_batch_set_stateless)
     std::vector<int32_t> pkg_quality; // per package: the caller's analyzer verdict (r433_batch_set_package_quality; grab mode 4)
     bool dispatched = false;
 

@@ -101,6 +101,12 @@ class BatchEngine:
                                                 C.byref(hooks) if hooks is not None else None, n_threads)
         return _lib.check(rc, "r433_batch_dispatch_ordered", self.L)
 
+    def set_stateless(self, flags):
+        """flags: ctypes uint8 array, one per device (plugins.stateless_flags), or None (r433_batch_set_stateless)"""
+        rc = self.L.r433_batch_set_stateless(self.h, C.cast(flags, C.c_void_p) if flags is not None else None,
+                                             len(flags) if flags is not None else 0)
+        return _lib.check(rc, "r433_batch_set_stateless", self.L)
+
     def probe_prefilter(self, rdevices):
         """Learn which bitbuffers each decoder provably refuses on its head alone (r433_batch_probe_prefilter); from the
         next run on the slicer kernel drops those records.  -> number of decoders with a table."""
@@ -187,6 +193,14 @@ class BatchEngine:
         p, n, c = C.c_void_p(), C.c_size_t(), C.c_uint32()
         _lib.check(fn(self.h, C.byref(p), C.byref(n), C.byref(c)), fn.__name__, self.L)
         return (C.string_at(p, n.value) if n.value else b""), c.value
+
+    def sizes(self):
+        """(package bytes, packages, event-record bytes, event records) of the last run -- no copies"""
+        p, n, c = C.c_void_p(), C.c_size_t(), C.c_uint32()
+        _lib.check(self.L.r433_batch_packages(self.h, C.byref(p), C.byref(n), C.byref(c)), "r433_batch_packages", self.L)
+        pk = (n.value, c.value)
+        _lib.check(self.L.r433_batch_events(self.h, C.byref(p), C.byref(n), C.byref(c)), "r433_batch_events", self.L)
+        return pk[0], pk[1], n.value, c.value
 
     def packages(self):
         return self._blob(self.L.r433_batch_packages)

@@ -287,8 +287,8 @@ def test_run_host_all_empty(backend):
     eng.close()
 
 
-@pytest.mark.parametrize("threads", [1, 4])
-def test_dispatch_ordered_equals_single_thread(threads, backend):
+@pytest.mark.parametrize("threads,stateless", [(1, False), (4, False), (4, True)])
+def test_dispatch_ordered_equals_single_thread(threads, stateless, backend):
     """r433_batch_dispatch_ordered: decoders spread over threads, each decoder's calls in reference order, the priority
     rule kept, and what decoders hand to output_fn / log_fn committed in the order of the single-threaded replay."""
     devs = _devices()
@@ -340,7 +340,16 @@ def test_dispatch_ordered_equals_single_thread(threads, backend):
             o.log_fn = C.cast(real_log, C.c_void_p)
         null_event = C.cast(None, _lib.HOOK_EVENT_FN)
         hooks = _lib.DispatchHooks(None, begin, null_event, end)
+        if ordered and stateless:
+            # every decoder declared stateless (r433_batch_set_stateless): its calls go out in stretches of five records to
+            # whichever thread is free -- hooks, outputs, statistics and events stay those of the single-threaded replay
+            eng.set_stateless((C.c_uint8 * len(devs))(*([1] * len(devs))))
+            eng.set_debug(8)
         n = eng.dispatch_ordered(rdevs, hooks, threads) if ordered else eng.dispatch_hooks(rdevs, hooks)
+        if ordered and stateless:
+            per_dev_calls = {d: sorted(v) for d, v in per_dev_calls.items()}  # (a decoder's calls: the same set, any thread)
+            eng.set_stateless(None)
+            eng.set_debug(0)
         stats = [(o.decode_events, o.decode_ok, o.decode_messages, list(o.decode_fails)) for o in objs]
         fns = all(o.output_fn == C.cast(real_out, C.c_void_p).value and o.log_fn == C.cast(real_log, C.c_void_p).value for o in objs)
         return n, trace, per_dev_calls, stats, list(eng.decoded()), fns
@@ -349,6 +358,8 @@ def test_dispatch_ordered_equals_single_thread(threads, backend):
     b = run(True)
     assert a[0] == b[0] and a[0] > 0
     assert a[1] == b[1]            # hooks and committed outputs: same sequence
+    if stateless:
+        a = (a[0], a[1], {d: sorted(v) for d, v in a[2].items()}) + a[3:]
     assert a[2] == b[2]            # every decoder saw the same calls in the same order (priority gating included)
     assert a[3] == b[3] and a[4] == b[4]
     assert a[5] and b[5]           # output_fn / log_fn restored

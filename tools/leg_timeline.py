@@ -1,7 +1,9 @@
 """Where a step of the software pipeline goes (GPU box): the bench's Pipeline (bench.py) over resident inputs with the
 library's stage stamps (R433_TRACE_LEGS=1: enter / turn / detected / sliced / mirrored per pass and engine) and the host's
 own (submit, result, replay begin / end), merged into one timeline on the monotonic clock.
-    python tools/leg_timeline.py [steps] [engines] [exclusive level]
+    python tools/leg_timeline.py [steps] [engines] [exclusive level] [threads] [real: 0 | 1]
+real = 1: the reference's real decoders (dropin/_build/libr433plugins.so) behind the ordered replay, pre-filter on -- the
+bench's headline pipeline; 0: the checksum decode_fn behind the plain multi-threaded replay.
 Prints per stage the mean duration over the steps and, for the last three steps, every stamp in order."""
 import ctypes as C, os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,12 +20,22 @@ from rtl_433_amd.engine import digest_plugin_addr, flow_cfg, load_device_table, 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 n_eng = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 bench.EXCLUSIVE = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+threads = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+real = len(sys.argv) > 5 and int(sys.argv[5]) != 0
 host = np.tile(synth.ook_batch(1024, 65536, 250000, seed0=0), (8, 1))
 batches = [torch.from_numpy(np.roll(host, 341 * k, axis=0).copy()).cuda() for k in range(3)]
 devs, protocols, names = load_device_table()
 ctx = _lib.DigestCtx(0, 0)
 rdev_arr, rdev_objs = make_rdevices(devs, digest_plugin_addr(), C.addressof(ctx), names, protocols)
-pipe = bench.Pipeline(lambda: flow_cfg(2, 250000), devs, rdev_arr, 32, n_eng, 0)
+if real:
+    from rtl_433_amd import plugins
+    plug = plugins.Plugins()
+    pipe = bench.Pipeline(lambda: flow_cfg(2, 250000), devs, plug.devices, threads, n_eng, 0, on_host_leg=lambda k, e, n: plug.take(), ordered=True)
+    for e in pipe.engines:
+        e.set_stateless(plugins.stateless_flags(plug.devices))
+        e.probe_prefilter(plug.devices)
+else:
+    pipe = bench.Pipeline(lambda: flow_cfg(2, 250000), devs, rdev_arr, threads, n_eng, 0)
 stamps = []  # (ms, who, what)
 
 
@@ -88,7 +100,7 @@ for line in text.decode(errors="replace").splitlines():
             order[h] = order.get(h, -1) + 1
         stamps.append((float(ms), f"eng{e}", f"{what} (pass {order.get(h, 0)} of this engine)"))
 stamps.sort()
-print(f"{steps} steps over {n_eng} engines, turn level {bench.EXCLUSIVE}: {(t1 - t0) / steps:.2f} ms per step")
+print(f"{steps} steps over {n_eng} engines, turn level {bench.EXCLUSIVE}, {threads} replay threads, {'real decoders (ordered, pre-filter)' if real else 'checksum decode_fn'}: {(t1 - t0) / steps:.2f} ms per step")
 # mean stage durations from the library's stamps
 per = {}
 last = {}
