@@ -635,6 +635,7 @@ int run_slice_and_mirror(RunCtx &r)
     b->n_pkgs = r.total_pkgs;
     b->n_events = 0;
     b->pkg_bytes = b->evt_bytes = 0;
+    b->slices_valid = false;
     uint32_t const n_devs = (uint32_t)b->timing.size();
     uint32_t const max_pkgs = std::max<uint32_t>(r.total_pkgs, 1);
 
@@ -674,6 +675,7 @@ int run_slice_and_mirror(RunCtx &r)
         lp.cursor = b->d_slice_cursor.p;
     }
     bool placed = false; // the event records are in d_events already (large batches: stretch by stretch)
+    bool want_index = false; // the slice index of this run is being made
     lp.pkg_begin = 0;
     lp.pkg_end = max_pkgs;
     b->pf_ran = b->pf_accounted = false;
@@ -763,6 +765,13 @@ int run_slice_and_mirror(RunCtx &r)
                 HIP_TRY(hipEventRecord(b->ev[3], r.st));
             launch_scan_u32(b->d_pkg_bytes.p, b->d_pkg_off.p, b->d_scal.p, max_pkgs, b->d_scal.p + 3, r.st);
         }
+        // the slice index: how many non-empty (package, decoder) slices each decoder has (the sizes are final here)
+        uint32_t const idx_blocks = slice_index_blocks(r.total_pkgs);
+        if ((rc = b->d_idx_cnt.ensure((size_t)idx_blocks * n_devs + 16)) || (rc = b->d_slice_start.ensure(n_devs + 16)))
+            return rc;
+        launch_slice_index_count(b->d_sizes.p, b->d_scal.p, max_pkgs, r.total_pkgs, n_devs, b->d_idx_cnt.p, b->d_slice_start.p, b->d_scal.p + 4, r.st);
+        HIP_TRY(hipGetLastError());
+        want_index = true;
     }
     else {
         HIP_TRY(hipMemsetAsync(b->d_scal.p + 3, 0, sizeof(uint32_t), r.st));
@@ -771,10 +780,11 @@ int run_slice_and_mirror(RunCtx &r)
     }
     if (b->profiling)
         HIP_TRY(hipEventRecord(b->ev[4], r.st));
-    HIP_TRY(hipMemcpyAsync(b->h_scal.p, b->d_scal.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, r.st));
+    HIP_TRY(hipMemcpyAsync(b->h_scal.p, b->d_scal.p, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, r.st));
     HIP_TRY(stream_wait(b, r.st));
     size_t const pkg_bytes = b->h_scal.p[2];
     size_t const evt_bytes = b->h_scal.p[3];
+    uint32_t const n_slices = want_index ? b->h_scal.p[4] : 0u;
     // the scans saturate at 0xffffffff (k_scan_u32): offsets are 32-bit by format, a larger batch has to be split
     if (evt_bytes > 0xf0000000ull)
         return fail(R433_EOVERFLOW, "event stream of this batch exceeds 3.75 GiB: run it in smaller batches");
@@ -794,6 +804,12 @@ int run_slice_and_mirror(RunCtx &r)
             lp.events = b->d_events.p;
             lp.events_cap = (uint32_t)std::min<size_t>(b->d_events.cap, 0xffffffffu);
             launch_slice_write(lp, r.total_pkgs, r.st);
+        }
+        if (want_index && n_slices) { // where every decoder's slices lie, now that the offsets are final (k_dev_prefix)
+            if ((rc = b->d_slices.ensure(n_slices)) || (rc = b->h_slices.ensure(n_slices)) || (rc = b->h_slice_start.ensure(n_devs + 16)))
+                return rc;
+            launch_slice_index_fill(b->d_sizes.p, b->d_dev_off.p, b->d_pkg_off.p, b->d_scal.p, max_pkgs, r.total_pkgs, n_devs, b->d_idx_cnt.p,
+                    b->d_slices.p, n_slices, r.st);
         }
         HIP_TRY(hipGetLastError());
     }
@@ -817,6 +833,10 @@ int run_slice_and_mirror(RunCtx &r)
             hipMemcpyDeviceToHost, r.st));
     if (lp.pf_counts)
         HIP_TRY(hipMemcpyAsync(b->h_pf_counts.p, b->d_pf_counts.p, (size_t)n_devs * 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, r.st));
+    if (want_index && n_slices) {
+        HIP_TRY(hipMemcpyAsync(b->h_slices.p, b->d_slices.p, (size_t)n_slices * sizeof(uint2), hipMemcpyDeviceToHost, r.st));
+        HIP_TRY(hipMemcpyAsync(b->h_slice_start.p, b->d_slice_start.p, (size_t)(n_devs + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, r.st));
+    }
     if (b->logic_on && r.d_iq)
         HIP_TRY(hipMemcpyAsync(b->h_logic.p, b->d_logic.p, (size_t)r.n_streams * b->logic_stride, hipMemcpyDeviceToHost, r.st));
     if (b->profiling)
@@ -835,6 +855,8 @@ int run_slice_and_mirror(RunCtx &r)
         }
     }
     b->evt_bytes = evt_bytes;
+    b->n_slices = n_slices;
+    b->slices_valid = want_index && n_slices > 0;
     b->pf_ran = lp.pf_counts != nullptr;
     b->events_counted = false;
     b->dispatched = false;
@@ -872,6 +894,7 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
         b->n_streams = 0;
         b->n_pkgs = b->n_events = 0;
         b->pkg_bytes = b->evt_bytes = 0;
+        b->slices_valid = false;
         return 0;
     }
     if (!d_iq || (stride_bytes & 15u) || ((uintptr_t)d_iq & 15u))
@@ -958,6 +981,7 @@ int r433_batch_run_pulses(r433_batch *b, r433_pulse_data const *pulses, uint32_t
         b->n_streams = 0;
         b->n_pkgs = b->n_events = 0;
         b->pkg_bytes = b->evt_bytes = 0;
+        b->slices_valid = false;
         return 0;
     }
     if (!pulses)

@@ -526,9 +526,20 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
     // call, 171 ns against 75-100: a package's records go to 277 different decoders in turn, half a megabyte of decoder
     // code cycling through a 32 KB instruction cache, where the walk per decoder keeps one decoder's code and branch history
     // hot.  So: the walk per decoder, in stretches for the stateless ones, with the next records prefetched.)
+    // Where a decoder's records lie.  With the slice index of the run (slicer_kernels.hip k_index_*: per decoder the (offset,
+    // bytes) of its non-empty slices, made on the device) nothing is searched here: dev_count counts slices and an item walks
+    // the records of its slices.  Without it (runs that made none) the host indexes every record itself.
+    bool const by_slice = b->slices_valid && n_devices == b->timing.size();
+    uint2 const *const slices = b->h_slices.p;
     std::vector<uint32_t> dev_count(n_devices + 1, 0);
     std::vector<uint32_t> ev_off;
-    {
+    if (by_slice) {
+        for (uint32_t d = 0; d <= n_devices; ++d)
+            dev_count[d] = b->h_slice_start.p[d];
+        if (dev_count[n_devices] != b->n_slices)
+            return fail(R433_EHIP, "slice index: %u entries listed, %u made", dev_count[n_devices], b->n_slices);
+    }
+    else {
     // index: the events of every device, in package order (the stream is sorted by package, device, ordinal).  Built by
     // the pool over package ranges of about equal bytes (h_pkg_off delimits a package's events): every thread counts its
     // range per device, the counts are laid out device-major / range-minor, every thread fills its own slices.
@@ -573,10 +584,14 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
         walk(t, [&](r433_evt_rec const &eh, size_t at) { ev_off[fill[eh.dev]++] = (uint32_t)at; });
     });
     }
-    b->n_events = dev_count[n_devices]; // (the index has walked and checked the whole stream: r433_batch_events need not count again)
-    b->events_counted = true;
+    if (!by_slice) {
+        b->n_events = dev_count[n_devices]; // (the index has walked and checked the whole stream: r433_batch_events need not count again)
+        b->events_counted = true;
+    }
     if (trace)
-        fprintf(stderr, "r.dispatch: engine %p index of %u records over %u packages %.3f ms\n", (void *)b, dev_count[n_devices], np, since(t_begin));
+        fprintf(stderr, "r.dispatch: engine %p index of %u %s over %u packages %.3f ms\n", (void *)b, dev_count[n_devices], by_slice ? "slices (made on the device)" : "records",
+                np, since(t_begin));
+    std::atomic<uint64_t> walked{0}; // records met on the way through the slices (every decoder's, whatever the levels let through)
     for (uint32_t li = 0; li < b->prio_levels.size() && !failed.load(); ++li) {
         auto const t_level = std::chrono::steady_clock::now();
         uint32_t const level = b->prio_levels[li];
@@ -593,7 +608,7 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
         std::vector<Item> items;
         // records per item of a stateless decoder: a third of a millisecond of a cheap decoder -- small enough that the pass ends
         // with every thread busy (tests: R433_DEBUG_SMALL_STRETCH, a handful)
-        uint32_t const kStretch = (b->debug_flags & R433_DEBUG_SMALL_STRETCH) ? 5u : 6144u;
+        uint32_t const kStretch = (b->debug_flags & R433_DEBUG_SMALL_STRETCH) ? 5u : by_slice ? 1536u : 6144u; // (a slice holds ~4 records)
         for (uint32_t d : devs_of_level) {
             uint32_t const first = dev_count[d], last = dev_count[d + 1];
             bool const split = d < b->stateless.size() && b->stateless[d] && last - first > kStretch + kStretch / 2;
@@ -624,27 +639,48 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
                 uint32_t const dev = items[k].dev;
                 auto const t_dev = std::chrono::steady_clock::now();
                 Tally t;
-                for (uint32_t e = items[k].first; e < items[k].last; ++e) {
-                    uint8_t const *rec = ev + ev_off[e];
-                    if (e + 12 < items[k].last) // a decoder's records lie a package's worth of other decoders' apart: every one a cache miss
-                        __builtin_prefetch(ev + ev_off[e + 12]);
-                    r433_evt_rec eh;
-                    memcpy(&eh, rec, sizeof(eh));
-                    if (!open[eh.pkg])
+                bool go_on = true;
+                uint32_t walked_here = 0;
+                for (uint32_t e = items[k].first; e < items[k].last && go_on; ++e) {
+                    // a decoder's records lie a package's worth of other decoders' apart: every slice a cache miss
+                    if (e + 12 < items[k].last)
+                        __builtin_prefetch(ev + (by_slice ? slices[e + 12].x : ev_off[e + 12]));
+                    if (!by_slice) {
+                        uint8_t const *rec = ev + ev_off[e];
+                        r433_evt_rec eh;
+                        memcpy(&eh, rec, sizeof(eh));
+                        if (open[eh.pkg])
+                            go_on = call_one(dev, rec, eh, bits, t);
                         continue;
-                    if (!call_one(dev, rec, eh, bits, t))
-                        break;
+                    }
+                    size_t at = slices[e].x;
+                    size_t const stop = std::min<size_t>(at + slices[e].y, end);
+                    while (at < stop && go_on) { // the records of one (package, decoder) slice
+                        walked_here += 1;
+                        r433_evt_rec eh;
+                        if (!record_at(at, stop, eh) || eh.dev != dev) {
+                            corrupt_at.store(at);
+                            go_on = false;
+                            break;
+                        }
+                        if (open[eh.pkg])
+                            go_on = call_one(dev, ev + at, eh, bits, t);
+                        at += eh.total_bytes;
+                    }
                 }
                 if (trace) {
                     std::lock_guard<std::mutex> g(err_m);
                     dev_ms[dev] += since(t_dev);
                 }
+                walked.fetch_add(walked_here, std::memory_order_relaxed);
                 book(dev, t);
             }
             g_capture.out = nullptr;
             digest_publish();
             free(bits);
         });
+        if (corrupt_at.load() != SIZE_MAX)
+            return fail(R433_EHIP, "corrupt event stream at byte %zu", corrupt_at.load());
         if (trace)
             fprintf(stderr, "r.dispatch: level %u, %zu decoders in %zu items on %u threads %.3f ms\n", level, devs_of_level.size(), items.size(), nt, since(t_level));
     }
@@ -659,6 +695,10 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
             fprintf(stderr, " %s %.3f ms / %u calls;", devices[by[k]] && devices[by[k]]->name ? devices[by[k]]->name : "?", dev_ms[by[k]],
                     dev_count[by[k] + 1] - dev_count[by[k]]);
         fprintf(stderr, "\n");
+    }
+    if (by_slice && !failed.load()) { // every slice has been walked once: that was every record of the stream
+        b->n_events = (uint32_t)walked.load();
+        b->events_counted = true;
     }
     auto const t_commit = std::chrono::steady_clock::now();
     put_back.now();

@@ -241,6 +241,11 @@ void r433_batch_destroy(r433_batch *b)
     b->d_tile_max.release();
     b->d_order.release();
     b->d_wg.release();
+    b->d_idx_cnt.release();
+    b->d_slice_start.release();
+    b->d_slices.release();
+    b->h_slice_start.release();
+    b->h_slices.release();
     b->d_pkg_order.release();
     b->d_slice_cursor.release();
     b->d_pf_tables.release();
@@ -400,7 +405,7 @@ int r433_batch_events(r433_batch *b, uint8_t const **blob, size_t *len, uint32_t
         *blob = b->h_events.p;
     if (len)
         *len = b->evt_bytes;
-    if (!b->events_counted) {
+    if (count && !b->events_counted) { // (a walk over the whole stream: only for a caller that asks)
         uint32_t n = 0;
         size_t at = 0;
         while (at + sizeof(r433_evt_rec) <= b->evt_bytes) {

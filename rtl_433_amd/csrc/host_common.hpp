@@ -212,6 +212,13 @@ struct r433_batch {
     PinBuf<StreamState> h_state;
     uint32_t last_segments = 0, last_redone = 0;
     DevBuf<uint32_t> d_dir_stream, d_dir_off, d_rec_bytes, d_rec_off, d_sizes, d_dev_off, d_pkg_bytes, d_pkg_off;
+    // the slice index (slicer_kernels.hip k_index_*): per decoder the (offset, bytes) of its slices of the event stream
+    DevBuf<uint32_t> d_idx_cnt, d_slice_start;
+    DevBuf<uint2> d_slices;
+    PinBuf<uint32_t> h_slice_start;
+    PinBuf<uint2> h_slices;
+    uint32_t n_slices = 0;
+    bool slices_valid = false;
     DevBuf<uint32_t> d_pkg_order, d_slice_cursor; // the sizing pass of the slicers: packages heaviest first, a cursor per chunk of devices
     DevBuf<uint8_t> d_pkg_blob, d_events, d_stage, d_converted;
     DevBuf<r433_analysis> d_analysis;

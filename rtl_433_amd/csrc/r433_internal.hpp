@@ -182,6 +182,13 @@ void launch_gather_packages(uint8_t const *arena, uint32_t arena_stride, uint32_
         uint32_t dst_cap, uint32_t grid_pkgs, hipStream_t st);
 void launch_slice_count(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st);
 void launch_slice_write(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st);
+// the slice index (slicer_kernels.hip): per decoder the (offset, bytes) of its non-empty slices of the event stream, package order.
+// count: cnt[blocks][n_devs] (scratch, then every block's first entry), start[n_devs + 1], *total; fill: after dev_off / pkg_off are final
+uint32_t slice_index_blocks(uint32_t n_pkgs);
+void launch_slice_index_count(uint32_t const *sizes, uint32_t const *n_pkgs_ptr, uint32_t max_pkgs, uint32_t n_pkgs, uint32_t n_devs,
+        uint32_t *cnt, uint32_t *start, uint32_t *total, hipStream_t st);
+void launch_slice_index_fill(uint32_t const *sizes, uint32_t const *dev_off, uint32_t const *pkg_off, uint32_t const *n_pkgs_ptr,
+        uint32_t max_pkgs, uint32_t n_pkgs, uint32_t n_devs, uint32_t const *base, uint2 *slices, uint32_t cap, hipStream_t st);
 
 // ---- function-level baseband kernels (device pointers) ----
 enum { ENV_AMP_CU8 = 0, ENV_MAG_CU8 = 1, ENV_MAG_CS16 = 2, ENV_TRUE_CU8 = 3, ENV_TRUE_CS16 = 4 }; // == R433_ENV_* of r433_hip.h

@@ -310,6 +310,93 @@ __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t const *in, uint32_t 
         *total = carry > 0xffffffffull ? 0xffffffffu : (uint32_t)carry;
 }
 
+// ---- the slice index: where each decoder's records lie in the (package-major) event stream ----
+//
+// A decoder's bitbuffers of one package are contiguous in the stream (a "slice": sizes[pkg][dev] bytes at pkg_off[pkg] +
+// dev_off[pkg][dev]); the host's ordered replay walks a decoder's slices in package order.  Finding them on the host took
+// two passes over the whole stream -- a third of the replay's CPU time, on hosts whose CPU quota is what bounds the
+// pipeline.  Here: per decoder the list of its non-empty slices as (offset, bytes), a column compaction of the sizes
+// matrix in three small launches (count per block of packages, scan, fill).
+constexpr uint32_t kIdxBlock = 256; // packages per block
+
+__global__ __launch_bounds__(64) void k_index_count(uint32_t const *sizes, uint32_t const *n_pkgs_ptr, uint32_t max_pkgs, uint32_t n_devs,
+        uint32_t *cnt)
+{
+    uint32_t const n_pkgs = min(*n_pkgs_ptr, max_pkgs);
+    uint32_t const chunks = (n_devs + 63) / 64;
+    uint32_t const blk = blockIdx.x / chunks, d = (blockIdx.x % chunks) * 64 + threadIdx.x;
+    uint32_t const p0 = blk * kIdxBlock, p1 = min(n_pkgs, p0 + kIdxBlock);
+    if (d >= n_devs)
+        return;
+    uint32_t c = 0;
+    for (uint32_t p = p0; p < p1; ++p)
+        c += sizes[(uint64_t)p * n_devs + d] != 0u;
+    cnt[(uint64_t)blk * n_devs + d] = c;
+}
+
+// cnt[block][dev]: from a count to the first entry of that block in the decoder's list; start[dev]: first entry of the decoder
+__global__ __launch_bounds__(256) void k_index_scan(uint32_t *cnt, uint32_t n_blocks, uint32_t n_devs, uint32_t *start, uint32_t *total)
+{
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t carry;
+    int const tid = (int)threadIdx.x;
+    if (tid == 0)
+        carry = 0;
+    __syncthreads();
+    for (uint32_t d0 = 0; d0 < n_devs; d0 += 256) {
+        uint32_t const d = d0 + (uint32_t)tid;
+        uint32_t run = 0;
+        if (d < n_devs)
+            for (uint32_t b = 0; b < n_blocks; ++b) {
+                uint32_t const t = cnt[(uint64_t)b * n_devs + d];
+                cnt[(uint64_t)b * n_devs + d] = run;
+                run += t;
+            }
+        part[tid] = run;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) { // Hillis-Steele inclusive scan
+            uint32_t const add = tid >= o ? part[tid - o] : 0u;
+            __syncthreads();
+            part[tid] += add;
+            __syncthreads();
+        }
+        uint32_t const first = carry + part[tid] - run;
+        if (d < n_devs) {
+            start[d] = first;
+            for (uint32_t b = 0; b < n_blocks; ++b)
+                cnt[(uint64_t)b * n_devs + d] += first;
+        }
+        __syncthreads();
+        if (tid == 255)
+            carry += part[255];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        start[n_devs] = carry;
+        *total = carry;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_index_fill(uint32_t const *sizes, uint32_t const *dev_off, uint32_t const *pkg_off,
+        uint32_t const *n_pkgs_ptr, uint32_t max_pkgs, uint32_t n_devs, uint32_t const *base, uint2 *slices, uint32_t cap)
+{
+    uint32_t const n_pkgs = min(*n_pkgs_ptr, max_pkgs);
+    uint32_t const chunks = (n_devs + 63) / 64;
+    uint32_t const blk = blockIdx.x / chunks, d = (blockIdx.x % chunks) * 64 + threadIdx.x;
+    uint32_t const p0 = blk * kIdxBlock, p1 = min(n_pkgs, p0 + kIdxBlock);
+    if (d >= n_devs)
+        return;
+    uint32_t at = base[(uint64_t)blk * n_devs + d];
+    for (uint32_t p = p0; p < p1; ++p) {
+        uint32_t const sz = sizes[(uint64_t)p * n_devs + d];
+        if (sz) {
+            if (at < cap)
+                slices[at] = make_uint2(pkg_off[p] + dev_off[(uint64_t)p * n_devs + d], sz);
+            at += 1;
+        }
+    }
+}
+
 uint32_t slice_grid(uint32_t grid_pkgs, uint32_t n_rows)
 {
     uint32_t const chunks = n_rows / 64 ? n_rows / 64 : 1;
@@ -339,6 +426,31 @@ void launch_scan_u32(uint32_t const *in, uint32_t *out, uint32_t const *n_ptr, u
         hipStream_t st, uint32_t const *carry_in, uint32_t n_skip)
 {
     hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, in, out, n_ptr, n_cap, total, carry_in, n_skip);
+}
+
+uint32_t slice_index_blocks(uint32_t n_pkgs)
+{
+    return (n_pkgs + kIdxBlock - 1) / kIdxBlock;
+}
+
+void launch_slice_index_count(uint32_t const *sizes, uint32_t const *n_pkgs_ptr, uint32_t max_pkgs, uint32_t n_pkgs, uint32_t n_devs,
+        uint32_t *cnt, uint32_t *start, uint32_t *total, hipStream_t st)
+{
+    uint32_t const blocks = slice_index_blocks(n_pkgs), chunks = (n_devs + 63) / 64;
+    if (!blocks || !chunks)
+        return;
+    hipLaunchKernelGGL(k_index_count, dim3(blocks * chunks), dim3(64), 0, st, sizes, n_pkgs_ptr, max_pkgs, n_devs, cnt);
+    hipLaunchKernelGGL(k_index_scan, dim3(1), dim3(256), 0, st, cnt, blocks, n_devs, start, total);
+}
+
+void launch_slice_index_fill(uint32_t const *sizes, uint32_t const *dev_off, uint32_t const *pkg_off, uint32_t const *n_pkgs_ptr,
+        uint32_t max_pkgs, uint32_t n_pkgs, uint32_t n_devs, uint32_t const *base, uint2 *slices, uint32_t cap, hipStream_t st)
+{
+    uint32_t const blocks = slice_index_blocks(n_pkgs), chunks = (n_devs + 63) / 64;
+    if (!blocks || !chunks)
+        return;
+    hipLaunchKernelGGL(k_index_fill, dim3(blocks * chunks), dim3(64), 0, st, sizes, dev_off, pkg_off, n_pkgs_ptr, max_pkgs, n_devs, base,
+            slices, cap);
 }
 
 void launch_slice_write(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st)
