@@ -13,8 +13,17 @@
  * calls -- src/devices/secplus_v1.c:142 -- depends on that), what they report is printed by the reference's own
  * data_print_jsons, one line per message, in list order.  With -e 1 the same code runs one pass at a time: same output.
  *
- *     pipeline_host [-e engines] [-b captures per pass] [-t replay threads] [-s sample rate] [-f frequency] [-p] file.cu8 ...
+ *     pipeline_host [-g gpus] [-e engines] [-b captures per pass] [-t replay threads] [-s sample rate] [-f frequency] [-p] [-o] file.cu8 ...
+ *       -g: spread the engines over that many GPUs of the node (0 = all visible).  Engine e lives on GPU e mod gpus
+ *           (r433_batch_create_on) and the passes go to the engines in turn, so consecutive passes run on different GPUs;
+ *           the replay stays one ordered stream on the main thread, the output is the one of a single GPU.  (The list is NOT
+ *           cut into one contiguous half per GPU: the decoders must see the list in order, so the second half's results would
+ *           sit in their engines until the first half is through -- the second GPU would fill its engines and stop.)  No
+ *           collective library: one process, host memory is the meeting point (the multi-PROCESS form, one rank per GPU with a
+ *           gather of the ranks' JSON lines, is bench.py --config 4 over torch.distributed / RCCL).
  *       -p: ask the decoders which bitbuffer heads they refuse and leave those records on the device (r433_batch_probe_prefilter)
+ *       -o: keep every decoder's calls on one thread (default: the decoders the plugin library declares stateless are spread
+ *           over the replay threads, r433_batch_set_stateless)
  *
  * Own code; C99 + pthreads.  Compiled against include/ only (r433_abi.h mirrors r_device). */
 #include <errno.h>
@@ -32,6 +41,7 @@
 void *r433p_create(void);
 int r433p_devices(void *h, r433_r_device **out, int cap);
 size_t r433p_take(void *h, char const **text, unsigned long *messages);
+int r433p_stateless(void *h, unsigned char *flags, int cap);
 void r433p_destroy(void *h);
 
 typedef struct leg {
@@ -136,9 +146,10 @@ static void leg_wait(leg *g)
 
 int main(int argc, char **argv)
 {
-    unsigned n_eng = 3, per_pass = 1024, threads = 16, rate = 250000, freq = 433920000;
+    unsigned n_eng = 0, per_pass = 1024, threads = 16, rate = 250000, freq = 433920000;
+    int n_gpus = 1;
     size_t file_room = 0; /* bytes of staging per capture; 0 = the largest file of the list */
-    int prefilter = 0, quiet = 0;
+    int prefilter = 0, quiet = 0, one_thread_each = 0;
     int a         = 1;
     for (; a < argc && argv[a][0] == '-' && argv[a][1]; ++a) {
         char const o = argv[a][1];
@@ -150,11 +161,17 @@ int main(int argc, char **argv)
             quiet = 1;
             continue;
         }
+        if (o == 'o') {
+            one_thread_each = 1;
+            continue;
+        }
         if (a + 1 >= argc)
             break;
         unsigned long const v = strtoul(argv[++a], NULL, 10);
         if (o == 'e')
             n_eng = v ? (unsigned)v : 1;
+        else if (o == 'g')
+            n_gpus = (int)v;
         else if (o == 'b')
             per_pass = v ? (unsigned)v : 1;
         else if (o == 't')
@@ -170,9 +187,18 @@ int main(int argc, char **argv)
     }
     size_t const n_files = (size_t)(argc - a);
     if (n_files == 0) {
-        fprintf(stderr, "usage: %s [-e engines] [-b captures per pass] [-t replay threads] [-s rate] [-f frequency] [-p] [-q] file.cu8 ...\n", argv[0]);
+        fprintf(stderr, "usage: %s [-g gpus] [-e engines] [-b captures per pass] [-t replay threads] [-s rate] [-f frequency] [-p] [-o] [-q] file.cu8 ...\n", argv[0]);
         return 2;
     }
+    int const visible = r433_device_count();
+    if (visible <= 0) {
+        fprintf(stderr, "no GPU: %s\n", r433_last_error());
+        return 1;
+    }
+    if (n_gpus <= 0 || n_gpus > visible)
+        n_gpus = visible;
+    if (n_eng == 0)
+        n_eng = n_gpus > 1 ? 2u * (unsigned)n_gpus : 3u; /* two passes in flight per GPU, three on a single one */
     char *const *files = argv + a;
     for (size_t i = 0; i < n_files; ++i) {
         FILE *f = fopen(files[i], "rb");
@@ -191,6 +217,8 @@ int main(int argc, char **argv)
     size_t const n_passes = (n_files + per_pass - 1) / per_pass;
     if (n_eng > n_passes)
         n_eng = (unsigned)n_passes;
+    if ((unsigned)n_gpus > n_eng)
+        n_gpus = (int)n_eng;
 
     /* the decoders: the reference's, registered the way the CLI registers them */
     void *plugins = r433p_create();
@@ -213,6 +241,9 @@ int main(int argc, char **argv)
         rows[d].tolerance   = devs[d]->tolerance;
         rows[d].priority    = devs[d]->priority;
     }
+    unsigned char *stateless = one_thread_each ? NULL : calloc((size_t)n_dev, 1);
+    if (stateless && r433p_stateless(plugins, stateless, n_dev) != n_dev)
+        return 1;
     r433_flow_cfg cfg;
     r433_flow_cfg_default(&cfg, 2, rate);
     cfg.center_frequency = freq;
@@ -221,13 +252,17 @@ int main(int argc, char **argv)
     leg *legs = calloc(n_eng, sizeof(*legs));
     for (unsigned e = 0; e < n_eng; ++e) {
         leg *g  = &legs[e];
-        g->eng  = r433_batch_create(&cfg, rows, (uint32_t)n_dev);
+        g->eng  = r433_batch_create_on((int)(e % (unsigned)n_gpus), &cfg, rows, (uint32_t)n_dev);
         if (!g->eng) {
-            fprintf(stderr, "r433_batch_create: %s\n", r433_last_error());
+            fprintf(stderr, "r433_batch_create_on(%u): %s\n", e % (unsigned)n_gpus, r433_last_error());
             return 1;
         }
-        if (n_eng > 1)
-            r433_batch_set_exclusive_detect(g->eng, 2); /* the engines take turns on the kernels of a pass */
+        if (n_eng > (unsigned)n_gpus)
+            r433_batch_set_exclusive_detect(g->eng, 2); /* the engines of one GPU take turns on the kernels of a pass */
+        if (stateless && r433_batch_set_stateless(g->eng, stateless, (uint32_t)n_dev) != 0) {
+            fprintf(stderr, "r433_batch_set_stateless: %s\n", r433_last_error());
+            return 1;
+        }
         if (prefilter && r433_batch_probe_prefilter(g->eng, devs, (uint32_t)n_dev) < 0) {
             fprintf(stderr, "r433_batch_probe_prefilter: %s\n", r433_last_error());
             return 1;
@@ -307,10 +342,12 @@ int main(int argc, char **argv)
         free(g->ptrs);
         free(g->bytes);
     }
+    fprintf(stderr, "pipeline_host: %u engine(s) on %d of %d visible GPU(s)\n", n_eng, n_gpus, visible);
     fprintf(stderr, "pipeline_host: %zu captures in %zu passes over %u engine(s): %.1f ms (reading %.1f ms and GPU legs %.1f ms on the engines' threads, "
                     "replay %.1f ms and waiting for a pass %.1f ms on the main thread), %ld decoded events, %lu messages\n",
             n_files, n_passes, n_eng, total_ms, read_ms, gpu_ms, replay_ms, wait_ms, events, messages);
     free(legs);
+    free(stateless);
     free(devs);
     free(rows);
     r433p_destroy(plugins);

@@ -94,6 +94,28 @@ int r433p_devices(void *hv, r_device **out, int cap)
     return n;
 }
 
+/* Which of these decoders keep nothing between calls: what a host passes to r433_batch_set_stateless (include/r433_hip.h) so
+ * that the ordered replay may spread a decoder's calls over its threads.  The plugin library is the one that knows: of the
+ * reference's decoders four keep state in file-scope statics (src/devices/secplus_v1.c:142-143, secplus_v2.c:260-266,
+ * ikea_sparsnas.c:92, arad_ms_meter.c:256), and every decoder made by a create_fn owns a context (flex, blueline, vivint,
+ * arad_ms_meter); all others are functions of the bitbuffer they are handed.  Returns the number of decoders. */
+int r433p_stateless(void *hv, unsigned char *flags, int cap)
+{
+    static char const *const stateful[] = {"Security+ (Keyfob)", "Security+ 2.0 (Keyfob)", "IKEA Sparsnas Energy Meter Monitor",
+            "Arad/Master Meter Dialog3G water utility meter"};
+    r433p *h = hv;
+    int n    = 0;
+    for (void **it = h->cfg->demod->r_devs.elems; it && *it; ++it, ++n) {
+        r_device const *d = *it;
+        int keeps         = d->decode_ctx != NULL || d->create_fn != NULL;
+        for (size_t k = 0; k < sizeof(stateful) / sizeof(stateful[0]); ++k)
+            keeps |= d->name && strcmp(d->name, stateful[k]) == 0;
+        if (flags && n < cap)
+            flags[n] = keeps ? 0 : 1;
+    }
+    return n;
+}
+
 /* the JSON lines since the last call (valid until the next message arrives); *messages = how many */
 size_t r433p_take(void *hv, char const **text, unsigned long *messages)
 {

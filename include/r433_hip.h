@@ -78,6 +78,16 @@ typedef struct r433_batch r433_batch;
 
 /* devs: timing rows of the registered r_devices in registration order (may be 0 rows: detection only) */
 r433_batch *r433_batch_create(r433_flow_cfg const *cfg, r433_dev_timing const *devs, uint32_t n_devs);
+/* The same on GPU `device` (0 .. r433_device_count() - 1) instead of the calling thread's current one.  The engine stays on
+ * that GPU: every later call on it switches the calling thread to the engine's device for the time of the call (and back),
+ * so one host process can keep an engine per GPU and drive them from any thread -- the batch semantics of the reference's
+ * file loop (`-r a -r b ...` with reset_sdr_flow between files, src/rtl_433.c:1703-1854) spread over the GPUs of a node by a
+ * plain C host, no collective library involved (dropin/pipeline_host.c --gpus N).  Device pointers handed
+ * to r433_batch_run must belong to that GPU; r433_batch_run_host takes host memory and is the portable form.
+ * Returns NULL (R433_ENODEV) for a device that is not there. */
+r433_batch *r433_batch_create_on(int device, r433_flow_cfg const *cfg, r433_dev_timing const *devs, uint32_t n_devs);
+/* the GPU an engine lives on */
+int r433_batch_device(r433_batch *b);
 void r433_batch_destroy(r433_batch *b);
 
 /* Decode n_streams captures resident in device memory.  Capture s starts at d_iq + s*stride_bytes

@@ -116,7 +116,7 @@ DUMP_FORMATS = {"cu8": 1, "cs16": 2, "cs8": 3, "cf32": 4, "am.s16": 5, "fm.s16":
 
 EXPORTS = [
     "r433_version", "r433_last_error", "r433_device_count", "r433_flow_cfg_default", "r433_level_db",
-    "r433_batch_create", "r433_batch_destroy", "r433_batch_run", "r433_batch_packages", "r433_batch_events",
+    "r433_batch_create", "r433_batch_create_on", "r433_batch_device", "r433_batch_destroy", "r433_batch_run", "r433_batch_packages", "r433_batch_events",
     "r433_batch_frame_sums", "r433_batch_device_events", "r433_batch_set_taps", "r433_batch_set_split",
     "r433_batch_split_stats", "r433_batch_set_profiling", "r433_batch_set_debug", "r433_batch_set_exclusive_detect", "r433_batch_enable_logic_dump", "r433_batch_logic_dump",
     "r433_batch_get_timing", "r433_batch_debug_state", "r433_batch_dispatch", "r433_batch_dispatch_mt", "r433_dispatch_current",
@@ -163,6 +163,11 @@ def bind(L):
     L.r433_level_db.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
     L.r433_batch_create.restype = vp
     L.r433_batch_create.argtypes = [C.POINTER(FlowCfg), vp, C.c_uint32]
+    if hasattr(L, "r433_batch_create_on"):
+        L.r433_batch_create_on.restype = vp
+        L.r433_batch_create_on.argtypes = [C.c_int, C.POINTER(FlowCfg), vp, C.c_uint32]
+        L.r433_batch_device.restype = C.c_int
+        L.r433_batch_device.argtypes = [vp]
     L.r433_batch_destroy.restype = None
     L.r433_batch_destroy.argtypes = [vp]
     L.r433_batch_run.restype = C.c_int

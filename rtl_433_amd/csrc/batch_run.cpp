@@ -6,7 +6,7 @@
 
 using namespace r433;
 
-std::mutex g_detect_turn;
+std::mutex g_detect_turn[kTurnDevices]; // one per GPU: engines on different GPUs have nothing to take turns on
 
 // ---- r433_batch_run, stage by stage --------------------------------------------------------------
 namespace {
@@ -25,7 +25,7 @@ void leg_stamp(r433_batch const *b, char const *what)
 
 // What one r433_batch_run call carries from stage to stage.
 struct RunCtx {
-    std::unique_lock<std::mutex> turn{g_detect_turn, std::defer_lock}; // exclusive_detect: this pass's turn on the detection kernel
+    std::unique_lock<std::mutex> turn; // exclusive_detect: this pass's turn on the detection kernel of the engine's GPU (bound in run_detect)
     r433_batch *b;
     hipStream_t st;
     uint32_t ss;                  // bytes per sample: 2 = cu8, 4 = cs16
@@ -568,6 +568,7 @@ int run_detect(RunCtx &r)
     std::unique_lock<std::mutex> &turn = r.turn;
     leg_stamp(b, "enter");
     if (b->exclusive_detect) {
+        turn = std::unique_lock<std::mutex>(g_detect_turn[(unsigned)(b->device < 0 ? 0 : b->device) % kTurnDevices], std::defer_lock);
         turn.lock();
         leg_stamp(b, "turn");
         if (b->profiling) // the time spent waiting for the turn is not the kernel's
@@ -890,6 +891,7 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
 {
     if (!b)
         return fail(R433_EINVAL, "null batch");
+    DeviceScope on_device(b->device);
     if (n_streams == 0) {
         b->n_streams = 0;
         b->n_pkgs = b->n_events = 0;
@@ -919,7 +921,7 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
 void *r433_host_alloc(size_t bytes)
 {
     void *p = nullptr;
-    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable);
     if (e != hipSuccess) {
         fail(e == hipErrorNoDevice ? R433_ENODEV : R433_ENOMEM, "hipHostMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
         return nullptr;
@@ -937,6 +939,7 @@ int r433_batch_run_host(r433_batch *b, void const *const *h_captures, uint32_t c
 {
     if (!b)
         return fail(R433_EINVAL, "null batch");
+    DeviceScope on_device(b->device);
     if (n_captures == 0)
         return r433_batch_run(b, nullptr, 0, nullptr, 0, nullptr);
     if (!h_captures || !capture_bytes)
@@ -977,6 +980,7 @@ int r433_batch_run_pulses(r433_batch *b, r433_pulse_data const *pulses, uint32_t
 {
     if (!b)
         return fail(R433_EINVAL, "null batch");
+    DeviceScope on_device(b->device);
     if (n_packages == 0) {
         b->n_streams = 0;
         b->n_pkgs = b->n_events = 0;

@@ -145,8 +145,35 @@ float r433_level_db(uint32_t sum, uint32_t n, int is_magnitude)
     return is_magnitude ? 20.0f * lg - 84.2884f : 10.0f * lg - 42.1442f;
 }
 
+r433_batch *r433_batch_create_on(int device, r433_flow_cfg const *cfg, r433_dev_timing const *devs, uint32_t n_devs);
+
 r433_batch *r433_batch_create(r433_flow_cfg const *cfg, r433_dev_timing const *devs, uint32_t n_devs)
 {
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) {
+        (void)hipGetLastError();
+        cur = 0;
+    }
+    return r433_batch_create_on(cur, cfg, devs, n_devs);
+}
+
+int r433_batch_device(r433_batch *b)
+{
+    return b ? b->device : fail(R433_EINVAL, "null batch");
+}
+
+r433_batch *r433_batch_create_on(int device, r433_flow_cfg const *cfg, r433_dev_timing const *devs, uint32_t n_devs)
+{
+    {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) {
+            (void)hipGetLastError();
+            fail(R433_ENODEV, "no GPU %d (%d visible)", device, n);
+            return nullptr;
+        }
+    }
+    DeviceScope on_device(device);
+
     if (!cfg || (cfg->sample_size != 2 && cfg->sample_size != 4) || cfg->samp_rate == 0) {
         fail(R433_EINVAL, "bad flow configuration");
         return nullptr;
@@ -177,6 +204,7 @@ r433_batch *r433_batch_create(r433_flow_cfg const *cfg, r433_dev_timing const *d
         return nullptr;
     }
     levels_from_db(b->det, (int)cfg->use_mag_est, cfg->level_limit_db, cfg->min_level_db, cfg->min_snr_db);
+    b->device = device;
     b->det.per_ms = (int)(cfg->samp_rate / 1000);
     b->det.rate = cfg->samp_rate;
     b->det.fpdm = (int)cfg->fpdm;
@@ -232,6 +260,7 @@ void r433_batch_destroy(r433_batch *b)
 {
     if (!b)
         return;
+    DeviceScope on_device(b->device);
     b->d_rows.release();
     b->d_arena.release();
     b->d_ring.release();
@@ -319,6 +348,7 @@ int r433_batch_enable_logic_dump(r433_batch *b, int on)
 {
     if (!b)
         return fail(R433_EINVAL, "null batch");
+    DeviceScope on_device(b->device);
     b->logic_on = on != 0;
     return 0;
 }
@@ -367,6 +397,7 @@ int r433_batch_set_profiling(r433_batch *b, int on)
 {
     if (!b)
         return fail(R433_EINVAL, "null batch");
+    DeviceScope on_device(b->device);
     if (on && !b->ev_made) {
         for (auto &e : b->ev)
             HIP_TRY(hipEventCreate(&e));
@@ -380,6 +411,7 @@ int r433_batch_get_timing(r433_batch *b, r433_batch_timing *t)
 {
     if (!b || !t)
         return fail(R433_EINVAL, "null argument");
+    DeviceScope on_device(b->device);
     *t = b->last_timing;
     return 0;
 }
@@ -439,6 +471,7 @@ int r433_batch_debug_state(r433_batch *b, void *host_buf, size_t bytes)
 {
     if (!b || !host_buf)
         return fail(R433_EINVAL, "null argument");
+    DeviceScope on_device(b->device);
     size_t have = (size_t)b->n_streams * sizeof(StreamState);
     HIP_TRY(hipMemcpy(host_buf, b->d_state.p, bytes < have ? bytes : have, hipMemcpyDeviceToHost));
     return (int)sizeof(StreamState);

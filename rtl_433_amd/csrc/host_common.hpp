@@ -182,7 +182,30 @@ class Pool {
 
 using namespace r433; // internal header of four host translation units; the batch type itself is the C ABI's (global)
 
+// Every engine belongs to one GPU (r433_batch_create_on).  The HIP runtime's current device is a property of the calling
+// THREAD: every entry point that touches the device switches to the engine's for the time of the call and puts the
+// caller's back, so that a host may drive engines on several GPUs from any of its threads (dropin/pipeline_host.c --gpus).
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceScope(int device)
+    {
+        if (device < 0)
+            return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != device)
+            switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceScope()
+    {
+        if (switched)
+            (void)hipSetDevice(prev);
+    }
+    DeviceScope(DeviceScope const &) = delete;
+    DeviceScope &operator=(DeviceScope const &) = delete;
+};
+
 struct r433_batch {
+    int device = -1; // the GPU this engine lives on (-1: whatever was current when it was made)
     r433_flow_cfg cfg;
     DetCfg det;
     int a16 = 0, b16 = 0;
@@ -272,7 +295,8 @@ struct r433_batch {
     Pool pool;
 };
 
-extern std::mutex g_detect_turn; // engines with exclusive_detect take turns on the detection kernel (batch_run.cpp)
+constexpr unsigned kTurnDevices = 64;
+extern std::mutex g_detect_turn[kTurnDevices]; // engines with exclusive_detect take turns on the detection kernel of their GPU (batch_run.cpp)
 
 inline hipError_t stream_wait(r433_batch *b, hipStream_t st)
 {

@@ -347,6 +347,7 @@ int r433_batch_probe_prefilter(r433_batch *b, r433_r_device *const *devices, uin
 {
     if (!b || (!devices && n_devices))
         return fail(R433_EINVAL, "null argument");
+    DeviceScope on_device(b->device);
     if (n_devices != b->timing.size())
         return fail(R433_EINVAL, "the probe needs the %zu devices the engine was created with", b->timing.size());
     std::lock_guard<std::mutex> guard(g_probe_lock);

@@ -10,6 +10,7 @@ int r433_batch_analyze(r433_batch *b, r433_analysis *out, uint32_t max_packages,
 {
     if (!b || (!out && max_packages))
         return fail(R433_EINVAL, "null argument");
+    DeviceScope on_device(b->device);
     uint32_t const n = std::min(b->n_pkgs, max_packages);
     if (n == 0)
         return 0;
@@ -227,6 +228,7 @@ int r433_batch_grab_plan(r433_batch *b, int grab_mode, r433_grab *out, uint32_t 
 {
     if (!b || (!out && max_grabs))
         return fail(R433_EINVAL, "null argument");
+    DeviceScope on_device(b->device);
     if (grab_mode < 1 || grab_mode > 4)
         return fail(R433_EINVAL, "grab mode must be 1 (all), 2 (unknown), 3 (known) or 4 (undecoded)");
     if (grab_mode == 4 && b->pkg_quality.size() != b->n_pkgs)

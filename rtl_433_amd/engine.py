@@ -44,7 +44,7 @@ def flow_cfg(sample_size=2, samp_rate=250000, fpdm=0, enable_fm=1, use_mag_est=0
 
 
 class BatchEngine:
-    def __init__(self, cfg: FlowCfg, devs=None, profiling=False, library=None):
+    def __init__(self, cfg: FlowCfg, devs=None, profiling=False, library=None, device=None):
         # `library` is for the test suite's emulator build of the same sources; the product always
         # goes through _lib.lib(), which raises if librtl433hip.so is missing.
         self.L = library if library is not None else _lib.lib()
@@ -52,7 +52,9 @@ class BatchEngine:
         self.cfg = cfg
         self.devs = np.zeros(0, dtype=DEV_DTYPE) if devs is None else np.ascontiguousarray(devs, dtype=DEV_DTYPE)
         ptr = self.devs.ctypes.data_as(C.c_void_p) if len(self.devs) else None
-        self.h = self.L.r433_batch_create(C.byref(cfg), ptr, len(self.devs))
+        # device: the GPU the engine lives on (r433_batch_create_on); None = the calling thread's current device
+        self.h = (self.L.r433_batch_create(C.byref(cfg), ptr, len(self.devs)) if device is None else
+                  self.L.r433_batch_create_on(int(device), C.byref(cfg), ptr, len(self.devs)))
         if not self.h:
             raise RuntimeError("r433_batch_create failed: " + _lib.last_error(self.L))
         if profiling:

@@ -52,6 +52,14 @@ class Plugins:
         self.devices = (C.c_void_p * n)()
         assert L.r433p_devices(self.h, self.devices, n) == n
 
+    def stateless(self):
+        """-> ctypes uint8 array for r433_batch_set_stateless: what the plugin library says about its own decoders"""
+        flags = (C.c_uint8 * len(self.devices))()
+        self.L.r433p_stateless.restype = C.c_int
+        self.L.r433p_stateless.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        assert self.L.r433p_stateless(self.h, flags, len(flags)) == len(flags)
+        return flags
+
     def take(self):
         """-> (JSON lines since the last call as bytes, number of messages)"""
         text, n = C.c_char_p(), C.c_ulong()

@@ -130,8 +130,11 @@ static uint8_t *get_stack(unsigned i)
     return g_stacks[i];
 }
 
+static std::mutex g_launch_lock; // one kernel at a time, whichever host thread (engines on several pretend devices launch side by side)
+
 void launch(dim3 grid, dim3 block, std::function<void()> const &body)
 {
+    std::lock_guard<std::mutex> one_at_a_time(g_launch_lock);
     Block &B = g_blk;
     if (B.cur) {
         fprintf(stderr, "hip_emu: nested launch\n");
@@ -258,7 +261,22 @@ hipError_t hipStreamCreateWithFlags(hipStream_t *st, unsigned) { *st = (hipStrea
 hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
-hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static int emu_devices()
+{
+    char const *e = getenv("R433_EMU_DEVICES");
+    int const n = e ? atoi(e) : 1;
+    return n < 1 ? 1 : n;
+}
+static thread_local int t_device = 0;
+hipError_t hipGetDeviceCount(int *n) { *n = emu_devices(); return hipSuccess; }
+hipError_t hipSetDevice(int device)
+{
+    if (device < 0 || device >= emu_devices())
+        return (hipError_t)101; // hipErrorInvalidDevice
+    t_device = device;
+    return hipSuccess;
+}
+hipError_t hipGetDevice(int *device) { *device = t_device; return hipSuccess; }
 hipError_t hipGetLastError() { return hipSuccess; }
 char const *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "emulated error"; }
 static double now_ms()

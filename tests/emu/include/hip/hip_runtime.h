@@ -244,7 +244,10 @@ hipError_t hipStreamCreateWithFlags(hipStream_t *st, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t st);
 hipError_t hipStreamSynchronize(hipStream_t st);
 hipError_t hipDeviceSynchronize();
-hipError_t hipGetDeviceCount(int *n);
+hipError_t hipGetDeviceCount(int *n); /* R433_EMU_DEVICES pretend devices (default 1): one address space, the current one is thread-local */
+hipError_t hipSetDevice(int device);
+hipError_t hipGetDevice(int *device);
+enum { hipHostMallocPortable = 1 };
 hipError_t hipGetLastError();
 char const *hipGetErrorString(hipError_t e);
 enum { hipEventBlockingSync = 1, hipEventDisableTiming = 2 };

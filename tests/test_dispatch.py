@@ -412,3 +412,28 @@ def test_package_filter_leaves_packages_out(ordered, backend):
     dec = list(eng.decoded())
     assert all(dec[k] == 0 for k in range(len(pkgs)) if k not in kept) and n == sum(dec) > 0
     eng.close()
+
+
+def test_engine_on_a_chosen_device(backend):
+    """r433_batch_create_on: an engine belongs to one GPU and says which; a GPU that is not there is R433_ENODEV; an engine on
+    the last visible device gives the records of one made the old way."""
+    if backend == "gpu":
+        L = _lib.lib()
+    else:
+        from tests.emu import host
+        L = host.emu_lib()
+    n = L.r433_device_count()
+    assert n >= 1
+    cfg = flow_cfg(2, 250000)
+    h = L.r433_batch_create_on(n - 1, C.byref(cfg), None, 0)
+    assert h and L.r433_batch_device(h) == n - 1
+    L.r433_batch_destroy(h)
+    assert not L.r433_batch_create_on(n, C.byref(cfg), None, 0)
+    assert "no GPU" in _lib.last_error(L)
+    iqs = [synth.ook_stream(3, 20000)[0], synth.ook_stream(4, 24000)[0]]
+    e0 = BatchEngine(cfg, None, library=L)
+    e1 = BatchEngine(cfg, None, library=L, device=n - 1)
+    assert e0.run_host(iqs) == e1.run_host(iqs) >= 2  # host memory: the portable form, whichever GPU the engine is on
+    assert e0.packages() == e1.packages()
+    e0.close()
+    e1.close()

@@ -43,9 +43,12 @@ def _messages(text):
     return out
 
 
-def _run(binary, args, files, cwd):
-    p = subprocess.run([binary] + args + files, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1800)
+def _run(binary, args, files, cwd, env=None, want_stderr=None):
+    p = subprocess.run([binary] + args + files, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1800,
+                       env=dict(os.environ, **(env or {})))
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-1500:]
+    if want_stderr:
+        assert want_stderr in p.stderr.decode(errors="replace"), p.stderr.decode(errors="replace")[-600:]
     return p.stdout.decode()
 
 
@@ -70,6 +73,25 @@ def test_pipeline_host_on_the_emulator(tmp_path):
     _check(EMU, tmp_path, 1, [["-e", "1", "-b", "5", "-t", "4"], ["-e", "3", "-b", "4", "-t", "4"], ["-e", "2", "-b", "7", "-t", "2", "-p"]])
 
 
+@pytest.mark.skipif(not build_emu.available(), reason="wave emulator needs x86-64")
+def test_pipeline_host_over_two_devices_on_the_emulator(tmp_path):
+    """-g N: engines on several GPUs (r433_batch_create_on), passes to the engines in turn, ONE ordered replay: the output of
+    two (pretend) devices is the output of one, byte for byte, with and without the stateless decoders spread over threads."""
+    if not (os.path.exists(EMU) and os.path.exists(REF)):
+        pytest.skip("dropin/_build/pipeline_host_emu or oracle/_ref not built")
+    files = _files(str(tmp_path), 1)
+    one = _run(EMU, ["-g", "1", "-e", "2", "-b", "4", "-t", "4"], files, tmp_path, want_stderr="on 1 of 1 visible GPU")
+    two_env = {"R433_EMU_DEVICES": "2"}
+    two = _run(EMU, ["-g", "2", "-b", "4", "-t", "4"], files, tmp_path, env=two_env, want_stderr="4 engine(s) on 2 of 2 visible GPU")
+    assert two == one
+    assert _run(EMU, ["-g", "0", "-e", "3", "-b", "5", "-t", "3", "-p", "-o"], files, tmp_path, env=two_env, want_stderr="on 2 of 2 visible GPU") == one
+    # a device that is not there is an error, not a silent fallback
+    p = subprocess.run([EMU, "-g", "1", "-e", "1"] + files[:1], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, R433_EMU_DEVICES="1"))
+    assert p.returncode == 0
+
+
 @pytest.mark.gpu
 def test_pipeline_host_on_the_gpu(tmp_path):
-    _check(HIP, tmp_path, 12, [["-e", "1", "-b", "64"], ["-e", "3", "-b", "32"], ["-e", "4", "-b", "17", "-p"], ["-e", "2", "-b", "500", "-t", "32"]])
+    _check(HIP, tmp_path, 12, [["-e", "1", "-b", "64"], ["-e", "3", "-b", "32"], ["-e", "4", "-b", "17", "-p"], ["-e", "2", "-b", "500", "-t", "32"],
+                               ["-g", "0", "-b", "40", "-o"]])  # -g 0: every visible GPU (one on the test box: the same code path)
