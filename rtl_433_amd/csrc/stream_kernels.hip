@@ -405,7 +405,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
     // Off for split captures (their pieces are verified against each other by the host), the function seam, taps, the logic
     // dump, sample files that are not IQ, filters outside the FAST class, frames that are not whole tiles.
     bool const lazy_cfg = !SEAM && FAST && FORM != 3 && !p.segs && !p.tap_env && !p.tap_am && !p.logic && F % (uint32_t)kTile == 0
-            && !(p.flags & (RUN_NO_LAZY | RUN_DBG_SKIP_FILTERS | RUN_DBG_SKIP_DETECT | RUN_AM_IS_INPUT | RUN_FM_IS_INPUT | RUN_ENV_RAW16));
+            && !(p.flags & (RUN_NO_LAZY | RUN_DBG_SKIP_FILTERS | RUN_AM_IS_INPUT | RUN_FM_IS_INPUT | RUN_ENV_RAW16));
     bool lazy = lazy_cfg;        // this attempt
     int attempts = 0, n_quiet = 0;
     uint32_t sums_done = tile_first; // tiles whose frame sums are in p.frame_sums (a second attempt must not add them again)
@@ -424,7 +424,11 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
     int retry_why = 0;
     int p_fail = 0, p_over = 0;  // producer side of seg_fail / det.overflow
 
-    auto init_run = [&]() {
+    // (Two of them: what a role keeps across tiles must be dead in the other role's loop, or the pair kernel does not fit its
+    // 168 registers -- with one shared start-over loop every scalar of both roles was alive around its back edge, the
+    // consumer spilled eighteen registers at every entry to the train engine and a grid of 8192 captures wrote 900 MB of
+    // scratch.)
+    auto init_consumer = [&]() {
         // ---- detector: wave-uniform.  Every lane carries the same scalar state and takes the same
         // branches, in the fast paths and in the general step alike; lane 0 alone touches the arena and
         // the FSK ring (detect_device.hpp).
@@ -447,6 +451,15 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
             det.lead_in = 1025; // saturated for good after the first 1025 idle samples of a capture
         if (p.frame_min_high) // -Y autolevel: the level of the frame the segment starts in
             cfg.min_high = p.frame_min_high[(uint64_t)cap * p.frames_cap + min(frame, p.frames_cap - 1)];
+        seg_fail = seg_init_low = seg_init_high = 0;
+        lz_n = lz_from = 0;
+        lz_min = 0x7fffffff, lz_max = -0x7fffffff;
+        lz_carried = false;
+        lzc_min = 0x7fffffff, lzc_max = -0x7fffffff;
+        lz_fail = 0;
+        n_quiet = 0;
+    };
+    auto init_producer = [&]() {
         carry_ya = carry_xa = carry_yf = carry_ff = carry_i = carry_q = 0;
         if (SEAM && p.seam_init) { // a frame that continues a stream: filter_state_t / demodfm_state_t of the caller
             carry_ya = p.seam_init[0], carry_xa = p.seam_init[1];
@@ -454,19 +467,12 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
             carry_i = p.seam_init[4], carry_q = p.seam_init[5];
         }
         seam_end[0] = carry_ya, seam_end[1] = carry_xa, seam_end[2] = carry_yf, seam_end[3] = carry_ff;
-        seg_fail = seg_init_low = seg_init_high = 0;
         carry_known = true;
         prev_quiet = false;
         prev_bound = 0;
         tail_max = 0;
         carry_w = SS == 2 ? 0x8080u : 0u; // the centred (0, 0) the discriminator starts from
-        lz_n = lz_from = 0;
-        lz_min = 0x7fffffff, lz_max = -0x7fffffff;
-        lz_carried = false;
-        lzc_min = 0x7fffffff, lzc_max = -0x7fffffff;
-        lz_fail = 0;
         p_fail = p_over = 0;
-        n_quiet = 0;
     };
 
     // profiling aid (RUN_DBG_TIMING): shader-clock ticks per phase, returned in unused StreamState slots
@@ -526,9 +532,15 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
     };
 
     uint4 pf[G::loads];
-    auto issue_loads = [&](uint32_t tile) {
+    uint4 hd[SS == 2 ? 1 : 2]; // lazy tiles look one row past their end: row 0 of the tile after the one in `pf`
+    // (have_head: `hd` already holds this tile's first row -- it was looked at when the tile before was judged)
+    auto issue_loads = [&](uint32_t tile, bool have_head = false) {
 #pragma unroll
         for (int k = 0; k < G::loads; ++k) {
+            if (have_head && k < (SS == 2 ? 1 : 2)) {
+                pf[k] = hd[k];
+                continue;
+            }
             uint64_t samp = (uint64_t)tile * kTile + (uint64_t)(SS == 2 ? k : k / 2) * kRow + (uint64_t)lane * 8;
             uint64_t off = samp * SS + (SS == 2 ? 0 : (k & 1) * 16);
             uint4 v = make_uint4(0, 0, 0, 0);
@@ -537,8 +549,6 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
             pf[k] = v;
         }
     };
-    // lazy tiles look one row past their end: row 0 of the tile after the one in `pf`
-    uint4 hd[SS == 2 ? 1 : 2];
     auto issue_head = [&](uint32_t tile) {
 #pragma unroll
         for (int k = 0; k < (SS == 2 ? 1 : 2); ++k) {
@@ -724,7 +734,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                 prev_bound = qmax;
                 if (lane == 0)
                     st_desc(buf) = kQuietTile | qmax;
-                issue_loads(tile + 1);
+                issue_loads(tile + 1, true);
                 issue_head(tile + 2);
                 return;
             }
@@ -831,7 +841,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                 }
             }
         }
-        issue_loads(tile + 1); // in flight while phase B runs
+        issue_loads(tile + 1, lazy); // in flight while phase B runs
         if (lazy)
             issue_head(tile + 2);
         wave_sync();
@@ -1305,8 +1315,8 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
         int const n_t = (int)min((uint32_t)kTile, seg_end - t0);
         bool const warm = !seg_first && tile == tile_first;
         uint8_t const *const c_am = s_am + buf * (64 * kPitchOut), *const c_fm = s_fm + buf * (64 * kPitchOut);
-        if (p.flags & RUN_DBG_SKIP_FILTERS)
-            return;
+        if (p.flags & (RUN_DBG_SKIP_FILTERS | RUN_DBG_SKIP_DETECT)) // (profiling: the producers alone -- tools/pmc_issue.py splits the
+            return;                                                   // instruction counts by role this way)
         if (warm) {
             if (st_pflag(buf)) // (bits: 1 the filters -- 8 a carry that cannot be proven inside the tile, 16 an unproven chunk among
                 seg_fail |= 1 | st_pflag(buf); // those the floor is walked over --, 2 floor range too wide, 4 the walks did not meet)
@@ -1365,16 +1375,15 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
 
         // ================= phase C: pulse detector =================
         int i = (p.flags & RUN_DBG_SKIP_DETECT) ? n_t : vq;
-        int loaded = -1;           // block whose samples the lanes hold
-        int am_l = 0, fm_l = 0;    // my sample of that block
-        int a64_l = 0, f64_l = 0;  // am / 64, fm / 64 (C division) for the level and carrier averages
-        int in_pk_l = 0;           // the two of them packed as 16-bit halves
-        int in_pkn_l = 0;          // the same with the carrier half negated (|f1| form of the average)
-        int ff_pk_l = 0;           // fm / 64 in both halves (the package's and the FSK detector's carrier averages)
-        int bmax = 0, bmin = 0;
         // chunk statistics (lane = chunk) and their suffix extrema, for jumping over whole chunks
-        int const my_cmax = st_cmax(buf, lane), my_cmin = st_cmin(buf, lane);
-        int sfx_max = my_cmax, sfx_min = my_cmin;
+        // (Kept in LDS, not in registers: four values per lane that live as long as the tile does were what pushed the
+        // consumer over its 168 registers -- 900 MB of scratch written per grid of 8192 captures.  The chunk extrema are
+        // where the producer left them; their suffix extrema go into the last free bytes of the padding, written here.)
+        auto my_cmax = [&]() -> int { return (int)st_cmax(buf, lane); };
+        auto my_cmin = [&]() -> int { return (int)st_cmin(buf, lane); };
+        auto st_sfx_max = [&](int chunk) -> short & { return *(short *)(s_env + chunk * kPitch16 + 2 * kChunk + 12); };
+        auto st_sfx_min = [&](int chunk) -> short & { return *(short *)(s_env + chunk * kPitch16 + 2 * kChunk + 14); };
+        int sfx_max = my_cmax(), sfx_min = my_cmin();
         for (int o = 1; o < 64; o <<= 1) {
             int const qa = __shfl_down(sfx_max, o, 64), qb = __shfl_down(sfx_min, o, 64);
             if (lane + o < 64) {
@@ -1382,6 +1391,11 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                 sfx_min = min(sfx_min, qb);
             }
         }
+        st_sfx_max(lane) = (short)sfx_max;
+        st_sfx_min(lane) = (short)sfx_min;
+        wave_sync();
+        auto sfx_max_at = [&](int chunk) -> int { return uni((int)st_sfx_max(chunk)); };
+        auto sfx_min_at = [&](int chunk) -> int { return uni((int)st_sfx_min(chunk)); };
         // Lazy noise floor.  While the detector idles over samples that cannot start a pulse, every
         // step moves `low` by exactly +-1 towards the sample (pulse_detect.c:326-329 with |am-low| < 1024),
         // so (a) its parity after n steps is known without walking, (b) it never leaves
@@ -1409,7 +1423,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                     // unfiltered samples and the chunks of this tile that begin before w0 (lz_min / lz_max also cover chunks
                     // behind the window, the signal that made the tile worth filtering among them)
                     bool const mine = lane >= (vq >> 5) && lane < ((w0 + kChunk - 1) >> 5);
-                    int const seen_hi = wave_max(mine ? my_cmax : -0x7fffffff), seen_lo = -wave_max(mine ? -my_cmin : -0x7fffffff);
+                    int const seen_hi = wave_max(mine ? my_cmax() : -0x7fffffff), seen_lo = -wave_max(mine ? -my_cmin() : -0x7fffffff);
                     int a = min(det.low, min(lzc_min, seen_lo)) - 1, b = max(det.low, max(lzc_max, seen_hi)) + 1;
                     a += (a ^ par) & 1;
                     b -= (b ^ par) & 1;
@@ -1549,7 +1563,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                 int const lim_i = min(n_t, i + (flen - dc));
                 int jump_to = i;
                 if (det.state == ST_IDLE) {
-                    int const rmin = __builtin_amdgcn_readlane(sfx_min, ci), rmax = __builtin_amdgcn_readlane(sfx_max, ci);
+                    int const rmin = sfx_min_at(ci), rmax = sfx_max_at(ci);
                     int const l_lo = min(det.low, min(lz_min, rmin)) - 1;
                     int const l_hi = max(det.low, max(lz_max, rmax)) + 1;
                     if (l_hi - l_lo < 1000) {
@@ -1557,7 +1571,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                         if (cfg.fixed_high != 0)
                             thr = (int)(int16_t)cfg.fixed_high;
                         int const hys = (int)(int16_t)(thr / 8);
-                        unsigned long long const m = __ballot(lane >= ci && my_cmax > thr + hys);
+                        unsigned long long const m = __ballot(lane >= ci && my_cmax() > thr + hys);
                         jump_to = min(m ? (__ffsll(m) - 1) * kChunk : n_t, lim_i);
                         if (jump_to > i) {
                             if (lz_n == 0)
@@ -1573,7 +1587,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                     if (cfg.fixed_high != 0)
                         thr = (int)(int16_t)cfg.fixed_high;
                     int const hys = (int)(int16_t)(thr / 8);
-                    unsigned long long const m = __ballot(lane >= ci && my_cmax > thr + hys);
+                    unsigned long long const m = __ballot(lane >= ci && my_cmax() > thr + hys);
                     // min(max(10 max_pulse, 10 per_ms), 100 per_ms) without leaving 32 bits (100 per_ms < 2^29)
                     int const lim = 10 * min(max(det.max_pulse, cfg.per_ms), 10 * cfg.per_ms);
                     int const togo = det.eop_spurious ? 0 : max(0, lim - det.run);
@@ -1595,6 +1609,15 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
             int const lim = min(n_t, i + (flen - dc)); // end of the tile or of the frame, whichever comes first
             int base = i & ~63;
             int e = min(base + 64, lim);
+            // (the block's values live one trip of this loop, not across trips: seven registers per lane that the compiler
+            // otherwise keeps -- and spills -- around the loop's head for the rare trip that meets the same block again)
+            int loaded = -1;           // block whose samples the lanes hold
+            int am_l = 0, fm_l = 0;    // my sample of that block
+            int a64_l = 0, f64_l = 0;  // am / 64, fm / 64 (C division) for the level and carrier averages
+            int in_pk_l = 0;           // the two of them packed as 16-bit halves
+            int in_pkn_l = 0;          // the same with the carrier half negated (|f1| form of the average)
+            int ff_pk_l = 0;           // fm / 64 in both halves (the package's and the FSK detector's carrier averages)
+            int bmax = 0, bmin = 0;
             auto load_block = [&]() { // the 64 samples at `base`, one per lane, and what the fast paths want of them
                 if (loaded == base)
                     return;
@@ -1642,7 +1665,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                 e = uni(e);
                 int const low = uni(det.low);
                 int const fl6 = uni(cfg.min_high >> 6);
-                int const amax_ub = __builtin_amdgcn_readlane(sfx_max, 0); // no filtered sample of this tile is larger
+                int const amax_ub = sfx_max_at(0); // no filtered sample of this tile is larger
                 v2s hv = {(short)det.high, (short)det.ook_f1};
                 v2s const floor_v = {(short)cfg.min_high, (short)-32768};
                 v2s const m63 = {63, 63};
@@ -1857,7 +1880,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                             int const thr = thr_of(uni((int)hv[0]));
                             thi = thr + (thr >> 3);
                         }
-                        unsigned long long const m = __ballot(lane >= (k >> 5) && my_cmax > thi);
+                        unsigned long long const m = __ballot(lane >= (k >> 5) && my_cmax() > thi);
                         int const togo = max(0, eop_lim - run);
                         int const je = togo < lim_u - k ? k + togo : lim_u;
                         int const jump_to = min(min(m ? (__ffsll(m) - 1) * kChunk : n_tu, je), lim_u);
@@ -2303,7 +2326,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                     if (cfg.fixed_high != 0)
                         thr = (int)(int16_t)cfg.fixed_high;
                     int const hys = (int)(int16_t)(thr / 8);
-                    unsigned long long const m = __ballot(lane >= (k >> 5) && my_cmax > thr + hys);
+                    unsigned long long const m = __ballot(lane >= (k >> 5) && my_cmax() > thr + hys);
                     int const lim_eop = 10 * min(max(det.max_pulse, cfg.per_ms), 10 * cfg.per_ms);
                     int const togo = det.eop_spurious ? 0 : max(0, lim_eop - det.run);
                     int const je = togo < lim - k ? k + togo : lim;
@@ -2375,10 +2398,27 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
     // (Lazy tiles: either role may find that the capture cannot be carried exactly across its unfiltered tiles and raises
     // st_retry in the slot of the barrier its tile ends at; both roles read that slot behind that barrier -- nobody writes it
     // before the barrier after the next -- and start the capture over with every tile filtered.)
-    for (;;) {
-        init_run();
-        bool again = false;
-        if constexpr (solo) {
+    // what both roles do between two attempts: everybody has seen the flag, it is cleared, every tile is filtered from now on
+    auto start_over = [&]() {
+        if (!solo)
+            __syncthreads();
+        if (threadIdx.x == 0) {
+            st_retry(0) = st_retry(1) = 0;
+            st_desc(0) = st_desc(1) = 0;
+            s_pover = 0;
+        }
+        lazy = false;
+        attempts += 1;
+        if (solo)
+            wave_sync();
+        else
+            __syncthreads();
+    };
+    if constexpr (solo) {
+        for (;;) {
+            init_consumer();
+            init_producer();
+            bool again = false;
             issue_loads(tile_first);
             if (lazy)
                 issue_head(tile_first + 1u);
@@ -2396,8 +2436,15 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                     }
                 }
             }
+            if (!again)
+                break;
+            start_over();
         }
-        else if (role == 0) {
+    }
+    else if (role == 0) {
+        for (;;) {
+            init_producer();
+            bool again = false;
             issue_loads(tile_first);
             if (lazy)
                 issue_head(tile_first + 1u);
@@ -2406,14 +2453,21 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                 if (it < tile_end)
                     produce(it, (int)(it & 1u));
                 __syncthreads();
-                if (int const why = lazy ? uni(st_retry((int)(it & 1u))) : 0) {
-                    retry_why |= why;
+                if (lazy && uni(st_retry((int)(it & 1u)))) {
                     again = true;
                     break;
                 }
             }
+            if (!again)
+                break;
+            start_over();
         }
-        else {
+        return; // the consumer wavefronts report
+    }
+    else {
+        for (;;) {
+            init_consumer();
+            bool again = false;
             for (uint32_t it = tile_first; it <= tile_end; ++it) {
                 retry_slot = (int)(it & 1u);
                 if (it > tile_first && !idle)
@@ -2425,25 +2479,13 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                     break;
                 }
             }
+            if (!again)
+                break;
+            start_over();
         }
-        if (!again)
-            break;
-        if (!solo)
-            __syncthreads(); // everybody has seen the flag
-        if (threadIdx.x == 0) {
-            st_retry(0) = st_retry(1) = 0;
-            st_desc(0) = st_desc(1) = 0;
-            s_pover = 0;
-        }
-        lazy = false;
-        attempts += 1;
-        if (solo)
-            wave_sync();
-        else
-            __syncthreads();
     }
-    if ((!solo && role == 0) || idle)
-        return; // the consumer wavefronts report
+    if (idle)
+        return; // (a triple's third wavefront whose piece has one variant only)
     if (s_pover)
         det.overflow = (uint32_t)s_pover;
 

@@ -99,9 +99,10 @@ def gather_rank_records(payload: bytes, dist_on: bool, dst=0, device=None, tail=
     others None.  tail = "packages": the records' tails are package records, merged into the canonical stream of the
     whole list under "merged"; tail = "text": the tails are the ranks' decoded events as JSON lines, which concatenate
     as they are (capture order is rank order)."""
-    got = gather_bytes(payload, dst=dst, device=device) if dist_on else [payload]
+    got = gather_bytes(payload, dst=dst, device=device) if dist_on else (list(payload) if isinstance(payload, (list, tuple)) else [payload])
     if got is None:
         return None
+    # (a list of payloads: shards that ran inside one process -- engines on several streams or GPUs -- merge the same way)
     per = [unpack_rank_record(b) for b in got]
     if tail == "text":
         return dict(per_rank=per, merged=b"".join(p["pk"] for p in per))

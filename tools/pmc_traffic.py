@@ -3,7 +3,7 @@
 (--kernel-trace, no other tracing domain), FETCH_SIZE doubled on gfx950 (128-byte requests of wide coalesced streaming
 reads are tallied at 64 bytes), WRITE_SIZE as it is (uncalibrated).  Run on the GPU box:
 
-    python tools/pmc_traffic.py[keys...]  -> gpurun_out/r03_pmc/traffic.json   (copy to profiles/r03_pmc_traffic.json)
+    python tools/pmc_traffic.py [keys...]  -> gpurun_out/r04_pmc/traffic.json   (copy to profiles/r04_pmc_traffic.json)
 """
 import json
 import os
@@ -12,7 +12,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "gpurun_out", "r03_pmc")
+OUT = os.path.join(ROOT, "gpurun_out", os.environ.get("R433_PMC_TAG", "r04_pmc"))
 
 WORKLOADS = {
     # key: (command, kernel name pattern, algorithmic bytes per launch, what a launch is)
