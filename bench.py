@@ -176,9 +176,10 @@ def cpu_baseline_config2(host_iq, devs_expected, gpu_digest, gpu_events, reps=3)
                 pool.map(_ref_worker_run, jobs, chunksize=1)
                 dt = time.perf_counter() - t0
                 bestn = dt if bestn is None else min(bestn, dt)
-        many = dict(value=round(n_streams * n_samples / bestn / 1e6, 2), unit="Msamples/s", cores=nproc, processes=len(jobs),
+        many = dict(value=round(n_streams * n_samples / bestn / 1e6, 2), unit="Msamples/s", cores=min(nproc, cpu_quota()), processes=len(jobs),
                     kind="reference", sample=f"the same batch split contiguously over {len(jobs)} independent reference processes "
-                                             f"(nproc = {nproc}), best of {reps}; process-level scaling, the reference itself is single-threaded")
+                                             f"(nproc = {nproc}, of which the container's CPU quota grants {cpu_quota()}), best of {reps}; "
+                                             "process-level scaling, the reference itself is single-threaded")
     except Exception as e:
         many = dict(error=str(e))
     return one, many, parity

@@ -181,6 +181,7 @@ int r433_batch_debug_state(r433_batch *b, void *host_buf, size_t bytes);
 #define R433_DEBUG_NO_PRIO 16384u     /* the consumer wavefront keeps the default issue priority (A/B timing) */
 #define R433_DEBUG_PAIR 32768u        /* a producer / consumer pair per capture also in launches of more than 1280 captures */
 #define R433_DEBUG_ONE_WAVE 4096u /* one wavefront per capture instead of a producer / consumer pair: same results, for A/B timing */
+#define R433_DEBUG_ONE_SLICE_LAUNCH 131072u /* the slicers' sizing pass as one launch (9.6 KB of LDS per workgroup) instead of large and small packages apart (A/B timing) */
 #define R433_DEBUG_STATIC_SLICE 65536u /* slicer workgroups take their packages at fixed strides instead of heaviest first from a shared cursor (A/B timing) */
 #define R433_DEBUG_NO_LAZY 262144u /* the detection kernel filters every tile, also those that provably cannot move the detector: same results, for A/B timing */
 #define R433_DEBUG_NO_TRAIN_ENGINE 2048u /* in-package legs through the older per-leg code: same results, for A/B timing */

@@ -645,7 +645,7 @@ int run_slice_and_mirror(RunCtx &r)
             || (rc = b->d_pkg_bytes.ensure(max_pkgs)) || (rc = b->d_pkg_off.ensure(max_pkgs))
             || (rc = b->d_sizes.ensure((size_t)max_pkgs * std::max<uint32_t>(n_devs, 1)))
             || (rc = b->d_dev_off.ensure((size_t)max_pkgs * std::max<uint32_t>(n_devs, 1)))
-            || (rc = b->d_pkg_order.ensure(max_pkgs)) || (rc = b->d_slice_cursor.ensure(std::max<size_t>(b->rows.size() / 64, 1))))
+            || (rc = b->d_pkg_order.ensure(max_pkgs)) || (rc = b->d_slice_cursor.ensure(2 * std::max<size_t>(b->rows.size() / 64, 1) + 1)))
         return rc;
 
     launch_directory(b->d_arena.p, b->arena_stride, b->d_state.p, r.split ? b->d_order.p : nullptr, r.n_order, b->d_pkg_base.p,
@@ -670,10 +670,19 @@ int run_slice_and_mirror(RunCtx &r)
     lp.pkg_bytes = b->d_pkg_bytes.p;
     lp.pkg_off = b->d_pkg_off.p;
     lp.max_pkgs = max_pkgs;
+    SliceFork fork{nullptr, nullptr, nullptr};
     if (!(b->debug_flags & R433_DEBUG_STATIC_SLICE)) {
-        lp.draw = 1;
+        lp.draw = (b->debug_flags & R433_DEBUG_ONE_SLICE_LAUNCH) ? 1 : 2;
         lp.pkg_order = b->d_pkg_order.p;
         lp.cursor = b->d_slice_cursor.p;
+        if (lp.draw == 2) { // the second stream of the sizing pass (made once per engine)
+            if (!b->slice_stream) {
+                HIP_TRY(hipStreamCreateWithFlags(&b->slice_stream, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&b->slice_forked, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&b->slice_joined, hipEventDisableTiming));
+            }
+            fork = SliceFork{b->slice_stream, b->slice_forked, b->slice_joined};
+        }
     }
     bool placed = false; // the event records are in d_events already (large batches: stretch by stretch)
     bool want_index = false; // the slice index of this run is being made
@@ -740,7 +749,7 @@ int run_slice_and_mirror(RunCtx &r)
                 for (uint32_t p0 = 0; p0 < r.total_pkgs; p0 += stretch) {
                     lp.pkg_begin = p0;
                     lp.pkg_end = std::min(r.total_pkgs, p0 + stretch);
-                    launch_slice_count(lp, lp.pkg_end - p0, r.st);
+                    launch_slice_count(lp, lp.pkg_end - p0, r.st, fork.st2 ? &fork : nullptr);
                     launch_scan_u32(b->d_pkg_bytes.p, b->d_pkg_off.p, b->d_scal.p, lp.pkg_end, b->d_scal.p + 3, r.st, b->d_scal.p + 3, p0);
                     launch_slice_write(lp, lp.pkg_end - p0, r.st);
                 }
@@ -760,7 +769,7 @@ int run_slice_and_mirror(RunCtx &r)
         }
         else {
             HIP_TRY(hipMemsetAsync(b->d_pkg_bytes.p, 0, (size_t)max_pkgs * sizeof(uint32_t), r.st));
-            launch_slice_count(lp, r.total_pkgs, r.st);
+            launch_slice_count(lp, r.total_pkgs, r.st, fork.st2 ? &fork : nullptr);
             HIP_TRY(hipGetLastError());
             if (b->profiling)
                 HIP_TRY(hipEventRecord(b->ev[3], r.st));

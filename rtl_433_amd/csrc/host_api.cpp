@@ -305,6 +305,12 @@ void r433_batch_destroy(r433_batch *b)
     b->h_logic.release();
     if (b->own_stream)
         (void)hipStreamDestroy(b->own_stream);
+    if (b->slice_stream)
+        (void)hipStreamDestroy(b->slice_stream);
+    if (b->slice_forked)
+        (void)hipEventDestroy(b->slice_forked);
+    if (b->slice_joined)
+        (void)hipEventDestroy(b->slice_joined);
     b->h_scal.release();
     b->h_frame_sums.release();
     b->h_pkg_blob.release();

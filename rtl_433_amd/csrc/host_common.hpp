@@ -271,6 +271,8 @@ struct r433_batch {
     // r433_batch_run_host: captures staged from host memory
     DevBuf<uint8_t> d_input;
     hipStream_t own_stream = nullptr;
+    hipStream_t slice_stream = nullptr;            // the sizing pass of the small packages runs beside the large ones' (slicer_kernels.hip)
+    hipEvent_t slice_forked = nullptr, slice_joined = nullptr;
     std::vector<uint32_t> host_bytes;
 
     hipEvent_t sync_ev = nullptr; // blocking (sleeping) wait: host threads of other pipeline stages need the cores

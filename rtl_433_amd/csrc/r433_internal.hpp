@@ -158,9 +158,9 @@ struct SliceParams {
     uint8_t const *pf_tables;   // pre-filter (r433_batch_probe_prefilter), or nullptr
     uint32_t *pf_counts;        // [orig dev][5]: records the filter dropped, by failure code
     // the sizing pass draws its items from a cursor, the heavy packages first (k_slice; launch_slice_count fills both arrays)
-    uint32_t draw;              // 0: fixed strides
+    uint32_t draw;              // 0: fixed strides; 1: from one cursor per chunk of devices; 2: large and small packages apart (two launches)
     uint32_t *pkg_order;        // the packages of this launch by pulse count, descending
-    uint32_t *cursor;           // [n_rows / 64] next entry of pkg_order per chunk of devices
+    uint32_t *cursor;           // [2 * n_rows / 64 + 1] next entry of pkg_order per chunk of devices: whole list / large part, small part; the split
 };
 
 // `order` (may be null = identity) lists the wavefront slots (whole captures or the chosen segments of split
@@ -180,7 +180,13 @@ void launch_scan_u32(uint32_t const *in, uint32_t *out, uint32_t const *n_ptr, u
 void launch_gather_packages(uint8_t const *arena, uint32_t arena_stride, uint32_t const *dir_stream,
         uint32_t const *dir_off, uint32_t const *rec_off, uint32_t const *n_pkgs, uint32_t max_pkgs, uint8_t *dst,
         uint32_t dst_cap, uint32_t grid_pkgs, hipStream_t st);
-void launch_slice_count(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st);
+// p.draw == 2: the sizing pass as two launches, the large packages and the small ones (less LDS, more wavefronts); with a fork
+// the small ones run on its second stream beside the large ones and the caller's stream waits for both
+struct SliceFork {
+    hipStream_t st2;
+    hipEvent_t forked, joined;
+};
+void launch_slice_count(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st, SliceFork const *fork = nullptr);
 void launch_slice_write(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st);
 // the slice index (slicer_kernels.hip): per decoder the (offset, bytes) of its non-empty slices of the event stream, package order.
 // count: cnt[blocks][n_devs] (scratch, then every block's first entry), start[n_devs + 1], *total; fill: after dev_off / pkg_off are final

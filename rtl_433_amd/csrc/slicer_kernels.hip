@@ -41,11 +41,19 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total)
 //              sliced again straight into the event stream
 enum { M_COUNT = 0, M_WRITE = 1, M_STAGE = 2, M_COMPACT = 3 };
 
-template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
+// Packages of at most this many pulses are "small": their sizing pass runs as its own launch whose workgroups stage the pulses
+// in 2 KB of LDS instead of 9.6 KB -- seven wavefronts to a SIMD instead of four (72 registers allow seven; LDS capped the
+// kernel at 16 workgroups per CU) -- beside the launch of the few large packages, on a second stream.  The slicers are a serial
+// walk per lane: what hides their latency is more wavefronts.
+constexpr uint32_t kSmallW = 52;                 // weight (pulses / 5) from which a package is large
+constexpr uint32_t kSmallPulses = kSmallW * 5;   // a small package has fewer pulses than this
+
+template <int MODE, int CAP = R433_PD_MAX_PULSES> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
 {
     constexpr bool PLACE = MODE == M_WRITE || MODE == M_COMPACT; // records go to their final offsets
     constexpr bool STORE = MODE != M_COUNT;                       // the sink stores bytes
-    __shared__ int2 pairs[R433_PD_MAX_PULSES];
+    constexpr bool SMALL = CAP < R433_PD_MAX_PULSES;              // the launch of the small packages (sizing passes only)
+    __shared__ int2 pairs[CAP];
 
     uint32_t const n_pkgs = min(min(*p.n_pkgs, p.max_pkgs), p.pkg_end);
     uint32_t const chunks = p.n_rows / 64;
@@ -70,14 +78,20 @@ template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
     // changing devices as it goes -- was slower (3.24 ms; 0.62 ms for 1024): the expensive chunks' long items then begin late.
     bool const drawn = !PLACE && p.draw != 0;
     uint32_t const n_mine = n_pkgs > p.pkg_begin ? n_pkgs - p.pkg_begin : 0u;
+    // two launches share the list (p.draw == 2): the large packages are its first cursor[2 * chunks] entries, drawn through
+    // cursor[chunk]; the small ones follow, drawn through cursor[chunks + chunk] (k_pkg_order sets all three)
+    bool const two = drawn && p.draw == 2;
+    uint32_t const n_large = two ? min(p.cursor[2 * chunks], n_mine) : n_mine;
+    uint32_t *const my_cursor = p.cursor + (two && SMALL ? chunks : 0u) + chunk;
+    uint32_t const my_end = two && !SMALL ? n_large : n_mine;
     for (uint32_t it = blockIdx.x / chunks;; it += gridDim.x / chunks) {
         uint32_t pkg;
         if (drawn) {
             uint32_t i = 0;
             if (lane == 0)
-                i = atomicAdd(&p.cursor[chunk], 1u);
+                i = atomicAdd(my_cursor, 1u);
             i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
-            if (i >= n_mine)
+            if (i >= my_end)
                 break;
             pkg = p.pkg_order[i];
         }
@@ -88,7 +102,7 @@ template <int MODE> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
         }
         uint8_t const *rec = p.arena + (uint64_t)p.dir_stream[pkg] * p.arena_stride + p.dir_off[pkg];
         uint32_t const type = ((uint32_t const *)rec)[2];
-        uint32_t const num = min(((uint32_t const *)rec)[3], (uint32_t)R433_PD_MAX_PULSES);
+        uint32_t const num = min(((uint32_t const *)rec)[3], (uint32_t)CAP); // (a small launch only draws packages that fit)
         int2 const *src = (int2 const *)(rec + sizeof(r433_pkg_rec));
         // The device row is read again for every package ON PURPOSE (the index is made opaque): with the row known to be the
         // same for all packages the compiler unswitches the loop on its modulation -- ten copies of the loop, twice the
@@ -233,20 +247,28 @@ __global__ __launch_bounds__(256) void k_pkg_order(uint8_t const *arena, uint32_
         return min(num / 5u, 255u);
     };
     count[threadIdx.x] = 0;
-    for (uint32_t c = threadIdx.x; c < chunks; c += 256)
-        cursor[c] = 0;
     __syncthreads();
     for (uint32_t pkg = pkg_begin + threadIdx.x; pkg < n_pkgs; pkg += 256)
         atomicAdd(&count[weight(pkg)], 1u);
     __syncthreads();
+    __shared__ uint32_t n_large;
     if (threadIdx.x == 0) {
         uint32_t run = 0;
         for (int w = 255; w >= 0; --w) {
             first[w] = run;
             run += count[w];
+            if (w == (int)kSmallW)
+                n_large = run; // the packages of kSmallPulses pulses and more come first
         }
     }
     __syncthreads();
+    // the cursors: [chunk] over the whole list (or its large part), [chunks + chunk] over the small part, [2 * chunks] the split
+    for (uint32_t c = threadIdx.x; c < chunks; c += 256) {
+        cursor[c] = 0;
+        cursor[chunks + c] = n_large;
+    }
+    if (threadIdx.x == 0)
+        cursor[2 * chunks] = n_large;
     for (uint32_t pkg = pkg_begin + threadIdx.x; pkg < n_pkgs; pkg += 256)
         order[atomicAdd(&first[weight(pkg)], 1u)] = pkg;
 }
@@ -411,15 +433,37 @@ uint32_t slice_grid(uint32_t grid_pkgs, uint32_t n_rows)
 } // namespace
 
 // (grid_pkgs: the packages of THIS launch, p.pkg_end - p.pkg_begin or fewer)
-void launch_slice_count(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st)
+void launch_slice_count(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st, SliceFork const *fork)
 {
     if (p.draw)
         hipLaunchKernelGGL(k_pkg_order, dim3(1), dim3(256), 0, st, p.arena, p.arena_stride, p.dir_stream, p.dir_off, p.n_pkgs, p.max_pkgs,
                 p.pkg_begin, p.pkg_end, p.pkg_order, p.cursor, p.n_rows / 64 ? p.n_rows / 64 : 1u);
+    dim3 const grid(slice_grid(grid_pkgs, p.n_rows));
+    if (p.draw == 2) {
+        // the small packages on the second stream beside the large ones (both wait for the order, the caller's stream for both)
+        hipStream_t const st2 = fork ? fork->st2 : st;
+        if (fork) {
+            (void)hipEventRecord(fork->forked, st);
+            (void)hipStreamWaitEvent(st2, fork->forked, 0);
+        }
+        if (p.stage) {
+            hipLaunchKernelGGL((k_slice<M_STAGE, R433_PD_MAX_PULSES>), grid, dim3(64), 0, st, p);
+            hipLaunchKernelGGL((k_slice<M_STAGE, (int)kSmallPulses>), grid, dim3(64), 0, st2, p);
+        }
+        else {
+            hipLaunchKernelGGL((k_slice<M_COUNT, R433_PD_MAX_PULSES>), grid, dim3(64), 0, st, p);
+            hipLaunchKernelGGL((k_slice<M_COUNT, (int)kSmallPulses>), grid, dim3(64), 0, st2, p);
+        }
+        if (fork) {
+            (void)hipEventRecord(fork->joined, st2);
+            (void)hipStreamWaitEvent(st, fork->joined, 0);
+        }
+        return;
+    }
     if (p.stage)
-        hipLaunchKernelGGL(k_slice<M_STAGE>, dim3(slice_grid(grid_pkgs, p.n_rows)), dim3(64), 0, st, p);
+        hipLaunchKernelGGL(k_slice<M_STAGE>, grid, dim3(64), 0, st, p);
     else
-        hipLaunchKernelGGL(k_slice<M_COUNT>, dim3(slice_grid(grid_pkgs, p.n_rows)), dim3(64), 0, st, p);
+        hipLaunchKernelGGL(k_slice<M_COUNT>, grid, dim3(64), 0, st, p);
 }
 
 void launch_scan_u32(uint32_t const *in, uint32_t *out, uint32_t const *n_ptr, uint32_t n_cap, uint32_t *total,

@@ -255,6 +255,7 @@ hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned flags);
 hipError_t hipEventCreate(hipEvent_t *e);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t st);
+hipError_t hipStreamWaitEvent(hipStream_t st, hipEvent_t e, unsigned flags);
 hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b);
 

@@ -151,6 +151,8 @@ def one_case(seed, run=None):
         form |= 65536  # R433_DEBUG_STATIC_SLICE: slicer workgroups at fixed strides instead of drawing from the cursors
     if seed % 11 == 5:
         form |= 262144  # R433_DEBUG_NO_LAZY: every tile filtered
+    if seed % 13 == 6:
+        form |= 131072  # R433_DEBUG_ONE_SLICE_LAUNCH: the slicers' sizing pass as one launch instead of large / small packages apart
     # One case in three with the sample taps; without them the detection kernel leaves tiles that cannot move the detector
     # unfiltered (lazy tiles), and the per-frame envelope sums are compared instead.
     taps = seed % 3 == 0
