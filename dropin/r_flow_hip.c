@@ -69,6 +69,8 @@
 
 #include "r433_hip.h"
 
+#include <pthread.h>
+
 /* the three structs that cross the boundary are the reference's own (include/r433_abi.h mirrors them) */
 _Static_assert(sizeof(r433_r_device) == sizeof(r_device), "r_device layout");
 _Static_assert(sizeof(r433_pulse_data) == sizeof(pulse_data_t), "pulse_data_t layout");
@@ -106,6 +108,7 @@ typedef struct hip_engine {
     size_t devs;
     void *first_dev;
     int probed, tables; /* the decoder pre-filter of this engine: asked for, decoders with a table */
+    int lane;           /* which of the two passes in flight it serves (a pass on the GPU while the one before is replayed) */
     unsigned long used; /* for the least recently used */
 } hip_engine;
 
@@ -145,7 +148,29 @@ static struct {
     uint32_t sums_cap;
     uint32_t cur_stream;
     uint32_t cur_frames_done;
+    /* two passes in flight (hip_sdr_flow_drain): the queue of one is on the GPU while the file loop fills the next */
+    int lane;            /* the engines of the next pass to start */
+    int final_drain;     /* the file loop is over: nothing is left in flight when the drain returns */
+    uint8_t *spare_stage; /* the pinned buffer of the pass before the one in flight, for the queue after it */
+    size_t spare_cap;
 } H = {.cur_stream = UINT32_MAX};
+
+/* a pass whose GPU leg runs (or has run) on a thread of its own and whose replay is owed */
+typedef struct pending_pass {
+    int active;
+    pthread_t thread;
+    r433_batch *eng;
+    hip_capture *caps;
+    size_t n;
+    uint8_t *stage;
+    size_t stage_cap, stage_len;
+    void const **ptrs;
+    uint32_t *bytes;
+    int n_pkgs;
+    char err[256];
+    double t_start;
+} pending_pass;
+static pending_pass P; /* the pass in flight */
 
 static size_t batch_limit(r_cfg_t *cfg)
 {
@@ -516,7 +541,7 @@ static void engine_ensure(r_cfg_t *cfg, r433_flow_cfg const *fc)
     hip_engine *slot       = NULL;
     for (int k = 0; k < HIP_ENGINES; ++k) {
         hip_engine *e = &H.engines[k];
-        if (e->eng && memcmp(fc, &e->cfg, sizeof(*fc)) == 0 && e->devs == demod->r_devs.len && e->first_dev == first) {
+        if (e->eng && memcmp(fc, &e->cfg, sizeof(*fc)) == 0 && e->devs == demod->r_devs.len && e->first_dev == first && e->lane == H.lane) {
             e->used = ++H.eng_clock;
             H.cur   = e;
             H.eng   = e->eng;
@@ -562,6 +587,7 @@ static void engine_ensure(r_cfg_t *cfg, r433_flow_cfg const *fc)
     slot->devs      = n;
     slot->first_dev = first;
     slot->used      = ++H.eng_clock;
+    slot->lane      = H.lane;
     H.cur           = slot;
     H.eng           = slot->eng;
 }
@@ -769,6 +795,8 @@ static void write_grabs(r_cfg_t *cfg, hip_capture *group, size_t n)
     free(plan);
 }
 
+static int replay_group(r_cfg_t *cfg, hip_capture *group, size_t n, int n_pkgs);
+
 static int run_group(r_cfg_t *cfg, hip_capture *group, size_t n)
 {
     struct dm_state *demod = cfg->demod;
@@ -877,7 +905,13 @@ static int run_group(r_cfg_t *cfg, hip_capture *group, size_t n)
     free(bytes);
     if (n_pkgs < 0)
         hip_fatal("r433_batch_run_host");
+    return replay_group(cfg, group, n, n_pkgs);
+}
 
+/* the host half of a pass: the records of H.eng's last run into the decoders, the files that hang on them */
+static int replay_group(r_cfg_t *cfg, hip_capture *group, size_t n, int n_pkgs)
+{
+    struct dm_state *demod = cfg->demod;
     H.cfg        = cfg;
     H.group      = group;
     H.cur_stream = UINT32_MAX;
@@ -932,10 +966,119 @@ static int same_group(r_cfg_t *cfg, hip_capture const *a, hip_capture const *b)
             && capture_input_format(a) == capture_input_format(b);
 }
 
+/* ---- two passes in flight ------------------------------------------------------------------------------------------
+   The file loop does one thing at a time (src/rtl_433.c:1703-1859); with a list to get through, the GPU leg of a pass can run
+   while the decoders work through the pass before it and the loop reads the files of the pass after it: the queue is handed to
+   a thread (its own engine, its own pinned buffer), and its replay happens at the NEXT drain -- in list order, on the calling
+   thread, as ever.  Only for the plain case: one flow configuration in the queue, no dumper, no sample grabber, no -E.
+   RTL433_HIP_OVERLAP=0 turns it off, =1 takes every pass (tests); by default passes of 512 captures and more. */
+static void *pass_thread(void *arg)
+{
+    (void)arg;
+    P.n_pkgs = r433_batch_run_host(P.eng, P.ptrs, P.bytes, (uint32_t)P.n);
+    if (P.n_pkgs < 0)
+        snprintf(P.err, sizeof(P.err), "%s", r433_last_error());
+    return NULL;
+}
+
+static int pass_may_overlap(r_cfg_t *cfg, size_t n_run)
+{
+    struct dm_state *demod = cfg->demod;
+    char const *e          = getenv("RTL433_HIP_OVERLAP");
+    if (e && *e == '0')
+        return 0;
+    if (H.final_drain || H.open || H.sync_active || cfg->after_successful_events_flag || demod->samp_grab || n_run == 0)
+        return 0;
+    if (!(e && *e == '1') && n_run < 512)
+        return 0;
+    for (void **iter = demod->dumper.elems; iter && *iter; ++iter)
+        if (((file_info_t const *)*iter)->file)
+            return 0;
+    for (size_t i = 0; i < n_run; ++i) {
+        hip_capture const *c = &H.caps[i];
+        if (c->irregular || c->bytes == 0 || c->n_frames == 0 || (c->n_frames > 1 && c->frame_bytes / c->sample_size % 64 != 0)
+                || !same_group(cfg, &H.caps[0], c))
+            return 0;
+    }
+    return 1;
+}
+
+/* the queue leaves for the GPU on a thread of its own; H gets an empty queue and the other pinned buffer */
+static void pass_start(r_cfg_t *cfg, size_t n)
+{
+    r433_flow_cfg fc;
+    engine_config(cfg, &H.caps[0], &fc);
+    engine_ensure(cfg, &fc); /* (the engine of H.lane) */
+    r433_batch_enable_logic_dump(H.eng, 0);
+    r433_batch_set_taps(H.eng, NULL, NULL, NULL, 0);
+    engine_prefilter(cfg);
+    P.eng   = H.eng;
+    P.ptrs  = malloc(n * sizeof(*P.ptrs));
+    P.bytes = malloc(n * sizeof(*P.bytes));
+    if (!P.ptrs || !P.bytes)
+        FATAL_MALLOC("hip capture list");
+    for (size_t i = 0; i < n; ++i) {
+        P.ptrs[i]  = H.stage + H.caps[i].offset;
+        P.bytes[i] = H.caps[i].bytes;
+        H.pushed_before_queue += H.caps[i].bytes;
+    }
+    P.caps      = H.caps;
+    P.n         = n;
+    P.stage     = H.stage;
+    P.stage_cap = H.stage_cap;
+    P.stage_len = H.stage_len;
+    P.n_pkgs    = 0;
+    P.err[0]    = '\0';
+    P.t_start   = trace_now();
+    /* the file loop goes on into a queue and a buffer of its own */
+    H.caps      = NULL;
+    H.n_caps    = 0;
+    H.caps_cap  = 0;
+    H.stage     = H.spare_stage;
+    H.stage_cap = H.spare_cap;
+    H.stage_len = 0;
+    H.spare_stage = NULL;
+    H.spare_cap   = 0;
+    H.lane ^= 1;
+    if (pthread_create(&P.thread, NULL, pass_thread, NULL) != 0) {
+        print_log(LOG_FATAL, "HIP", "pthread_create failed");
+        exit(1);
+    }
+    P.active = 1;
+}
+
+/* the replay that is owed, of a pass whose thread has been joined: the decoders, in list order, on this thread */
+static int pass_replay(r_cfg_t *cfg, pending_pass *d)
+{
+    if (trace_on())
+        fprintf(stderr, "hip flow: %zu captures, %.1f MiB: GPU pass on its own thread, taken %.1f ms after its start\n", d->n, d->stage_len / 1048576.0,
+                trace_now() - d->t_start);
+    free(d->ptrs);
+    free(d->bytes);
+    if (d->n_pkgs < 0) {
+        print_logf(LOG_FATAL, "HIP", "r433_batch_run_host: %s", d->err);
+        exit(1);
+    }
+    r433_batch *keep_eng = H.eng;
+    H.eng                = d->eng;
+    int const events     = replay_group(cfg, d->caps, d->n, d->n_pkgs);
+    H.eng                = keep_eng;
+    for (size_t i = 0; i < d->n; ++i)
+        capture_free(&d->caps[i]);
+    free(d->caps);
+    /* its pinned buffer serves the queue after the one that is being filled now */
+    if (H.spare_stage)
+        r433_host_free(H.spare_stage);
+    H.spare_stage = d->stage;
+    H.spare_cap   = d->stage_cap;
+    memset(d, 0, sizeof(*d));
+    return events;
+}
+
 int hip_sdr_flow_drain(struct r_cfg *cfg)
 {
     struct dm_state *demod = cfg->demod;
-    if (!demod || H.n_caps == 0)
+    if (!demod || (H.n_caps == 0 && !P.active))
         return 0;
     /* what the host set for the file it is working on right now: restored after the replay */
     char const *keep_filename  = cfg->in_filename;
@@ -952,6 +1095,23 @@ int hip_sdr_flow_drain(struct r_cfg *cfg)
     double const t_drain = trace_now();
     if (trace_on())
         fprintf(stderr, "hip flow: %zu captures queued over %.1f ms (since the start / the pass before)\n", n_run, t_last_drain ? t_drain - t_last_drain : 0.0);
+    if (pass_may_overlap(cfg, n_run)) {
+        /* this queue to the GPU, THEN the replay of the pass before it -- beside it */
+        pending_pass done = P;
+        if (done.active)
+            pthread_join(done.thread, NULL); /* (one GPU leg at a time: the pass before is off the device) */
+        memset(&P, 0, sizeof(P));
+        pass_start(cfg, n_run);
+        if (done.active)
+            events += pass_replay(cfg, &done);
+        n_run = 0;
+    }
+    else if (P.active) { /* nothing may overtake the pass that is owed */
+        pending_pass done = P;
+        pthread_join(done.thread, NULL);
+        memset(&P, 0, sizeof(P));
+        events += pass_replay(cfg, &done);
+    }
     for (size_t i = 0; i < n_run;) {
         hip_capture *c = &H.caps[i];
         if (c->irregular || c->bytes == 0 || c->n_frames == 0 || (c->n_frames > 1 && c->frame_bytes / c->sample_size % 64 != 0)) {
@@ -1030,7 +1190,9 @@ int hip_sdr_flow_drain(struct r_cfg *cfg)
    last act (src/rtl_433.c:1861) first drains what is still queued. */
 void hip_sdr_flow_close_dumpers(struct r_cfg *cfg)
 {
+    H.final_drain = 1; /* the file loop is over: the pass in flight and the queue, in that order, and nothing left behind */
     hip_sdr_flow_drain(cfg);
+    H.final_drain = 0;
     close_dumpers(cfg);
 }
 

@@ -108,6 +108,18 @@ def check_batch(binary, tmp_path, seeds, extra_env=None):
     return ref
 
 
+def check_two_passes_in_flight(binary, tmp_path):
+    """The GPU leg of a pass on a thread of its own while the pass before is replayed (dropin/r_flow_hip.c pass_start /
+    pass_replay): forced for every pass of three files -- five passes, the last one and the tail of the list synchronous --
+    stdout is the stock binary's, and the flow's own with the overlap off."""
+    seeds = list(range(300, 314))
+    ref = check_batch(binary, tmp_path, seeds, {"RTL433_HIP_BATCH": "3", "RTL433_HIP_OVERLAP": "1"})
+    names = [f"s{s:05d}_433.92M_250k.cu8" for s in seeds]
+    args = file_args(names) + FLEX + ["-F", "json", "-M", "level", "-M", "protocol", "-M", "bits", "-K", "FILE"]
+    assert run_cli(binary, args, tmp_path, {"RTL433_HIP_BATCH": "3", "RTL433_HIP_OVERLAP": "0"}) == ref
+    assert run_cli(binary, args, tmp_path, {"RTL433_HIP_BATCH": "5", "RTL433_HIP_OVERLAP": "1", "RTL433_HIP_THREADS": "1"}) == ref
+
+
 def check_config3(binary, tmp_path):
     config3_recipe(tmp_path / "mc_868M_1024k.cs16")
     args = ["-r", "mc_868M_1024k.cs16", "-X", "n=mc,m=FSK_MC_ZEROBIT,s=50,l=50,r=120", "-F", "json", "-M", "level"]
@@ -174,6 +186,17 @@ def test_hip_batch64(tmp_path):
     _ensure_built(HIP)
     ref = check_batch(HIP, tmp_path, range(64))
     assert ref.count("\n") > 64
+
+
+def test_emu_two_passes_in_flight(tmp_path):
+    _ensure_built(EMU)
+    check_two_passes_in_flight(EMU, tmp_path)
+
+
+@pytest.mark.gpu
+def test_hip_two_passes_in_flight(tmp_path):
+    _ensure_built(HIP)
+    check_two_passes_in_flight(HIP, tmp_path)
 
 
 @pytest.mark.gpu
