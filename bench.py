@@ -423,6 +423,35 @@ def replay_threads(world):
     return max(1, min(64, (cpu_quota() * 3 // 2) // max(1, world)))
 
 
+class _RefPlugins:
+    """The reference's decoders taken from oracle/_ref/libr433ref.so (the same sources as libr433plugins.so, the same JSON
+    printer) when dropin/_build did not travel: same interface as rtl_433_amd.plugins.Plugins."""
+
+    def __init__(self):
+        from oracle import pyoracle as po
+        self.ref = po.Ref(call_real=True, record=False)
+        self.ref.set_digest_mode(0)
+        self.ref.text_mode(True)
+        self.devices = self.ref.plain_devices()
+        self.source = "oracle/_ref/libr433ref.so (dropin/_build/libr433plugins.so is missing)"
+
+    def take(self):
+        t = self.ref.take_text()
+        return t, t.count(b"\n")
+
+    def close(self):
+        self.ref.close()
+
+
+def real_decoder_plugins():
+    from rtl_433_amd import plugins
+    if plugins.available():
+        p = plugins.Plugins()
+        p.source = "dropin/_build/libr433plugins.so"
+        return p
+    return _RefPlugins()
+
+
 def timed(dist, torch, fn):
     """barrier + synchronize on both sides, MAX over ranks"""
     if dist:
@@ -466,7 +495,7 @@ def run_batched(args, ctxd):
     # reference's sources as plugins, unchanged behind r_device.decode_fn), what they report as JSON lines printed by the
     # reference's own data_print_jsons -- that text is what the ranks gather and what is compared with the reference.
     from rtl_433_amd import plugins
-    plug = plugins.Plugins()
+    plug = real_decoder_plugins()
     assert len(plug.devices) == len(devs), "the plugin library registers another decoder set than the device table"
     stateless = plugins.stateless_flags(plug.devices)  # what this host knows about its plugins (r433_batch_set_stateless)
 
@@ -611,7 +640,7 @@ def run_batched(args, ctxd):
             "kernel_only": {"value": round(n_streams * n_samples / (live_det_ms * 1e-3) / 1e6, 1), "unit": "Msamples/s"},
             "packages_per_step": int(tot_pk), "decoded_messages_per_step": int(tot_msg), "bitbuffers_to_host_per_step": int(tot_bits),
             "d2h_bytes_per_step_per_gpu": int(records["sent"][1]),
-            "decoders_behind_the_path": "the reference's real decode_fn (dropin/_build/libr433plugins.so), ordered multi-threaded replay, "
+            "decoders_behind_the_path": f"the reference's real decode_fn ({plug.source}), ordered multi-threaded replay, "
                                         f"device-side pre-filter on, {int(sum(stateless))} of {len(stateless)} decoders declared stateless by the host",
             "decoded_events_gathered": gathered_json,
             "gathered": [{k: v for k, v in p.items() if k != "pk"} for p in per],

@@ -151,7 +151,7 @@ int r433_batch_split_stats(r433_batch *b, uint32_t *segments, uint32_t *pieces_r
 
 /* Kernel timing of the last run measured with HIP events on the caller's stream (ms). */
 typedef struct r433_batch_timing {
-    float detect_ms;  /* k_stream: IQ -> packages */
+    float detect_ms;  /* k_wave (+ the grid-ordering look and, for split captures, k_tile_max and the stitch rounds): IQ -> packages */
     float dir_ms;     /* package directory */
     float count_ms;   /* slicer pass 1 */
     float scan_ms;
