@@ -150,6 +150,7 @@ static struct {
     uint32_t cur_frames_done;
     /* two passes in flight (hip_sdr_flow_drain): the queue of one is on the GPU while the file loop fills the next */
     int lane;            /* the engines of the next pass to start */
+    int lane_seen;       /* a pass has been handed over: fresh staging buffers start at the size of a pass */
     int final_drain;     /* the file loop is over: nothing is left in flight when the drain returns */
     uint8_t *spare_stage; /* the pinned buffer of the pass before the one in flight, for the queue after it */
     size_t spare_cap;
@@ -246,7 +247,7 @@ static void stage_reserve(size_t need)
     /* Pinning memory costs ~0.2 ms per MiB and a grown buffer has to be copied into: 8 MiB for the lone small file, then
        straight to the size a pass is cut at (STAGE_PASS below), doubling only for captures that are larger than that.  (Growing
        by doubling up to 1 GiB took 0.55 s of a 1.1 s run over 8192 captures, RTL433_HIP_TRACE=1.) */
-    size_t cap = H.stage_cap ? H.stage_cap : (size_t)8 << 20;
+    size_t cap = H.stage_cap ? H.stage_cap : H.lane_seen ? STAGE_PASS : (size_t)8 << 20; /* (a process that hands passes over has a list) */
     if (cap < need && cap < STAGE_PASS)
         cap = STAGE_PASS;
     while (cap < need)
@@ -1040,6 +1041,7 @@ static void pass_start(r_cfg_t *cfg, size_t n)
     H.spare_stage = NULL;
     H.spare_cap   = 0;
     H.lane ^= 1;
+    H.lane_seen = 1;
     if (pthread_create(&P.thread, NULL, pass_thread, NULL) != 0) {
         print_log(LOG_FATAL, "HIP", "pthread_create failed");
         exit(1);
@@ -1066,11 +1068,13 @@ static int pass_replay(r_cfg_t *cfg, pending_pass *d)
     for (size_t i = 0; i < d->n; ++i)
         capture_free(&d->caps[i]);
     free(d->caps);
-    /* its pinned buffer serves the queue after the one that is being filled now */
-    if (H.spare_stage)
-        r433_host_free(H.spare_stage);
-    H.spare_stage = d->stage;
-    H.spare_cap   = d->stage_cap;
+    /* its pinned buffer (if the queue after it has not taken it already) serves a later queue */
+    if (d->stage) {
+        if (H.spare_stage)
+            r433_host_free(H.spare_stage);
+        H.spare_stage = d->stage;
+        H.spare_cap   = d->stage_cap;
+    }
     memset(d, 0, sizeof(*d));
     return events;
 }
@@ -1097,18 +1101,25 @@ int hip_sdr_flow_drain(struct r_cfg *cfg)
         fprintf(stderr, "hip flow: %zu captures queued over %.1f ms (since the start / the pass before)\n", n_run, t_last_drain ? t_drain - t_last_drain : 0.0);
     if (pass_may_overlap(cfg, n_run)) {
         /* this queue to the GPU, THEN the replay of the pass before it -- beside it */
-        pending_pass done = P;
-        if (done.active)
-            pthread_join(done.thread, NULL); /* (one GPU leg at a time: the pass before is off the device) */
+        if (P.active)
+            pthread_join(P.thread, NULL); /* (one GPU leg at a time: the pass before is off the device) */
+        pending_pass done = P;            /* (after the join: its thread wrote the package count into P) */
         memset(&P, 0, sizeof(P));
+        if (done.active && !H.spare_stage) {
+            /* its samples are on the device and its replay reads none of them (no dumper, no grabber here): the buffer
+               can take the queue after this one right away -- two pinned buffers in all, not three */
+            H.spare_stage = done.stage;
+            H.spare_cap   = done.stage_cap;
+            done.stage    = NULL;
+        }
         pass_start(cfg, n_run);
         if (done.active)
             events += pass_replay(cfg, &done);
         n_run = 0;
     }
     else if (P.active) { /* nothing may overtake the pass that is owed */
+        pthread_join(P.thread, NULL);
         pending_pass done = P;
-        pthread_join(done.thread, NULL);
         memset(&P, 0, sizeof(P));
         events += pass_replay(cfg, &done);
     }
