@@ -220,6 +220,58 @@ void apply_prefilter_counts(r433_batch *b, r433_r_device *const *devices, uint32
 
 } // namespace r433
 
+// One-row bitbuffers of a few bits are most of what a slicer makes of a signal that is not its decoder's (a PWM burst under a
+// PCM slicer with a short reset limit: a bitbuffer per pulse; 70 % of the records that survive the head tables of the bench's
+// decoders are one row of at most 16 bits), and the decoders they go to begin by inverting or searching the row -- a look
+// past the head, so the fenced probe learns nothing.  But a row of n bits has 2^n contents: for n <= kTinyBits every one of
+// them is ASKED, on an ordinary (readable, writable, otherwise cleared) bitbuffer_t.  If the decoder returns the same failure
+// code for all of them, twice over, it returns that code for every real bitbuffer with that head whose row carries no sync
+// count -- the verdict is stored with kPfTiny set, and the device applies it only to num_rows == free_row == 1,
+// syncs_before_row[0] == 0, no byte ever written past the row's bits (BitSink::fire).
+constexpr unsigned kTinyBits = 14;
+
+void probe_tiny(r433_r_device *dev, std::vector<uint8_t> &tab, bool &useful, bool &accepts)
+{
+    r433_bitbuffer *bits = (r433_bitbuffer *)calloc(1, sizeof(r433_bitbuffer));
+    if (!bits)
+        return;
+    unsigned tiny_bits = kTinyBits;
+    if (char const *e = getenv("R433_PROBE_TINY_BITS")) // development: cost / yield of the exhaustive part
+        tiny_bits = (unsigned)std::min(atoi(e), (int)kTinyBits);
+    (void)accepts; // (a tiny row it takes is a length left alone, nothing more: unlike a bare head it had the content to go on)
+    for (unsigned n = 0; n <= tiny_bits; ++n) {
+        if (tab[1 * kPfBits + n] != kPfKeep)
+            continue; // refused on the head alone already
+        int code = INT_MIN;
+        bool same = true;
+        for (int round = 0; round < 2 && same; ++round) {
+            memset(bits, 0, sizeof *bits); // (all of it once a round, what a refusing decoder can have touched once a call)
+            for (unsigned v = 0; v < (1u << n) && same; ++v) {
+                memset(bits, 0, offsetof(r433_bitbuffer, bb) + R433_BITBUF_COLS); // head, row lengths, sync counts, row 0
+                bits->num_rows = bits->free_row = 1;
+                bits->bits_per_row[0] = (uint16_t)n;
+                uint32_t const msb = n ? v << (16 - n) : 0u; // MSB first, like bitbuffer_add_bit
+                bits->bb[0][0] = (uint8_t)(msb >> 8);
+                bits->bb[0][1] = (uint8_t)msb;
+                int const ret = dev->decode_fn(dev, bits);
+                if (ret > 0 || ret < R433_DECODE_FAIL_SANITY)
+                    same = false;
+                else if (code == INT_MIN)
+                    code = ret;
+                else
+                    same = ret == code;
+            }
+        }
+        if (same && code != INT_MIN) {
+            tab[1 * kPfBits + n] = (uint8_t)(kPfTiny | (unsigned)(-code));
+            useful = true;
+        }
+    }
+    free(bits);
+}
+
+bool probe_heads(Fence &fence, r433_r_device *dev, std::vector<uint8_t> &tab, bool &useful, bool &accepts);
+
 // Every question one decoder is asked.  True: `tab` holds its verdicts (something to filter, answers steady).
 bool probe_one(Fence &fence, r433_r_device *dev, std::vector<uint8_t> &tab)
 {
@@ -238,20 +290,30 @@ bool probe_one(Fence &fence, r433_r_device *dev, std::vector<uint8_t> &tab)
             d->log_fn = log;
         }
     } quiet(dev);
+    bool useful = false, accepts = false;
+    tab.assign(kPfTable, (uint8_t)kPfKeep); // a head nobody asked about goes to the host: always safe
+    bool const steady = probe_heads(fence, dev, tab, useful, accepts);
+    if (!steady || accepts)
+        return false;
+    probe_tiny(dev, tab, useful, accepts);
+    return useful && !accepts;
+}
+
+// the questions under the memory fence: heads a decoder refuses without looking further.  False: its answers moved.
+bool probe_heads(Fence &fence, r433_r_device *dev, std::vector<uint8_t> &tab, bool &useful, bool &accepts)
+{
     // a decoder that reaches past the head whatever the head says is not worth 50 000 faults, and one that accepts a
     // bare head is nothing to filter
     static unsigned const sample[8][2] = {{1, 0}, {1, 1}, {1, 7}, {2, 5}, {3, 200}, {1, 1000}, {5, 33}, {12, 12}};
-    bool any = false, accepts = false;
+    bool any = false;
     for (auto const &s : sample) {
         int const ret = fence.ask(dev, s[0], s[1]);
         any |= ret != INT_MIN;
         accepts |= ret != INT_MIN && ret > 0;
     }
     if (!any || accepts)
-        return false;
-    bool useful = false;
+        return true; // (nothing learned under the fence; the tiny rows are still worth asking unless it accepted)
     unsigned faults = 0;
-    tab.assign(kPfTable, (uint8_t)kPfKeep); // a head nobody asked about goes to the host: always safe
     unsigned blind_rows = 0; // row counts in a row for which the decoder reached past the head whatever the length
     // (bitbuffers of more than 24 rows are a few in a hundred: their heads are left unasked -- they go to the host)
     constexpr unsigned kAskedRows = 25;
@@ -317,7 +379,7 @@ bool probe_one(Fence &fence, r433_r_device *dev, std::vector<uint8_t> &tab)
         }
     }
     if (!useful || accepts)
-        return false;
+        return true;
     // the same questions again: a decoder whose answers move between calls keeps state that its length test looks at
     // (only refusals are asked again, in runs of neighbouring lengths: no faults here unless the decoder did move)
     std::vector<int> again(kPfBits);
@@ -381,9 +443,10 @@ int r433_batch_probe_prefilter(r433_batch *b, r433_r_device *const *devices, uin
     std::vector<uint8_t> answered(ask_list.size(), 0);
     if (!ask_list.empty()) {
         unsigned const hw = std::thread::hardware_concurrency();
-        // (four: the refusals run side by side, the faults do not -- a process takes its signals one at a time -- and more
-        // threads only queue up for them.  Measured for the reference's 335 decoders: 0.21 s on one thread, 0.11 s on four or eight.)
-        unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(hw ? hw : 1u, 4u), ask_list.size() / 4));
+        // (eight: the refusals and the seven million tiny rows run side by side, the faults do not -- a process takes its
+        // signals one at a time.  Measured for the reference's 335 decoders: 0.95 s on one thread, 0.49 on two, 0.29 on
+        // four, 0.21 on eight; the fenced questions alone were 0.21 s on one thread and 0.11 s on four or eight.)
+        unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(hw ? hw : 1u, 8u), ask_list.size() / 4));
         if (char const *e = getenv("R433_PROBE_THREADS")) // development: A/B timing
             nt = (unsigned)std::max(1, atoi(e));
         std::atomic<uint32_t> cursor{0};

@@ -134,6 +134,9 @@ struct DevRow {
 
 // pre-filter tables: one byte per (num_rows 0..50, bits_per_row[0] 0..kPfBits-1); kPfKeep, or the decode_fn failure code negated
 constexpr uint32_t kPfRows = 51, kPfBits = 1024, kPfKeep = 0xff;
+// a verdict with this bit holds for one-row bitbuffers without a sync count and nothing written past the row's bits only: it was
+// found by asking the decoder every content such a row can have (prefilter.cpp probe_tiny), not under the memory fence
+constexpr uint32_t kPfTiny = 0x40;
 constexpr uint32_t kPfTable = kPfRows * kPfBits;
 
 struct SliceParams {

@@ -233,7 +233,9 @@ template <bool WRITE> struct BitSink {
         // the next one is built over it (same offset, next ordinal), the refusal is counted under the code the decoder
         // would have returned.  Every pass of the slicer takes the same decisions, so sizes and offsets agree.
         if (pf && num_rows <= R433_BB_ROWS && free_row == num_rows && row0_bits < kPfBits) {
-            uint32_t const verdict = pf[num_rows * kPfBits + row0_bits];
+            uint32_t verdict = pf[num_rows * kPfBits + row0_bits];
+            if (verdict != kPfKeep && (verdict & kPfTiny)) // asked content by content for plain one-row bitbuffers only
+                verdict = (num_rows == 1 && cur_syncs == 0 && extent == cur_bits) ? (verdict & ~kPfTiny) : kPfKeep;
             if (verdict != kPfKeep) {
                 pf_d0 += verdict == 0u || verdict > 4u;
                 pf_d1 += verdict == 1u;

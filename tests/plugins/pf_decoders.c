@@ -49,11 +49,14 @@ int pf_dec_rows(struct r_device *d, bitbuffer_t *b)
     return -1;
 }
 
-/* the data first */
+/* the data first (so nothing is learned from the head alone); a short row is refused whatever it holds -- unless sync pulses
+ * came before it: what the exhaustive probe of tiny rows may and may not conclude */
 int pf_dec_data(struct r_device *d, bitbuffer_t *b)
 {
     (void)d;
     pf_calls[3]++;
+    if (b->syncs_before_row[0])
+        return -3;
     if (b->bb[0][0] == 0xff)
         return -2;
     return b->bits_per_row[0] < 12 ? -1 : payload_verdict(b, 0);
