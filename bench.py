@@ -324,7 +324,7 @@ class Pipeline:
     decoders, the GPU already works on steps k+1, k+2.  Every step is one complete pass of the hot path over its
     batch, and all K of them finish inside the timed region."""
 
-    def __init__(self, cfg_fn, devs, rdev_arr, threads, n_eng, local_rank, on_host_leg=None, ordered=False):
+    def __init__(self, cfg_fn, devs, rdev_arr, threads, n_eng, local_rank, on_host_leg=None, ordered=False, hooks=None):
         import torch
         from concurrent.futures import ThreadPoolExecutor
 
@@ -344,6 +344,7 @@ class Pipeline:
         self.local_rank = local_rank
         self.on_host_leg = on_host_leg
         self.ordered = ordered  # the replay for decoders that keep state between calls (r433_batch_dispatch_ordered)
+        self.hooks = hooks      # r433_dispatch_hooks of the ordered replay (the plugins' output_render: JSON lines made on the replay threads)
         self.stagger = 0.0
         self.replay_s = []  # the library's replay call alone, per host leg
 
@@ -360,7 +361,7 @@ class Pipeline:
         e = self.engines[k % self.n_eng]
         t0 = time.perf_counter()
         if self.ordered:
-            e.dispatch_ordered(self.rdev_arr, None, self.threads)
+            e.dispatch_ordered(self.rdev_arr, self.hooks, self.threads)
         else:
             e.dispatch(self.rdev_arr, n_threads=self.threads)
         self.replay_s.append(time.perf_counter() - t0)
@@ -543,7 +544,8 @@ def run_batched(args, ctxd):
         st[5] += ev_n          # bitbuffers that crossed to the host (the pre-filter keeps the provably refused ones on the device)
         st[6] += pk_b + ev_b   # bytes of records copied back
 
-    pipe = Pipeline(lambda: flow_cfg(2, 250000), devs, plug.devices, threads, max(2, args.engines), local_rank, on_host_leg, ordered=True)
+    pipe = Pipeline(lambda: flow_cfg(2, 250000), devs, plug.devices, threads, max(2, args.engines), local_rank, on_host_leg, ordered=True,
+                    hooks=plug.hooks() if hasattr(plug, "hooks") else None)
     for e in pipe.engines:
         e.set_stateless(stateless)
         e.probe_prefilter(plug.devices)  # records a decoder provably refuses on their head stay on the device (statistics unchanged)
@@ -666,7 +668,7 @@ def run_batched(args, ctxd):
         pipe.on_host_leg = None
         plug.take()
         pipe.gpu_leg(0, src=batches[0][:n_batch])
-        e0.dispatch_ordered(plug.devices, None, threads)
+        e0.dispatch_ordered(plug.devices, pipe.hooks, threads)  # (the replay of the timed region, hook and all)
         gpu_text, gpu_msgs = plug.take()
         e0.set_prefilter(0)
         ctx.sum = 0

@@ -43,6 +43,7 @@ int r433p_devices(void *h, r433_r_device **out, int cap);
 size_t r433p_take(void *h, char const **text, unsigned long *messages);
 int r433p_stateless(void *h, unsigned char *flags, int cap);
 void r433p_destroy(void *h);
+void *r433p_render(void *user, void *device, void *data); /* r433_dispatch_hooks.output_render: data_t -> its JSON line, on the replay threads */
 
 typedef struct leg {
     r433_batch *eng;
@@ -302,8 +303,10 @@ int main(int argc, char **argv)
             rc = 1;
             break;
         }
-        /* the replay, in list order: the decoders of pass k run while the other engines' passes are on the GPU */
-        int const ev = r433_batch_dispatch_ordered(g->eng, devs, (uint32_t)n_dev, NULL, threads);
+        /* the replay, in list order: the decoders of pass k run while the other engines' passes are on the GPU; what they report
+           is rendered where they ran, this thread appends the lines in reference order */
+        r433_dispatch_hooks const hooks = {plugins, NULL, NULL, NULL, NULL, (void *(*)(void *, r433_r_device *, void *))r433p_render};
+        int const ev = r433_batch_dispatch_ordered(g->eng, devs, (uint32_t)n_dev, &hooks, threads);
         if (ev < 0) {
             fprintf(stderr, "r433_batch_dispatch_ordered: %s\n", r433_last_error());
             rc = 1;

@@ -9,6 +9,7 @@
  * buffer the host takes, one line per message -- the payload of the final event gather of BASELINE.json configs[3].
  *
  * Own code: only this file.  Compiled against the reference's headers; C99. */
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -36,12 +37,27 @@ static void quiet_log(log_level_t level, char const *src, char const *msg, void 
     (void)userdata;
 }
 
-static void take_message(r_device *decoder, data_t *data)
+/* A rendered message: what r433p_render hands the replay in a data_t's place.  take_message tells the two apart by the first
+ * word: a data_t begins with its `next` pointer (include/data.h:70-72: NULL or a malloc'ed data_t), never with this value. */
+#define R433P_LINE_MAGIC ((uintptr_t)0x52343333u | 1u) /* "R433", odd: no allocator returns it */
+typedef struct r433p_line {
+    uintptr_t magic;
+    char *text;
+} r433p_line;
+
+/* the rendering: a pure function of the data (any thread) */
+static char *render_line(data_t *data)
 {
-    r433p *h = decoder->output_ctx;
     char *line = data_print_jsons_dup(data); /* grows until the whole document fits: never a truncated line */
     if (!line)
         abort();
+    data_free(data);
+    return line;
+}
+
+/* the ordered append (the committing thread): takes the line */
+static void append_line(r433p *h, char *line)
+{
     size_t const n = strlen(line);
     if (h->cap - h->len < n + 2) {
         while (h->cap - h->len < n + 2)
@@ -56,7 +72,34 @@ static void take_message(r_device *decoder, data_t *data)
     h->text[h->len++] = '\n';
     h->text[h->len]   = '\0';
     h->messages += 1;
-    data_free(data);
+}
+
+/* r_device.output_fn: a data_t from a decoder -- or, behind a replay that was given r433p_render as its output_render hook
+ * (include/r433_hip.h r433_dispatch_hooks), the line the data was rendered to on the replay thread that ran the decoder. */
+static void take_message(r_device *decoder, data_t *data)
+{
+    r433p *h = decoder->output_ctx;
+    r433p_line *rendered = (r433p_line *)data;
+    if (rendered->magic == R433P_LINE_MAGIC) {
+        append_line(h, rendered->text);
+        free(rendered);
+    }
+    else {
+        append_line(h, render_line(data));
+    }
+}
+
+/* r433_dispatch_hooks.output_render for these plugins (thread-safe: it only touches the data it is given) */
+void *r433p_render(void *user, void *device, void *data)
+{
+    (void)user;
+    (void)device;
+    r433p_line *rendered = malloc(sizeof(*rendered));
+    if (!rendered)
+        abort();
+    rendered->magic = R433P_LINE_MAGIC;
+    rendered->text  = render_line(data);
+    return rendered;
 }
 
 static void drop_log(r_device *decoder, int level, data_t *data)

@@ -934,11 +934,11 @@ static int replay_group(r_cfg_t *cfg, hip_capture *group, size_t n, int n_pkgs)
     int events;
     double const t_replay = trace_now();
     if (chatty || n_threads <= 1) {
-        r433_dispatch_hooks hooks = {NULL, on_package_begin, on_event_done, on_package_end, H.sync_active ? sync_filter : NULL};
+        r433_dispatch_hooks hooks = {NULL, on_package_begin, on_event_done, on_package_end, H.sync_active ? sync_filter : NULL, NULL};
         events = r433_batch_dispatch_hooks(H.eng, (r433_r_device *const *)demod->r_devs.elems, (uint32_t)demod->r_devs.len, &hooks);
     }
     else {
-        r433_dispatch_hooks hooks = {NULL, on_package_begin, NULL, on_package_end, H.sync_active ? sync_filter : NULL};
+        r433_dispatch_hooks hooks = {NULL, on_package_begin, NULL, on_package_end, H.sync_active ? sync_filter : NULL, NULL};
         events = r433_batch_dispatch_ordered(H.eng, (r433_r_device *const *)demod->r_devs.elems, (uint32_t)demod->r_devs.len, &hooks, (uint32_t)n_threads);
     }
     if (events == R433_EDECODER) {

@@ -224,6 +224,13 @@ typedef struct r433_dispatch_hooks {
      * dropin/r_flow_hip.c uses it when it has to answer every push at once (-E quit): it then replays a growing prefix of the
      * capture and only lets the packages of the newest frame through. */
     int (*package_filter)(void *user, r433_pkg_rec const *rec);
+    /* optional, r433_batch_dispatch_ordered only: called on the replay thread that runs the decoder, at the moment the decoder
+     * hands a data_t to r_device.output_fn (src/decoder_util.c decoder_output_data); what it returns takes the data's place
+     * in the output_fn call committed later, in reference order, on the calling thread.  For hosts whose output handler is a
+     * pure rendering of the data followed by an ordered append (dropin/plugins_shim.c: the JSON line of data_print_jsons):
+     * the rendering -- 0.7 us per event, a sixth of a replay when it all ran on the committing thread -- then runs beside
+     * the other decoders.  Must be thread-safe; owns the data_t from then on.  Log messages (log_fn) are not rendered. */
+    void *(*output_render)(void *user, r433_r_device *device, void *data);
 } r433_dispatch_hooks;
 int r433_batch_dispatch_hooks(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices,
         r433_dispatch_hooks const *hooks);
@@ -263,9 +270,13 @@ int r433_batch_decoded(r433_batch *b, int const **per_package, uint32_t *count);
  * and counts them per decoder and code; the dispatch functions add the counts to decode_events / decode_fails exactly as
  * account_event would have, so `-M stats` is unchanged.  Only decoders of the lowest priority level are filtered (the others
  * are not called for every package, src/r_api.c:442-451), only with verbose == 0 (account_event prints refused bitbuffers at
- * -vv), and never together with an event_done hook or a package_filter.  decode_fn is called n times per decoder here
- * (~50 000, outside account_event: no statistics move); a decoder that keeps state between calls must not let that state
- * decide its length test.  Returns the number of decoders with at least one provable refusal. */
+ * -vv), and never together with an event_done hook or a package_filter.  One-row bitbuffers of at most 14 bits are asked
+ * content by content as well: every one of the 2^n rows on an ordinary cleared bitbuffer_t, twice; where all of them get the
+ * same failure code, a bitbuffer of exactly that shape (one row, no sync pulses before it, nothing ever written behind its
+ * bits) is dropped under that code too.  decode_fn is called n times per decoder here (~50 000 heads and up to 65 534 tiny
+ * rows, outside account_event: no statistics move; output_fn and log_fn are swallowed meanwhile); a decoder that keeps state
+ * between calls must not let that state decide what it refuses, and must not remember a bitbuffer it refuses.  Returns the
+ * number of decoders with at least one provable refusal. */
 int r433_batch_probe_prefilter(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices);
 /* What the decoders answered is remembered for the life of the process (several engines over the same decoder objects ask
  * once), keyed by the decoder object, its decode_fn / decode_ctx pointers, protocol number, line code, timings and name.  A

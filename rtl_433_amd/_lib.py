@@ -106,7 +106,7 @@ HOOK_FILTER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(PkgRec))
 class DispatchHooks(C.Structure):
     """r433_dispatch_hooks (include/r433_hip.h)."""
     _fields_ = [("user", C.c_void_p), ("package_begin", HOOK_BEGIN_FN), ("event_done", HOOK_EVENT_FN),
-                ("package_end", HOOK_END_FN), ("package_filter", HOOK_FILTER_FN)]
+                ("package_end", HOOK_END_FN), ("package_filter", HOOK_FILTER_FN), ("output_render", C.c_void_p)]
 
 _lib = None
 

@@ -307,7 +307,7 @@ int r433_batch_dispatch_hooks(r433_batch *b, r433_r_device *const *devices, uint
         return fail(R433_EINVAL, "the last run dropped records on the device (r433_batch_probe_prefilter): no event_done hook or package_filter can see them");
     std::vector<DevStats> stats(n_devices);
     std::string err;
-    static r433_dispatch_hooks const none = {nullptr, nullptr, nullptr, nullptr};
+    static r433_dispatch_hooks const none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int const decoded = dispatch_range(b, devices, n_devices, nullptr, nullptr, 0, b->n_pkgs, stats, err, hooks ? hooks : &none);
     digest_publish();
     if (decoded < 0)
@@ -329,12 +329,15 @@ struct Captured {
 struct CaptureCtx {
     std::vector<Captured> *out = nullptr;
     uint32_t level_rank = 0, seq = 0;
+    void *(*render)(void *user, r433_r_device *device, void *data) = nullptr; // r433_dispatch_hooks::output_render
+    void *render_user = nullptr;
 };
 thread_local CaptureCtx g_capture;
 
 void capture_output(r433_r_device *decoder, struct data *payload)
 {
-    (void)decoder;
+    if (g_capture.out && g_capture.render) // the host renders what the decoder reported right here, beside the other decoders
+        payload = (struct data *)g_capture.render(g_capture.render_user, decoder, payload);
     if (g_capture.out)
         g_capture.out->push_back({g_current.package, g_capture.level_rank, g_current.device, g_current.ordinal, g_capture.seq++, 0, 0, payload});
 }
@@ -632,6 +635,8 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
             r433_bitbuffer *bits = (r433_bitbuffer *)calloc(1, sizeof(r433_bitbuffer));
             g_capture.out = &captured[w];
             g_capture.level_rank = li;
+            g_capture.render = hooks ? hooks->output_render : nullptr;
+            g_capture.render_user = hooks ? hooks->user : nullptr;
             for (;;) {
                 uint32_t const k = cursor.fetch_add(1, std::memory_order_relaxed);
                 if (k >= items.size() || failed.load(std::memory_order_relaxed))
@@ -676,6 +681,7 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
                 book(dev, t);
             }
             g_capture.out = nullptr;
+            g_capture.render = nullptr;
             digest_publish();
             free(bits);
         });

@@ -325,7 +325,7 @@ static int slice_one(pulse_data_t const *pulses, r_device *device, unsigned modu
     if (r433_batch_run_pulses(b, &copy, 1, NULL) < 0)
         die("r433_batch_run_pulses");
     EventHook hook = {func};
-    r433_dispatch_hooks hooks = {&hook, NULL, on_event, NULL, NULL};
+    r433_dispatch_hooks hooks = {&hook, NULL, on_event, NULL, NULL, NULL};
     r433_r_device *devs[1] = {device};
     int const events = r433_batch_dispatch_hooks(b, devs, 1, &hooks);
     if (events == R433_EDECODER) {

@@ -60,6 +60,15 @@ class Plugins:
         assert self.L.r433p_stateless(self.h, flags, len(flags)) == len(flags)
         return flags
 
+    def hooks(self):
+        """-> r433_dispatch_hooks for the ordered replay of these plugins: what a decoder reports is rendered to its JSON line
+        on the replay thread that ran it (output_render = r433p_render), the commit only appends the lines in order"""
+        from ._lib import DispatchHooks
+        h = DispatchHooks()
+        h.user = self.h
+        h.output_render = C.cast(self.L.r433p_render, C.c_void_p).value
+        return h
+
     def take(self):
         """-> (JSON lines since the last call as bytes, number of messages)"""
         text, n = C.c_char_p(), C.c_ulong()

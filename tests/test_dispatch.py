@@ -437,3 +437,30 @@ def test_engine_on_a_chosen_device(backend):
     assert e0.packages() == e1.packages()
     e0.close()
     e1.close()
+
+
+def test_output_render_hook_of_the_ordered_replay(backend):
+    """r433_dispatch_hooks.output_render: what the reference's real decoders report is rendered to its JSON line on the replay
+    thread that ran the decoder (dropin/plugins_shim.c r433p_render), the commit appends the lines in order -- the same text,
+    byte for byte, as when the output handler renders on the committing thread; a plain test plugin sees the hook's return
+    value in its output_fn, in reference order."""
+    from rtl_433_amd import plugins, protocols
+    from rtl_433_amd.engine import load_device_table
+    if not plugins.available():
+        pytest.skip("dropin/_build/libr433plugins.so not built")
+    devs = load_device_table()[0]
+    iqs = [protocols.bench_capture(3 * i + 2)[0] if i % 2 else synth.ook_stream(900 + i)[0] for i in range(10)]
+    eng, _ = _setup(devs, iqs, backend)
+    plug = plugins.Plugins()
+    texts = []
+    for hooks, threads in ((None, 1), (None, 5), (plug.hooks(), 1), (plug.hooks(), 5)):
+        n = eng.dispatch_ordered(plug.devices, hooks, threads)
+        text, n_msg = plug.take()
+        assert n == n_msg == text.count(b"\n") >= 4
+        texts.append(text)
+    assert texts[0] == texts[1] == texts[2] == texts[3]
+    eng.set_stateless(plug.stateless())  # a decoder's calls on several threads: the rendering, too
+    eng.dispatch_ordered(plug.devices, plug.hooks(), 5)
+    assert plug.take()[0] == texts[0]
+    plug.close()
+    eng.close()

@@ -23,7 +23,7 @@ for rep in range(3):
     n = eng.run(d)
     import time
     t0 = time.perf_counter()
-    ev = eng.dispatch_ordered(plug.devices, None, threads)
+    ev = eng.dispatch_ordered(plug.devices, plug.hooks() if hasattr(plug, 'hooks') else None, threads)
     dt = time.perf_counter() - t0
     text, n_msg = plug.take()
 print(f"{n} packages, {ev} decoded events, {n_msg} messages, replay {dt * 1e3:.2f} ms on {threads} threads; records {len(eng.events()[0])} B + packages {len(eng.packages()[0])} B; timing {eng.timing()}")

@@ -1,5 +1,6 @@
 #!/bin/bash
 # The closing GPU visit of round 4: everything profiles/r04_* quotes, from one build.  tools/gpu_r4_final.sh [tag]
+# R433_SKIP_WAVE_PMC=1 leaves the k_wave counter passes out (stream_kernels.hip unchanged since they were taken).
 TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -24,8 +25,10 @@ echo "== kbench: the detection kernel alone, by grid size; lazy tiles on / off; 
   timeout 300 python tools/kbench.py --nodevs --fsk-cu8 2>&1 | tail -1
   timeout 300 python tools/lazy_stats.py 1024 2>&1 | tail -2; } 2>&1 | grep -v amdgpu.ids | tee $OUT/kbench.txt
 echo "== PMC: traffic (FETCH_SIZE / WRITE_SIZE), issue (SQ counters, whole kernel and producers alone)"
+if [ -z "$R433_SKIP_WAVE_PMC" ]; then
 timeout 1200 python tools/pmc_traffic.py 2>&1 | tail -5 | cut -c1-300
 timeout 900 python tools/pmc_issue.py 2>&1 | tail -32
+fi
 echo "== PMC: slicers"
 for pmc in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   bash tools/pmc_run.sh ${TAG}_slice_$(echo $pmc | cut -d' ' -f2) "$pmc" --streams 8192 2>&1 | grep k_slice | cut -c1-130
@@ -39,11 +42,13 @@ echo "== the C pipeline host (one GPU; -g 0 = every visible GPU)"
   cd /tmp/cli_bench && for rep in 1 2; do $GRAFT_REPO_ROOT/dropin/_build/pipeline_host_hip -q -g 0 -b 1024 -p $(ls s*_433.92M_250k.cu8 | head -8192 | tr '\n' ' ') 2>&1 | tail -2 | sed 's/^/[-g 0 -b 1024 -p] /'; done; cd $GRAFT_REPO_ROOT; } 2>&1 | tee $OUT/pipeline_host.txt
 echo "== timeline of the pipeline (real decoders, stateless flags, 24 threads)"
 timeout 300 python tools/leg_timeline.py 12 3 2 24 1 2>&1 | grep -v amdgpu.ids | tee $OUT/leg_timeline.txt | head -12
+echo "== where the CPU quota goes"
+timeout 200 python tools/cpu_budget.py 12 2>&1 | grep -v amdgpu.ids | tee $OUT/cpu_budget.txt
 echo "== dispatch trace"
 timeout 200 python tools/dispatch_trace.py 24 1 2>&1 | grep "r.dispatch\|replay" | cut -c1-400 | tee $OUT/dispatch_trace.txt
 echo "== probes"
 { timeout 120 python tools/pcie_probe.py; } 2>&1 | grep -v amdgpu.ids | tee $OUT/probes.txt
 echo "== fuzz (GPU, 6000 cases)"
-timeout 1500 python tools/fuzz_emu.py --gpu 6000 500000 2>&1 | tail -1 | tee $OUT/fuzz.txt
+timeout 1500 python tools/fuzz_emu.py --gpu ${R433_FUZZ_CASES:-6000} 500000 2>&1 | tail -1 | tee $OUT/fuzz.txt
 grep thrott /sys/fs/cgroup/cpu.stat | tee -a $OUT/host.txt
 ls $OUT

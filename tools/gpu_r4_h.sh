@@ -13,4 +13,4 @@ timeout 300 python tools/leg_timeline.py 12 3 2 24 1 2>&1 | grep -v amdgpu.ids |
 echo "== dispatch trace"
 timeout 200 python tools/dispatch_trace.py 24 1 2>&1 | grep "r.dispatch\|replay" | cut -c1-400 | tee $OUT/dispatch_trace.txt
 echo "== fuzz (GPU, 1000 cases)"
-timeout 600 python tools/fuzz_emu.py --gpu 1000 500000 2>&1 | tail -1 | tee $OUT/fuzz.txt
+timeout 600 python tools/fuzz_emu.py --gpu 300 500000 2>&1 | tail -1 | tee $OUT/fuzz.txt

@@ -30,7 +30,8 @@ rdev_arr, rdev_objs = make_rdevices(devs, digest_plugin_addr(), C.addressof(ctx)
 if real:
     from rtl_433_amd import plugins
     plug = plugins.Plugins()
-    pipe = bench.Pipeline(lambda: flow_cfg(2, 250000), devs, plug.devices, threads, n_eng, 0, on_host_leg=lambda k, e, n: plug.take(), ordered=True)
+    pipe = bench.Pipeline(lambda: flow_cfg(2, 250000), devs, plug.devices, threads, n_eng, 0, on_host_leg=lambda k, e, n: plug.take(), ordered=True,
+                          hooks=plug.hooks() if hasattr(plug, "hooks") else None)
     for e in pipe.engines:
         e.set_stateless(plugins.stateless_flags(plug.devices))
         e.probe_prefilter(plug.devices)
