@@ -610,11 +610,12 @@ static void engine_prefilter(r_cfg_t *cfg)
 {
     struct dm_state *demod = cfg->demod;
     char const *env        = getenv("RTL433_HIP_PREFILTER");
-    /* Asking every decoder costs 0.1-0.2 s once per process; what it saves is ~40 % of the record copy and of the replay's
-       calls.  Measured with the CLI on the MI355X box (tools/cli_bench.sh): 1024 captures of 128 KiB 0.31 s without / 0.47 s
-       with, 8192 captures 1.49 s without / 1.26 s with.  So: from half a GiB of samples on, or when told to
-       (RTL433_HIP_PREFILTER=1; =0: never). */
-    int const worth        = (env && env[0] == '1') || H.staged_total >= ((size_t)1 << 29);
+    /* Asking every decoder costs 0.2-0.3 s once per process (50 000 heads and up to 65 534 tiny rows each, eight threads); what
+       it saves is two thirds of the records: of their copy and of the replay's calls -- 15-20 ms per GiB of samples as dense
+       with signals as the bench's, a few ms per GiB of mostly idle captures.  Measured with the CLI on the MI355X box
+       (tools/gpu_r4_cli.sh): 8192 captures of 128 KiB (1 GiB) 0.46-0.78 s without the questions, 0.59-0.90 s with them asked
+       half-way.  So: from 8 GiB of samples on, or when told to (RTL433_HIP_PREFILTER=1; =0: never). */
+    int const worth        = (env && env[0] == '1') || H.staged_total >= ((size_t)1 << 33);
     int const want         = !(env && env[0] == '0') && worth && !H.sync_active && replay_threads() > 1 && !replay_is_chatty(demod) && demod->r_devs.len;
     if (want && !H.cur->probed) {
         H.cur->probed = 1;

@@ -84,7 +84,7 @@ def test_emu_corpus_subset(tmp_path):
 def test_hip_corpus_256_files(tmp_path):
     """256 files, 22 protocols, nine modulations through rtl_433_hip (device-side pre-filter on) and the stock binary"""
     _ensure_built(HIP)
-    ref, seen = check_corpus(HIP, tmp_path, 256, 20, {"RTL433_HIP_PREFILTER": "1"})  # (by itself the CLI asks only from half a GiB of samples on)
+    ref, seen = check_corpus(HIP, tmp_path, 256, 20, {"RTL433_HIP_PREFILTER": "1"})  # (by itself the CLI asks only from 8 GiB of samples on)
     assert "Secplus-v1" in seen and "Rubicson-Temperature" in seen and "Nexus-TH" in seen
     assert '"mod" : "FSK"' in ref and '"mod" : "ASK"' in ref
 

@@ -1,12 +1,9 @@
 #!/bin/bash
-# the drop-in CLI with two passes in flight: its GPU tests, 1024 and 8192 files against the stock binary, overlap on / off
+# the drop-in CLI over 8192 files against the stock binary (the second half of tools/gpu_r4_cli.sh alone)
 OUT=gpurun_out/r04cli
 mkdir -p $OUT
-export TMPDIR=/tmp
-[ -n "$R433_SKIP_TESTS" ] || timeout 900 python -m pytest tests/test_dropin.py tests/test_corpus.py -m gpu -q -x 2>&1 | tail -3 | tee $OUT/pytest.txt
-timeout 600 tools/cli_bench.sh 1024 $OUT 2>&1 | tail -3
-mv $OUT/cli_bench.txt $OUT/cli_bench_1024.txt
 D=/tmp/cli_bench
+mkdir -p $D
 python - <<PY
 import sys, os
 sys.path.insert(0, "$PWD")
@@ -24,10 +21,12 @@ t() { local s=$(date +%s%N); "$@"; local e=$(date +%s%N); echo "$(( (e - s) / 10
 {
 tr=$(t $REF $ARGS -F json:ref.json -M level -K FILE 2>/dev/null)
 echo "8192 files: reference ${tr} ms, $(wc -l < ref.json) lines"
-for mode in 1 0 1 0 1; do
+for mode in 1 0 1 0 1 1; do
   rm -f hip.json
   th=$(RTL433_HIP_OVERLAP=$([ $mode = 1 ] && echo "" || echo 0) t $HIP $ARGS -F json:hip.json -M level -K FILE 2>/dev/null)
   echo "8192 files: hip ${th} ms (two passes in flight: $([ $mode = 1 ] && echo on || echo off))  $(cmp -s ref.json hip.json && echo IDENTICAL || echo DIFFERENT)"
 done
-rm -f hip.json; RTL433_HIP_TRACE=1 $HIP $ARGS -F json:hip.json -M level -K FILE 2>&1 >/dev/null | grep "hip flow" | tail -14
+rm -f hip.json
+th=$(RTL433_HIP_PREFILTER=1 t $HIP $ARGS -F json:hip.json -M level -K FILE 2>/dev/null)
+echo "8192 files: hip ${th} ms (RTL433_HIP_PREFILTER=1: the decoders asked before the first pass)  $(cmp -s ref.json hip.json && echo IDENTICAL || echo DIFFERENT)"
 } | tee $GRAFT_REPO_ROOT/$OUT/cli_bench_8192.txt
