@@ -83,3 +83,59 @@ int pf_dec_zero(struct r_device *d, bitbuffer_t *b)
         return -4;
     return payload_verdict(b, 0);
 }
+
+/* ---- decoders made of a random list of first-line tests (tests/test_prefilter.py::test_prefilter_random_decoders) ----
+ * decode_ctx (reference include/r_device.h: the last-but-one pointer of an r_device; offset 136 on LP64, include/r433_abi.h)
+ * points at a program: steps of the kinds the reference's decoders open with -- tests of the head, of other rows' lengths, of
+ * the sync count, of the content (after an inversion in place, through a search, by a sum) -- each returning its code. */
+typedef struct pf_step { int op, a, b, code; } pf_step;
+typedef struct pf_prog { int n; pf_step s[10]; unsigned long calls; } pf_prog;
+
+int pf_dec_random(struct r_device *d, bitbuffer_t *b)
+{
+    pf_prog *p = *(pf_prog **)((char *)d + 136);
+    p->calls++;
+    for (int k = 0; k < p->n; ++k) {
+        pf_step const *s = &p->s[k];
+        unsigned const bits0 = b->bits_per_row[0], nbytes0 = (bits0 + 7) / 8 < 128 ? (bits0 + 7) / 8 : 128;
+        switch (s->op) {
+        case 0: if (b->num_rows != s->a) return s->code; break;
+        case 1: if (b->num_rows < s->a || b->num_rows > s->b) return s->code; break;
+        case 2: if ((int)bits0 < s->a) return s->code; break;
+        case 3: if ((int)bits0 > s->b) return s->code; break;
+        case 4: if ((int)bits0 != s->a && (int)bits0 != s->b) return s->code; break;
+        case 5: /* bitbuffer_invert on row 0, then a look at its first byte */
+            for (unsigned i = 0; i < nbytes0; ++i)
+                b->bb[0][i] = (uint8_t)~b->bb[0][i];
+            if (bits0 % 8)
+                b->bb[0][nbytes0 - 1] &= (uint8_t)(0xff00 >> (bits0 % 8));
+            if (nbytes0 && b->bb[0][0] == (uint8_t)s->a) return s->code;
+            break;
+        case 6: if (b->syncs_before_row[0] != 0) return s->code; break;
+        case 7: { /* a search for a byte in row 0 */
+            unsigned i = 0;
+            while (i < nbytes0 && b->bb[0][i] != (uint8_t)s->a)
+                ++i;
+            if (i == nbytes0) return s->code;
+            break;
+        }
+        case 8: { /* the first row long enough, or none */
+            int r = 0;
+            while (r < b->num_rows && b->bits_per_row[r] < s->a)
+                ++r;
+            if (r == b->num_rows) return s->code;
+            break;
+        }
+        case 9: { /* a checksum over row 0 */
+            unsigned sum = 0;
+            for (unsigned i = 0; i < nbytes0; ++i)
+                sum += b->bb[0][i];
+            if (sum % (unsigned)s->a == (unsigned)s->b) return s->code;
+            break;
+        }
+        case 10: if (b->num_rows > 1 && b->bits_per_row[1] != bits0) return s->code; break; /* another row's length */
+        default: break;
+        }
+    }
+    return payload_verdict(b, 0);
+}

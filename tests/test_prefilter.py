@@ -168,3 +168,90 @@ def test_prefilter_real_decoders(backend):
     assert b["tables"] > 200
     assert a["stats"] == b["stats"] and a["per_pkg"] == b["per_pkg"] and a["decoded"] == b["decoded"]
     assert b["nev"] < 0.3 * a["nev"]
+
+
+class _Step(C.Structure):
+    _fields_ = [("op", C.c_int), ("a", C.c_int), ("b", C.c_int), ("code", C.c_int)]
+
+
+class _Prog(C.Structure):  # pf_prog, tests/plugins/pf_decoders.c
+    _fields_ = [("n", C.c_int), ("s", _Step * 10), ("calls", C.c_ulong)]
+
+
+def _random_case(seed, n_dev):
+    """timing rows of the common OOK line codes and a program of first-line tests per decoder"""
+    rng = np.random.default_rng(seed)
+    devs = np.zeros(n_dev, dtype=po.DEV_DTYPE)
+    progs = (_Prog * n_dev)()
+    for i in range(n_dev):
+        mod = int(rng.choice([3, 4, 5, 6, 6, 5, 4]))
+        short = float(rng.choice([80, 100, 200, 250, 400, 500]))
+        long_ = short if mod in (3, 4) else short * float(rng.choice([2, 3]))
+        reset = float(rng.choice([600, 900, 1500, 3000, 6000, 10000]))
+        gap = 0.0 if mod in (3, 4) else float(rng.choice([0, 700, 1000, 2000])) if reset > 2500 else float(rng.choice([0, 500]))
+        sync = float(rng.choice([0, 0, 900, 1200])) if mod == 6 else 0.0
+        tol = 0.0 if mod in (3, 4) else float(rng.choice([0, 80, 150]))
+        devs[i] = (mod, short, 0.0 if mod == 3 else long_, reset, gap, sync, tol, 0)
+        p = progs[i]
+        p.n = int(rng.integers(1, 7))
+        for k in range(p.n):
+            op = int(rng.choice([0, 1, 2, 2, 3, 4, 5, 6, 7, 8, 9, 10]))
+            a, b = int(rng.integers(0, 40)), int(rng.integers(0, 64))
+            if op == 0:
+                a = int(rng.choice([1, 1, 2, 3]))
+            elif op == 1:
+                a, b = int(rng.integers(1, 4)), int(rng.integers(3, 30))
+            elif op in (2, 8):
+                a = int(rng.choice([4, 8, 12, 16, 24, 40, 64]))
+            elif op == 3:
+                b = int(rng.choice([16, 40, 80, 200, 600]))
+            elif op in (5, 7):
+                a = int(rng.choice([0x00, 0xff, 0xaa, 0x55, int(rng.integers(0, 256))]))
+            elif op == 9:
+                a, b = int(rng.integers(2, 9)), int(rng.integers(0, 2))
+            p.s[k] = _Step(op, a, b, -int(rng.integers(0, 5)))
+    return devs, progs
+
+
+EMU_SEEDS = (0, 1, 7, 9)  # (7: the case that fails when BitSink::fire forgets the sync count of a tiny row)
+
+
+@pytest.mark.parametrize("seed", [pytest.param(s, marks=[] if s in EMU_SEEDS else [pytest.mark.gpu]) for s in range(12)])
+def test_prefilter_random_decoders(backend, plugins, seed):
+    """Decoders drawn at random: 16 timing rows of the OOK line codes, each with a program of one to six first-line tests of
+    the kinds the reference's decoders open with (head, other rows, sync count, content after an in-place inversion, a search, a
+    checksum).  Whatever the probe makes of them -- head tables, tiny-row tables, nothing -- statistics, events per package and
+    the calls that still arrive are those of the unfiltered run minus exactly what the device says it dropped."""
+    if backend == "emu" and seed not in EMU_SEEDS:
+        pytest.skip("the other seeds run on the GPU")
+    n_dev = 16
+    devs, progs = _random_case(1000 + seed, n_dev)
+    iqs = [synth.ook_stream(5000 + 17 * seed + k, 50000)[0] for k in range(14)] + [synth.random_cu8(300 + seed, 6000)]
+    runs = {}
+    for mode in ("plain", "filtered"):
+        eng = _engine(devs, backend)
+        arr, objs = make_rdevices(devs)
+        for i, o in enumerate(objs):
+            o.decode_fn = C.cast(plugins.pf_dec_random, C.c_void_p).value
+            o.decode_ctx = C.addressof(progs[i])
+        tables = eng.probe_prefilter(arr) if mode == "filtered" else 0
+        for p in progs:
+            p.calls = 0
+        eng.run_host(iqs)
+        ev, nev = eng.events()
+        dec = eng.dispatch(arr, n_threads=1)
+        runs[mode] = dict(stats=_stats(objs), per_pkg=list(eng.decoded()), decoded=dec, nev=nev, records=_records(ev),
+                          calls=[int(p.calls) for p in progs], tables=tables,
+                          dropped=eng.prefilter_counts() if mode == "filtered" else None)
+        eng.close()
+    a, b = runs["plain"], runs["filtered"]
+    assert a["stats"] == b["stats"] and a["per_pkg"] == b["per_pkg"] and a["decoded"] == b["decoded"]
+    assert a["nev"] > 200  # (the case has something to filter)
+    dropped = b["dropped"]
+    assert int(dropped.sum()) == a["nev"] - b["nev"]
+    for i in range(n_dev):
+        assert a["calls"][i] - b["calls"][i] == int(dropped[i].sum())
+    it = iter(a["records"])
+    assert all(any(r == x for x in it) for r in b["records"])
+    if b["tables"]:
+        assert b["nev"] < a["nev"]
