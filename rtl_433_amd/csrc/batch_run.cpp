@@ -706,12 +706,14 @@ int run_slice_and_mirror(RunCtx &r)
         // A batch whose staging slots would not fit the arena's limit goes through the slicers a stretch of packages at a
         // time, every stretch into the SAME slots (slice, scan its sizes on from the total so far, place): full-size slots
         // for any number of packages.  (Not a matter of speed: 8192 packages in one go take 3.9 ms, in eight stretches 5.0.)
-        uint32_t const fit = (uint32_t)std::max<size_t>(1, kStageMax / (b->rows.size() * 8192u));
+        uint32_t const fit = (uint32_t)std::max<size_t>(1, kStageMax / ((size_t)n_devs * 8192u)); // (a slot per device, not per padded row)
         uint32_t const stretch = (b->debug_flags & (R433_DEBUG_TWO_PASS_SLICER | R433_DEBUG_ONE_STRETCH)) ? r.total_pkgs
                 : (b->debug_flags & R433_DEBUG_SMALL_STRETCH)                                            ? std::min<uint32_t>(3u, r.total_pkgs)
                                                                                                          : std::min(r.total_pkgs, fit);
         uint32_t stage_cap = 8192;
-        while (stage_cap >= 512 && (size_t)stretch * b->rows.size() * stage_cap > kStageMax)
+        if (char const *e = getenv("R433_STAGE_CAP")) // development: A/B timing of smaller slots (records over the slot are sliced again by the placing pass)
+            stage_cap = std::max(512, std::min(8192, atoi(e))) & ~511u;
+        while (stage_cap >= 512 && (size_t)stretch * n_devs * stage_cap > kStageMax)
             stage_cap >>= 1;
         if (!(b->debug_flags & R433_DEBUG_TWO_PASS_SLICER)) {
             // (a device with less free memory than that: smaller slots -- a record that outgrows its slot is sliced a second
@@ -719,12 +721,12 @@ int run_slice_and_mirror(RunCtx &r)
             // do not even ask for more than the device has free: ensure() rounds up by a quarter
             size_t mem_free = 0, mem_total = 0;
             // (only when the arena has to grow: the call is a millisecond of driver time with the stream idle)
-            if (b->d_stage.cap < (size_t)stretch * b->rows.size() * stage_cap && hipMemGetInfo(&mem_free, &mem_total) == hipSuccess)
-                while (stage_cap >= 512 && b->d_stage.cap < (size_t)stretch * b->rows.size() * stage_cap
-                        && (size_t)stretch * b->rows.size() * stage_cap / 4 * 5 > mem_free + b->d_stage.cap)
+            if (b->d_stage.cap < (size_t)stretch * n_devs * stage_cap && hipMemGetInfo(&mem_free, &mem_total) == hipSuccess)
+                while (stage_cap >= 512 && b->d_stage.cap < (size_t)stretch * n_devs * stage_cap
+                        && (size_t)stretch * n_devs * stage_cap / 4 * 5 > mem_free + b->d_stage.cap)
                     stage_cap >>= 1;
             for (; stage_cap >= 512; stage_cap >>= 1) {
-                if (b->d_stage.ensure((size_t)stretch * b->rows.size() * stage_cap) == 0) {
+                if (b->d_stage.ensure((size_t)stretch * n_devs * stage_cap) == 0) {
                     lp.stage = b->d_stage.p;
                     lp.stage_cap = stage_cap;
                     break;

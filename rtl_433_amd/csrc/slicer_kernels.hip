@@ -128,7 +128,7 @@ template <int MODE, int CAP = R433_PD_MAX_PULSES> __global__ __launch_bounds__(6
         if (t.orig >= 0) { // not a padding row
             bool const run = t.valid && (t.is_fsk != 0) == (type == R433_PKG_FSK);
             uint8_t *const slot = MODE == M_STAGE || MODE == M_COMPACT
-                    ? p.stage + ((uint64_t)(pkg - p.pkg_begin) * p.n_rows + di) * p.stage_cap : nullptr;
+                    ? p.stage + ((uint64_t)(pkg - p.pkg_begin) * p.n_devs + (uint32_t)t.orig) * p.stage_cap : nullptr; // (a slot per DEVICE: padding rows have none)
             BitSink<STORE> sink;
             uint8_t *out = nullptr;
             uint32_t limit = 0;
@@ -173,7 +173,7 @@ template <int MODE, int CAP = R433_PD_MAX_PULSES> __global__ __launch_bounds__(6
             // per record, 64 in a row.  The rare long record is left to the whole wavefront below.
             constexpr uint32_t kOwn = 512;
             if (copy_bytes > 0 && copy_bytes <= kOwn) {
-                uint8_t const *src_r = p.stage + ((uint64_t)(pkg - p.pkg_begin) * p.n_rows + di) * p.stage_cap;
+                uint8_t const *src_r = p.stage + ((uint64_t)(pkg - p.pkg_begin) * p.n_devs + (uint32_t)t.orig) * p.stage_cap;
                 uint32_t *dst = (uint32_t *)(p.events + copy_base);
                 uint32_t const words = copy_bytes / 4;
                 for (uint32_t w = 0; w < words; w += 16) {
@@ -197,7 +197,8 @@ template <int MODE, int CAP = R433_PD_MAX_PULSES> __global__ __launch_bounds__(6
                 todo &= todo - 1;
                 uint32_t const nb = (uint32_t)__builtin_amdgcn_readlane((int)copy_bytes, r);
                 uint32_t const at = (uint32_t)__builtin_amdgcn_readlane((int)copy_base, r);
-                uint8_t const *src_r = p.stage + ((uint64_t)(pkg - p.pkg_begin) * p.n_rows + chunk * 64 + (uint32_t)r) * p.stage_cap;
+                uint32_t const orig_r = (uint32_t)__builtin_amdgcn_readlane(t.orig, r);
+                uint8_t const *src_r = p.stage + ((uint64_t)(pkg - p.pkg_begin) * p.n_devs + orig_r) * p.stage_cap;
                 uint32_t *const dst = (uint32_t *)(p.events + at);
                 for (uint32_t w0 = 0; w0 < nb; w0 += 4096) { // 4 KB a round: four 16-byte loads per lane in flight, then the stores
                     uint4 v[4];
