@@ -645,7 +645,7 @@ int run_slice_and_mirror(RunCtx &r)
             || (rc = b->d_pkg_bytes.ensure(max_pkgs)) || (rc = b->d_pkg_off.ensure(max_pkgs))
             || (rc = b->d_sizes.ensure((size_t)max_pkgs * std::max<uint32_t>(n_devs, 1)))
             || (rc = b->d_dev_off.ensure((size_t)max_pkgs * std::max<uint32_t>(n_devs, 1)))
-            || (rc = b->d_pkg_order.ensure(max_pkgs)) || (rc = b->d_slice_cursor.ensure(2 * std::max<size_t>(b->rows.size() / 64, 1) + 1)))
+            || (rc = b->d_pkg_order.ensure(max_pkgs)) || (rc = b->d_slice_cursor.ensure(2 * std::max<size_t>(b->rows.size() / 64, 1) + 4)))
         return rc;
 
     launch_directory(b->d_arena.p, b->arena_stride, b->d_state.p, r.split ? b->d_order.p : nullptr, r.n_order, b->d_pkg_base.p,
@@ -684,6 +684,28 @@ int run_slice_and_mirror(RunCtx &r)
             fork = SliceFork{b->slice_stream, b->slice_forked, b->slice_joined};
         }
     }
+    // The sizing pass shares its workgroups out by the work each chunk of devices had in this engine's runs so far (wavefront
+    // clocks, SliceParams::chunk_work -> slice_w, smoothed): with even shares the launch waited for the chunk with
+    // the most work -- the PCM slicers of the default decoders, twice the average -- at a seventh of the chip.
+    double const *shares = nullptr;
+    uint32_t least_share = 8;
+    double skewed[2][16];
+    if (lp.draw && n_devs && r.total_pkgs && !(b->debug_flags & R433_DEBUG_EVEN_SLICE)) {
+        if ((rc = b->d_chunk_work.ensure(2 * 16 * 2 + 1)) || (rc = b->h_chunk_work.ensure(2 * 16 * 2 + 1)) || (rc = b->d_chunk_deal.ensure(2 * 16384)))
+            return rc;
+        lp.chunk_deal = b->d_chunk_deal.p;
+        HIP_TRY(hipMemsetAsync(b->d_chunk_work.p, 0, (2 * 16 * 2 + 1) * sizeof(unsigned long long), r.st));
+        lp.chunk_work = b->d_chunk_work.p;
+        if (b->debug_flags & R433_DEBUG_SKEW_SLICE) { // tests: unequal shares however small the launch
+            for (int l = 0; l < 2; ++l)
+                for (int c = 0; c < 16; ++c)
+                    skewed[l][c] = 1.0 + 5.0 * ((c + l) % 3);
+            shares = &skewed[0][0];
+            least_share = 1;
+        }
+        else if (b->slice_w_valid)
+            shares = &b->slice_w[0][0];
+    }
     bool placed = false; // the event records are in d_events already (large batches: stretch by stretch)
     bool want_index = false; // the slice index of this run is being made
     lp.pkg_begin = 0;
@@ -695,6 +717,9 @@ int run_slice_and_mirror(RunCtx &r)
         HIP_TRY(hipMemsetAsync(b->d_pf_counts.p, 0, (size_t)n_devs * 5 * sizeof(uint32_t), r.st));
     }
     if (n_devs && r.total_pkgs) {
+        // (a chunk of devices only visits the packages of its own kind: what it never visits has no records)
+        if (lp.draw)
+            HIP_TRY(hipMemsetAsync(b->d_sizes.p, 0, (size_t)std::min(r.total_pkgs, max_pkgs) * n_devs * sizeof(uint32_t), r.st));
         // One slicing pass into staging slots when they fit.  A default device set yields ~135 B per
         // (package, device) on average, but the heavy PCM rows fill whole bitbuffers -- 50 rows x (4 + 128) B -- and
         // those are exactly the slow lanes: a record that outgrows its slot is sliced a second time by the placing
@@ -751,7 +776,7 @@ int run_slice_and_mirror(RunCtx &r)
                 for (uint32_t p0 = 0; p0 < r.total_pkgs; p0 += stretch) {
                     lp.pkg_begin = p0;
                     lp.pkg_end = std::min(r.total_pkgs, p0 + stretch);
-                    launch_slice_count(lp, lp.pkg_end - p0, r.st, fork.st2 ? &fork : nullptr);
+                    launch_slice_count(lp, lp.pkg_end - p0, r.st, fork.st2 ? &fork : nullptr, shares, least_share);
                     launch_scan_u32(b->d_pkg_bytes.p, b->d_pkg_off.p, b->d_scal.p, lp.pkg_end, b->d_scal.p + 3, r.st, b->d_scal.p + 3, p0);
                     launch_slice_write(lp, lp.pkg_end - p0, r.st);
                 }
@@ -771,7 +796,7 @@ int run_slice_and_mirror(RunCtx &r)
         }
         else {
             HIP_TRY(hipMemsetAsync(b->d_pkg_bytes.p, 0, (size_t)max_pkgs * sizeof(uint32_t), r.st));
-            launch_slice_count(lp, r.total_pkgs, r.st, fork.st2 ? &fork : nullptr);
+            launch_slice_count(lp, r.total_pkgs, r.st, fork.st2 ? &fork : nullptr, shares, least_share);
             HIP_TRY(hipGetLastError());
             if (b->profiling)
                 HIP_TRY(hipEventRecord(b->ev[3], r.st));
@@ -793,7 +818,27 @@ int run_slice_and_mirror(RunCtx &r)
     if (b->profiling)
         HIP_TRY(hipEventRecord(b->ev[4], r.st));
     HIP_TRY(hipMemcpyAsync(b->h_scal.p, b->d_scal.p, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, r.st));
+    if (lp.chunk_work)
+        HIP_TRY(hipMemcpyAsync(b->h_chunk_work.p, b->d_chunk_work.p, (2 * 16 * 2 + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, r.st));
     HIP_TRY(stream_wait(b, r.st));
+    if (lp.chunk_work && b->h_chunk_work.p[64]) { // what the chunks' work was this time: half of the next run's shares (small launches measure nothing)
+        unsigned long long const began = b->h_chunk_work.p[64];
+        bool any = false;
+        double w[2][16];
+        for (int l = 0; l < 2; ++l)
+            for (int c = 0; c < 16; ++c) {
+                unsigned long long const left = b->h_chunk_work.p[(l * 16 + c) * 2], n = b->h_chunk_work.p[(l * 16 + c) * 2 + 1];
+                // (a wavefront leaves when its chunk's list is dry: n wavefronts busy until the last one left)
+                w[l][c] = left > began ? (double)(left - began) * (double)n : 0.0;
+                any |= w[l][c] > 0;
+            }
+        if (any) {
+            for (int l = 0; l < 2; ++l)
+                for (int c = 0; c < 16; ++c)
+                    b->slice_w[l][c] = b->slice_w_valid ? 0.5 * b->slice_w[l][c] + 0.5 * w[l][c] : w[l][c];
+            b->slice_w_valid = true;
+        }
+    }
     size_t const pkg_bytes = b->h_scal.p[2];
     size_t const evt_bytes = b->h_scal.p[3];
     uint32_t const n_slices = want_index ? b->h_scal.p[4] : 0u;

@@ -277,6 +277,9 @@ void r433_batch_destroy(r433_batch *b)
     b->h_slices.release();
     b->d_pkg_order.release();
     b->d_slice_cursor.release();
+    b->d_chunk_work.release();
+    b->d_chunk_deal.release();
+    b->h_chunk_work.release();
     b->d_pf_tables.release();
     b->d_pf_counts.release();
     b->h_pf_counts.release();

@@ -243,6 +243,12 @@ struct r433_batch {
     uint32_t n_slices = 0;
     bool slices_valid = false;
     DevBuf<uint32_t> d_pkg_order, d_slice_cursor; // the sizing pass of the slicers: packages heaviest first, a cursor per chunk of devices
+    // ... and its workgroups shared out by the work each chunk had in the runs before (SliceParams::chunk_work / chunk_deal)
+    DevBuf<unsigned long long> d_chunk_work;
+    DevBuf<uint8_t> d_chunk_deal;
+    PinBuf<unsigned long long> h_chunk_work;
+    double slice_w[2][16] = {};
+    bool slice_w_valid = false;
     DevBuf<uint8_t> d_pkg_blob, d_events, d_stage, d_converted;
     DevBuf<r433_analysis> d_analysis;
     std::vector<uint32_t> conv_bytes;

@@ -162,8 +162,17 @@ struct SliceParams {
     uint32_t *pf_counts;        // [orig dev][5]: records the filter dropped, by failure code
     // the sizing pass draws its items from a cursor, the heavy packages first (k_slice; launch_slice_count fills both arrays)
     uint32_t draw;              // 0: fixed strides; 1: from one cursor per chunk of devices; 2: large and small packages apart (two launches)
-    uint32_t *pkg_order;        // the packages of this launch by pulse count, descending
-    uint32_t *cursor;           // [2 * n_rows / 64 + 1] next entry of pkg_order per chunk of devices: whole list / large part, small part; the split
+    uint32_t *pkg_order;        // the packages of this launch: OOK then FSK, each by pulse count, descending
+    uint32_t *cursor;           // [2 * n_rows / 64 + 4] next entry of pkg_order per chunk of devices: its kind's list / large part, small part; the four ends (k_pkg_order)
+    // Which chunk a workgroup of a drawn sizing launch serves: chunk_deal[blockIdx] when deal_grid is the launch's grid (k_deal
+    // made it from the shares the host worked out from what the engine's last runs measured, chunk_work), else blockIdx % chunks
+    // as ever.  The PCM chunk of the default decoders has twice the work of the average chunk, and with an equal share of the
+    // workgroups the launch waited for it (batch_run.cpp).
+    uint8_t *chunk_deal;        // [2][16384]: large / small launch
+    uint32_t deal_grid;
+    // [2][16][2] (large / small launch, chunk): when the chunk's last wavefront left (100 MHz wall clock) and how many wavefronts it
+    // had; [64]: when the launches could begin (k_pkg_order) -- next run's shares
+    unsigned long long *chunk_work;
 };
 
 // `order` (may be null = identity) lists the wavefront slots (whole captures or the chosen segments of split
@@ -189,7 +198,8 @@ struct SliceFork {
     hipStream_t st2;
     hipEvent_t forked, joined;
 };
-void launch_slice_count(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st, SliceFork const *fork = nullptr);
+void launch_slice_count(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st, SliceFork const *fork = nullptr, double const *shares = nullptr,
+        uint32_t least = 8);
 void launch_slice_write(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st);
 // the slice index (slicer_kernels.hip): per decoder the (offset, bytes) of its non-empty slices of the event stream, package order.
 // count: cnt[blocks][n_devs] (scratch, then every block's first entry), start[n_devs + 1], *total; fill: after dev_off / pkg_off are final

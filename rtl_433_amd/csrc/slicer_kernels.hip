@@ -13,6 +13,9 @@
 // Replaces run_ook_demods / run_fsk_demods (reference src/r_api.c:438-550) and the ten
 // pulse_slicer_* functions (src/pulse_slicer.c) up to, not including, the decode_fn call, which
 // stays on the host behind the r_device ABI.
+#include <algorithm>
+#include <cstdlib>
+
 #include "r433_internal.hpp"
 #include "slicer_device.hpp"
 
@@ -60,7 +63,14 @@ template <int MODE, int CAP = R433_PD_MAX_PULSES> __global__ __launch_bounds__(6
     uint32_t const lane = threadIdx.x;
     // the grid is a multiple of `chunks` (slice_grid): a workgroup keeps its 64 devices for all its packages, so what the
     // pre-filter drops is counted in registers and leaves with one atomic per lane and code at the end
-    uint32_t const chunk = blockIdx.x % chunks;
+    // (a drawn sizing launch may give the chunks unequal shares of its workgroups: SliceParams::chunk_deal)
+    bool const shared_out = !PLACE && p.draw != 0 && p.chunk_deal != nullptr && p.deal_grid == gridDim.x;
+    uint32_t chunk = blockIdx.x % chunks;
+    if (shared_out) {
+        // (workgroups start in the order of their index: the shares are dealt out like a hand of cards, k_deal, so that every
+        // chunk's workgroups begin at t = 0 -- as contiguous ranges the last chunk began 2 ms late)
+        chunk = min((uint32_t)p.chunk_deal[blockIdx.x], chunks - 1u);
+    }
     uint32_t const di = chunk * 64 + lane;
     int const my_pf = p.devs[di].pf, my_orig = p.devs[di].orig;
     uint8_t const *const pf_tab = (p.pf_tables && my_pf >= 0) ? p.pf_tables + (uint64_t)my_pf * kPfTable : nullptr;
@@ -78,12 +88,15 @@ template <int MODE, int CAP = R433_PD_MAX_PULSES> __global__ __launch_bounds__(6
     // changing devices as it goes -- was slower (3.24 ms; 0.62 ms for 1024): the expensive chunks' long items then begin late.
     bool const drawn = !PLACE && p.draw != 0;
     uint32_t const n_mine = n_pkgs > p.pkg_begin ? n_pkgs - p.pkg_begin : 0u;
-    // two launches share the list (p.draw == 2): the large packages are its first cursor[2 * chunks] entries, drawn through
-    // cursor[chunk]; the small ones follow, drawn through cursor[chunks + chunk] (k_pkg_order sets all three)
+    // a chunk draws the packages of its own kind (k_pkg_order); with two launches sharing the list (p.draw == 2) the large
+    // packages of the kind through cursor[chunk], the small ones through cursor[chunks + chunk]
     bool const two = drawn && p.draw == 2;
-    uint32_t const n_large = two ? min(p.cursor[2 * chunks], n_mine) : n_mine;
+    uint32_t my_end = 0;
+    if (drawn) {
+        uint32_t const kind = p.devs[chunk * 64].is_fsk != 0 ? 2u : 0u;
+        my_end = min(p.cursor[2 * chunks + kind + (two && !SMALL ? 0u : 1u)], n_mine);
+    }
     uint32_t *const my_cursor = p.cursor + (two && SMALL ? chunks : 0u) + chunk;
-    uint32_t const my_end = two && !SMALL ? n_large : n_mine;
     for (uint32_t it = blockIdx.x / chunks;; it += gridDim.x / chunks) {
         uint32_t pkg;
         if (drawn) {
@@ -225,6 +238,16 @@ template <int MODE, int CAP = R433_PD_MAX_PULSES> __global__ __launch_bounds__(6
                 atomicAdd(&p.pkg_bytes[pkg], tot);
         }
     }
+    // What the next run's shares are made of: when the chunk's last wavefront left (a wavefront leaves when its chunk's list is
+    // dry) and how many there were.  One clock read on the way out -- a clock read at the START, kept for the end, cost a launch
+    // of 1024 packages half its speed even with the measurement switched off (0.60 -> 1.22 ms, profiles/r04_slice_shares.txt).
+#ifndef R433_EMU
+    if (!PLACE && p.chunk_work && lane == 0 && chunk < 16) {
+        unsigned long long *const w = p.chunk_work + ((SMALL ? 16u : 0u) + chunk) * 2u;
+        atomicMax(w, (unsigned long long)wall_clock64());
+        atomicAdd(w + 1, 1ull);
+    }
+#endif
     if (!PLACE && pf_tab && p.pf_counts) {
         uint32_t *const c = p.pf_counts + (uint32_t)my_orig * 5u;
         if (dropped0) atomicAdd(c + 0, dropped0);
@@ -235,43 +258,64 @@ template <int MODE, int CAP = R433_PD_MAX_PULSES> __global__ __launch_bounds__(6
     }
 }
 
-// The packages [pkg_begin, n) by pulse count, descending: a counting sort in one workgroup (a launch has a few thousand
-// packages; pulse counts go up to 1200, five to a bucket).  Also rewinds the cursors of the sizing pass that follows.
+// The packages [pkg_begin, n) by kind and pulse count: the OOK packages first, then the FSK ones, each kind heaviest first -- a
+// counting sort in one workgroup (a launch has a few thousand packages; pulse counts go up to 1200, five to a bucket).  A chunk
+// of devices only ever draws the packages of its own kind (a line code is an OOK or an FSK one, src/r_api.c:438-550): an OOK
+// package under an FSK slicer is no work, but as an item it still cost a draw, four dependent loads and two barriers -- 38 us of
+// a wavefront's life, 8948 times per chunk (five of the thirteen chunks of the default decoders never had anything else to do:
+// profiles/r04_slice_shares.txt).  Also rewinds the cursors of the sizing pass that follows:
+//   cursor[chunk]            the chunk's next entry of its kind's list (one launch), or of its large part (two launches)
+//   cursor[chunks + chunk]   ... of its small part
+//   cursor[2 * chunks + k]   k = 0..3: the ends of OOK large / OOK / FSK large / FSK (= everything) in `order`
 __global__ __launch_bounds__(256) void k_pkg_order(uint8_t const *arena, uint32_t arena_stride, uint32_t const *dir_stream,
         uint32_t const *dir_off, uint32_t const *n_pkgs_ptr, uint32_t max_pkgs, uint32_t pkg_begin, uint32_t pkg_end,
-        uint32_t *order, uint32_t *cursor, uint32_t chunks)
+        uint32_t *order, uint32_t *cursor, uint32_t chunks, DevRow const *devs, uint32_t by_kind, unsigned long long *work_start)
 {
-    __shared__ uint32_t count[256], first[256];
+    __shared__ uint32_t count[512], first[512];
+    __shared__ uint32_t bound[4];
     uint32_t const n_pkgs = min(min(*n_pkgs_ptr, max_pkgs), pkg_end);
-    auto weight = [&](uint32_t pkg) -> uint32_t {
-        uint32_t const num = ((uint32_t const *)(arena + (uint64_t)dir_stream[pkg] * arena_stride + dir_off[pkg]))[3];
-        return min(num / 5u, 255u);
+    auto key = [&](uint32_t pkg) -> uint32_t {
+        uint32_t const *rec = (uint32_t const *)(arena + (uint64_t)dir_stream[pkg] * arena_stride + dir_off[pkg]);
+        return (by_kind && rec[2] == R433_PKG_FSK ? 256u : 0u) + min(rec[3] / 5u, 255u);
     };
-    count[threadIdx.x] = 0;
+    count[threadIdx.x] = count[256 + threadIdx.x] = 0;
     __syncthreads();
     for (uint32_t pkg = pkg_begin + threadIdx.x; pkg < n_pkgs; pkg += 256)
-        atomicAdd(&count[weight(pkg)], 1u);
+        atomicAdd(&count[key(pkg)], 1u);
     __syncthreads();
-    __shared__ uint32_t n_large;
     if (threadIdx.x == 0) {
         uint32_t run = 0;
-        for (int w = 255; w >= 0; --w) {
-            first[w] = run;
-            run += count[w];
-            if (w == (int)kSmallW)
-                n_large = run; // the packages of kSmallPulses pulses and more come first
+        for (int kind = 0; kind < 2; ++kind) {
+            for (int w = 255; w >= 0; --w) {
+                first[kind * 256 + w] = run;
+                run += count[kind * 256 + w];
+                if (w == (int)kSmallW)
+                    bound[2 * kind] = run; // the packages of kSmallPulses pulses and more come first
+            }
+            bound[2 * kind + 1] = run;
         }
     }
     __syncthreads();
-    // the cursors: [chunk] over the whole list (or its large part), [chunks + chunk] over the small part, [2 * chunks] the split
-    for (uint32_t c = threadIdx.x; c < chunks; c += 256) {
-        cursor[c] = 0;
-        cursor[chunks + c] = n_large;
+    if (!by_kind) { // one list for every chunk (small launches, see launch_slice_count): both kinds end where the list ends
+        if (threadIdx.x == 0) {
+            bound[2] = bound[0];
+            bound[3] = bound[1];
+        }
+        __syncthreads();
     }
-    if (threadIdx.x == 0)
-        cursor[2 * chunks] = n_large;
+    for (uint32_t c = threadIdx.x; c < chunks; c += 256) {
+        bool const fsk = by_kind && devs[c * 64].is_fsk != 0; // (a chunk is one line code; padding rows follow the real ones)
+        cursor[c] = fsk ? bound[1] : 0u;
+        cursor[chunks + c] = fsk ? bound[2] : bound[0];
+    }
+    if (threadIdx.x < 4)
+        cursor[2 * chunks + threadIdx.x] = bound[threadIdx.x];
+#ifndef R433_EMU
+    if (threadIdx.x == 0 && work_start)
+        *work_start = (unsigned long long)wall_clock64(); // (the sizing launches begin when this kernel ends)
+#endif
     for (uint32_t pkg = pkg_begin + threadIdx.x; pkg < n_pkgs; pkg += 256)
-        order[atomicAdd(&first[weight(pkg)], 1u)] = pkg;
+        order[atomicAdd(&first[key(pkg)], 1u)] = pkg;
 }
 
 // Where each device's records of a package begin inside the package's stretch of the event stream: the exclusive prefix
@@ -420,7 +464,7 @@ __global__ __launch_bounds__(64) void k_index_fill(uint32_t const *sizes, uint32
     }
 }
 
-uint32_t slice_grid(uint32_t grid_pkgs, uint32_t n_rows)
+uint32_t slice_grid(uint32_t grid_pkgs, uint32_t n_rows, uint32_t cap = 16384)
 {
     uint32_t const chunks = n_rows / 64 ? n_rows / 64 : 1;
     uint64_t items = (uint64_t)grid_pkgs * chunks;
@@ -428,32 +472,138 @@ uint32_t slice_grid(uint32_t grid_pkgs, uint32_t n_rows)
         items = chunks;
     // 256 CUs x 8 wavefront slots per SIMD pair is plenty; the kernel strides over the packages beyond this.  Always a
     // multiple of `chunks`: a workgroup serves one chunk of devices.
-    return (uint32_t)(items < 16384 ? items : 16384 / chunks * chunks);
+    return (uint32_t)(items < cap ? items : cap / chunks * chunks);
+}
+
+// The sizing launches DRAW their items: their workgroups should all be resident from the first moment and stay until the lists
+// are dry -- one round.  The kernel fits six wavefronts to a SIMD (79 registers): 24 workgroups per CU.  With 16 384 workgroups
+// for 6144 places the second round began when the first had drained its lists, paid its prologue for nothing and, worse, took
+// its places from workgroups that had work: 8192 bench packages with the pre-filter on, sizing pass 2.69 ms at 16 384
+// workgroups, 2.46 at 12 288, 2.04 at 8192, 1.66 at 6144, 1.77 at 4096 (profiles/r04_slice_shares.txt).
+uint32_t sizing_grid_cap()
+{
+    static uint32_t cap = 0;
+    if (!cap) {
+        if (char const *e = getenv("R433_SLICE_GRID")) // development: A/B timing
+            cap = (uint32_t)std::max(256, std::min(16384, atoi(e)));
+        else {
+            int cus = 256;
+#ifndef R433_EMU
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+                cus = 256;
+#endif
+            cap = (uint32_t)std::min(16384, cus * 24);
+        }
+    }
+    return cap;
 }
 
 } // namespace
 
-// (grid_pkgs: the packages of THIS launch, p.pkg_end - p.pkg_begin or fewer)
-void launch_slice_count(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st, SliceFork const *fork)
+// The shares of a launch, interleaved: chunk c's k-th workgroup wants to sit at (k + 1/2) / n_c of the way through the grid; the
+// workgroups in the order of these places (ties: the lower chunk first) are the deal.  Every thread ranks one (chunk, k) pair by
+// counting, chunk by chunk, the pairs in front of it.
+struct DealShares {
+    uint32_t first[17];
+};
+__global__ __launch_bounds__(256) void k_deal(DealShares s, uint32_t chunks, uint32_t grid, uint8_t *deal)
 {
+    uint32_t const j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= grid)
+        return;
+    uint32_t c = 0;
+    while (c + 1 < chunks && j >= s.first[c + 1])
+        ++c;
+    uint64_t const k = j - s.first[c], nc = s.first[c + 1] - s.first[c];
+    uint64_t rank = 0;
+    for (uint32_t c2 = 0; c2 < chunks; ++c2) {
+        uint64_t const n2 = s.first[c2 + 1] - s.first[c2];
+        if (c2 == c) {
+            rank += k;
+            continue;
+        }
+        // pairs (c2, k2) with (2 k2 + 1) / n2 before (2 k + 1) / nc: (2 k2 + 1) nc < (2 k + 1) n2, or <= for a lower chunk
+        uint64_t const a = (2 * k + 1) * n2, b2 = 2 * nc;
+        uint64_t const cnt = c2 < c ? (a >= nc ? (a - nc) / b2 + 1 : 0) : (a > nc ? (a + nc - 1) / b2 : 0);
+        rank += cnt < n2 ? cnt : n2;
+    }
+    deal[rank] = (uint8_t)c;
+}
+
+// Workgroups per chunk of devices in proportion to the work `w` measured for the chunks (at least `least` each); zeros = even.
+static void share_out(uint32_t *first, uint32_t chunks, uint32_t grid, double const *w, uint32_t least)
+{
+    for (int c = 0; c < 17; ++c)
+        first[c] = 0;
+    // (at least a quarter of an even share, whatever was measured: the next batch may be of another kind -- FSK packages after
+    // runs of OOK ones -- and a chunk left with eight workgroups would then take a hundred milliseconds to say so)
+    least = std::max(least, least > 1 ? grid / (4 * chunks) : 1u);
+    if (!w || chunks < 2 || chunks > 16 || grid < 2 * least * chunks)
+        return;
+    double sum = 0;
+    for (uint32_t c = 0; c < chunks; ++c)
+        sum += w[c] > 0 ? w[c] : 0;
+    if (!(sum > 0))
+        return;
+    uint32_t n[16], total = 0, heaviest = 0;
+    double const spare = (double)(grid - least * chunks);
+    for (uint32_t c = 0; c < chunks; ++c) {
+        n[c] = least + (uint32_t)(spare * (w[c] > 0 ? w[c] : 0) / sum);
+        total += n[c];
+        if (w[c] > w[heaviest])
+            heaviest = c;
+    }
+    n[heaviest] += grid - total; // (rounding down left a few over)
+    for (uint32_t c = 0; c < chunks; ++c)
+        first[c + 1] = first[c] + n[c];
+}
+
+// (grid_pkgs: the packages of THIS launch, p.pkg_end - p.pkg_begin or fewer; shares: [2][16] work per chunk of devices as the
+// engine's last run measured it for the large / small launch, or null)
+void launch_slice_count(SliceParams const &p_in, uint32_t grid_pkgs, hipStream_t st, SliceFork const *fork, double const *shares, uint32_t least)
+{
+    // Lists per kind, shares by measured work and one resident round are for the large batches.  A launch of a thousand
+    // packages lasts as long as its longest items: a workgroup per item, and every chunk walking the one list -- the chunks of the
+    // other kind pass over it doing nothing, and that they hold their places meanwhile is what the busy ones want (1024 packages:
+    // 0.59 ms so, 1.25 ms with the places all taken by slicing wavefronts; profiles/r04_slice_shares.txt).
+    bool const big = grid_pkgs >= 4096 || least == 1; // (least == 1: R433_DEBUG_SKEW_SLICE, the tests' small launches through the large form)
+    SliceParams p = p_in;
+    if (!big) {
+        shares = nullptr;
+        p.chunk_work = nullptr;
+    }
+    uint32_t const chunks = p.n_rows / 64 ? p.n_rows / 64 : 1u;
     if (p.draw)
         hipLaunchKernelGGL(k_pkg_order, dim3(1), dim3(256), 0, st, p.arena, p.arena_stride, p.dir_stream, p.dir_off, p.n_pkgs, p.max_pkgs,
-                p.pkg_begin, p.pkg_end, p.pkg_order, p.cursor, p.n_rows / 64 ? p.n_rows / 64 : 1u);
-    dim3 const grid(slice_grid(grid_pkgs, p.n_rows));
+                p.pkg_begin, p.pkg_end, p.pkg_order, p.cursor, chunks, p.devs, big ? 1u : 0u, p.chunk_work ? p.chunk_work + 64 : nullptr);
+    dim3 const grid(slice_grid(grid_pkgs, p.n_rows, p.draw && grid_pkgs >= 4096 ? sizing_grid_cap() : 16384u));
     if (p.draw == 2) {
-        // the small packages on the second stream beside the large ones (both wait for the order, the caller's stream for both)
+        // the small packages on the second stream beside the large ones (both wait for the order and for the deals, which are
+        // made on the caller's stream BEFORE the fork: the second stream must not start on a table that is still being dealt)
+        SliceParams large = p, small = p;
+        small.chunk_deal = p.chunk_deal ? p.chunk_deal + 16384 : nullptr;
+        int which = 0;
+        for (SliceParams *q : {&large, &small}) {
+            DealShares d;
+            share_out(d.first, chunks, grid.x, p.chunk_deal && shares ? shares + 16 * which : nullptr, least);
+            ++which;
+            q->deal_grid = d.first[chunks] == grid.x ? grid.x : 0u;
+            if (q->deal_grid)
+                hipLaunchKernelGGL(k_deal, dim3((grid.x + 255) / 256), dim3(256), 0, st, d, chunks, grid.x, q->chunk_deal);
+        }
         hipStream_t const st2 = fork ? fork->st2 : st;
         if (fork) {
             (void)hipEventRecord(fork->forked, st);
             (void)hipStreamWaitEvent(st2, fork->forked, 0);
         }
         if (p.stage) {
-            hipLaunchKernelGGL((k_slice<M_STAGE, R433_PD_MAX_PULSES>), grid, dim3(64), 0, st, p);
-            hipLaunchKernelGGL((k_slice<M_STAGE, (int)kSmallPulses>), grid, dim3(64), 0, st2, p);
+            hipLaunchKernelGGL((k_slice<M_STAGE, R433_PD_MAX_PULSES>), grid, dim3(64), 0, st, large);
+            hipLaunchKernelGGL((k_slice<M_STAGE, (int)kSmallPulses>), grid, dim3(64), 0, st2, small);
         }
         else {
-            hipLaunchKernelGGL((k_slice<M_COUNT, R433_PD_MAX_PULSES>), grid, dim3(64), 0, st, p);
-            hipLaunchKernelGGL((k_slice<M_COUNT, (int)kSmallPulses>), grid, dim3(64), 0, st2, p);
+            hipLaunchKernelGGL((k_slice<M_COUNT, R433_PD_MAX_PULSES>), grid, dim3(64), 0, st, large);
+            hipLaunchKernelGGL((k_slice<M_COUNT, (int)kSmallPulses>), grid, dim3(64), 0, st2, small);
         }
         if (fork) {
             (void)hipEventRecord(fork->joined, st2);
@@ -461,10 +611,16 @@ void launch_slice_count(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st
         }
         return;
     }
+    SliceParams one = p;
+    DealShares d;
+    share_out(d.first, chunks, grid.x, p.draw && p.chunk_deal ? shares : nullptr, least);
+    one.deal_grid = d.first[chunks] == grid.x ? grid.x : 0u;
+    if (one.deal_grid)
+        hipLaunchKernelGGL(k_deal, dim3((grid.x + 255) / 256), dim3(256), 0, st, d, chunks, grid.x, one.chunk_deal);
     if (p.stage)
-        hipLaunchKernelGGL(k_slice<M_STAGE>, grid, dim3(64), 0, st, p);
+        hipLaunchKernelGGL(k_slice<M_STAGE>, grid, dim3(64), 0, st, one);
     else
-        hipLaunchKernelGGL(k_slice<M_COUNT>, grid, dim3(64), 0, st, p);
+        hipLaunchKernelGGL(k_slice<M_COUNT>, grid, dim3(64), 0, st, one);
 }
 
 void launch_scan_u32(uint32_t const *in, uint32_t *out, uint32_t const *n_ptr, uint32_t n_cap, uint32_t *total,

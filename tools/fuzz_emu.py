@@ -151,6 +151,8 @@ def one_case(seed, run=None):
         form |= 65536  # R433_DEBUG_STATIC_SLICE: slicer workgroups at fixed strides instead of drawing from the cursors
     if seed % 11 == 5:
         form |= 262144  # R433_DEBUG_NO_LAZY: every tile filtered
+    if seed % 9 == 4:
+        form |= 1048576  # R433_DEBUG_SKEW_SLICE: the chunks of devices get unequal shares of the sizing pass's workgroups
     if seed % 13 == 6:
         form |= 131072  # R433_DEBUG_ONE_SLICE_LAUNCH: the slicers' sizing pass as one launch instead of large / small packages apart
     # One case in three with the sample taps; without them the detection kernel leaves tiles that cannot move the detector
