@@ -44,6 +44,17 @@ def build(force=False):
     if not force and not _stale():
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
+    # one builder at a time: the two ranks of a gloo test that both find the library stale would otherwise write the same
+    # object files and link half of each other's
+    import fcntl
+    with open(os.path.join(OUT_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale():  # (the other one built it while this one waited)
+            return OUT
+        return _build_locked()
+
+
+def _build_locked():
     procs, objs = [], []
     for src in sources():
         obj = os.path.join(OUT_DIR, os.path.basename(src) + ".o")
