@@ -291,3 +291,16 @@ def test_heaviest_captures_first(default_devices):
         assert g["packages"][0] == pk and g["events"][0] == ev, flags
     plain = host.emu_run(caps, 2, 250000, devs, taps=True)
     assert all(np.array_equal(a, b) for a, b in zip(g["taps"], plain["taps"]))
+
+
+@pytest.mark.parametrize("debug", [0, 1048576])  # R433_DEBUG_SKEW_SLICE
+def test_more_than_sixteen_chunks_of_devices(debug, default_devices):
+    """1125 decoders -- the default 335 three times over and 120 more: 13 line codes, more than the sixteen chunks of 64 the
+    sizing pass keeps shares and measurements for; OOK and FSK captures; records == the oracle's."""
+    from tests.emu import host
+    devs = default_devices[0]
+    many = np.concatenate([devs, devs, devs, devs[:120]])
+    iqs = [synth.ook_stream(4000 + k, 24000)[0] for k in range(3)] + [synth.fsk_stream_cu8(4010, 20000)]
+    g = host.emu_run(iqs, 2, 250000, many, debug=debug)
+    pk, ev, base = _oracle_batch(iqs, many, po.default_flow_cfg(2, 250000, fpdm=0))
+    assert base >= 4 and g["packages"][1] == base and g["packages"][0] == pk and g["events"][0] == ev
