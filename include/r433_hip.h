@@ -231,7 +231,8 @@ typedef struct r433_dispatch_hooks {
      * in the output_fn call committed later, in reference order, on the calling thread.  For hosts whose output handler is a
      * pure rendering of the data followed by an ordered append (dropin/plugins_shim.c: the JSON line of data_print_jsons):
      * the rendering -- 0.7 us per event, a sixth of a replay when it all ran on the committing thread -- then runs beside
-     * the other decoders.  Must be thread-safe; owns the data_t from then on.  Log messages (log_fn) are not rendered. */
+     * the other decoders.  Must be thread-safe; owns the data_t from then on; what it returns (never NULL) is handed to
+     * output_fn as is.  Log messages (log_fn) are not rendered. */
     void *(*output_render)(void *user, r433_r_device *device, void *data);
 } r433_dispatch_hooks;
 int r433_batch_dispatch_hooks(r433_batch *b, r433_r_device *const *devices, uint32_t n_devices,
