@@ -317,6 +317,7 @@ def _RDevice():
 
 EXCLUSIVE = 2    # --exclusive: 1 the engines take turns on the detection kernel, 2 on the slicer kernels as well, 0 no turns
 DEBUG_FLAGS = 0  # --debug: R433_DEBUG_* for every engine (development, A/B timing)
+NAP_WAIT = 2097152  # R433_DEBUG_NAP_WAIT (include/r433_hip.h)
 
 
 class Pipeline:
@@ -993,7 +994,15 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctxd = dict(rank=rank, world=world, local_rank=local_rank, dist=dist)
+    # Waiting for the GPU spins on this stack (tools/spin_probe.py), and a rank keeps two GPU legs in flight: ranks that share a
+    # small CPU quota -- eight on the 16 CPUs these boxes grant -- would burn it on waiting while their decoders starve.  With
+    # fewer than six CPUs to a rank the engines poll with naps instead (R433_DEBUG_NAP_WAIT; on one GPU with CPUs to spare the
+    # spinning wait is the faster one: profiles/r04_wait_asleep_ab.txt).
+    if world > 1 and cpu_quota() / world < 6:
+        DEBUG_FLAGS |= NAP_WAIT
     result = run_batched(args, ctxd) if args.config in (2, 4) else run_stream(args, ctxd)
+    if rank == 0 and isinstance(result, dict) and isinstance(result.get("config"), dict):
+        result["config"]["gpu_waits"] = "polled with naps (ranks share a small CPU quota)" if DEBUG_FLAGS & NAP_WAIT else "hipEventSynchronize (spins)"
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist:

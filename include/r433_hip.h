@@ -183,6 +183,7 @@ int r433_batch_debug_state(r433_batch *b, void *host_buf, size_t bytes);
 #define R433_DEBUG_ONE_WAVE 4096u /* one wavefront per capture instead of a producer / consumer pair: same results, for A/B timing */
 #define R433_DEBUG_ONE_SLICE_LAUNCH 131072u /* the slicers' sizing pass as one launch (9.6 KB of LDS per workgroup) instead of large and small packages apart (A/B timing) */
 #define R433_DEBUG_STATIC_SLICE 65536u /* slicer workgroups take their packages at fixed strides instead of heaviest first from a shared cursor (A/B timing) */
+#define R433_DEBUG_NAP_WAIT 2097152u /* wait for the GPU by polling with naps instead of the runtime's spinning hipEventSynchronize: for hosts with fewer CPUs than waiting threads (bench.py sets it for the ranks of a node that share a small CPU quota) */
 #define R433_DEBUG_EVEN_SLICE 524288u /* the slicers' sizing pass gives every chunk of devices the same number of workgroups instead of shares by measured work (A/B timing) */
 #define R433_DEBUG_SKEW_SLICE 1048576u /* ... and shares by a made-up skew, however small the launch (tests) */
 #define R433_DEBUG_NO_LAZY 262144u /* the detection kernel filters every tile, also those that provably cannot move the detector: same results, for A/B timing */

@@ -306,6 +306,13 @@ struct r433_batch {
 constexpr unsigned kTurnDevices = 64;
 extern std::mutex g_detect_turn[kTurnDevices]; // engines with exclusive_detect take turns on the detection kernel of their GPU (batch_run.cpp)
 
+// Waiting for the stream.  hipEventSynchronize spins on this stack even for an event made with hipEventBlockingSync
+// (tools/spin_probe.py on the MI355X box: 10.0 ms of CPU per 9.8 ms of waiting, blocking or not).  With a CPU to spare per GPU
+// leg that is the fastest wait there is, and the default.  A host that has fewer CPUs than waiting threads -- eight ranks of a
+// node on a 16-CPU quota: sixteen legs in flight -- asks for R433_DEBUG_NAP_WAIT: the event is polled, a short while eagerly
+// (the small waits between two kernels of a pass end within microseconds), then asleep in between (a twentieth of what has been
+// waited so far, 20-200 us: a 4 ms kernel is noticed at most 0.2 ms late).  Measured on one GPU with CPUs to spare: a GPU leg's
+// CPU time 12.5 -> 2.5 ms per step, the leg 0.5 ms longer, nothing faster (profiles/r04_wait_asleep_ab.txt).
 inline hipError_t stream_wait(r433_batch *b, hipStream_t st)
 {
     if (!b->sync_ev) {
@@ -314,7 +321,24 @@ inline hipError_t stream_wait(r433_batch *b, hipStream_t st)
             return e;
     }
     hipError_t e = hipEventRecord(b->sync_ev, st);
-    return e != hipSuccess ? e : hipEventSynchronize(b->sync_ev);
+    if (e != hipSuccess)
+        return e;
+    if (!(b->debug_flags & R433_DEBUG_NAP_WAIT))
+        return hipEventSynchronize(b->sync_ev);
+    auto const t0 = std::chrono::steady_clock::now();
+    for (unsigned polls = 0;; ++polls) {
+        e = hipEventQuery(b->sync_ev);
+        if (e != hipErrorNotReady)
+            return e;
+        if (polls < 16)
+            continue;
+        auto const waited = std::chrono::steady_clock::now() - t0;
+        if (waited < std::chrono::microseconds(30))
+            continue;
+        auto nap = std::chrono::duration_cast<std::chrono::microseconds>(waited) / 20;
+        nap = std::max(std::chrono::microseconds(20), std::min(std::chrono::microseconds(200), nap));
+        std::this_thread::sleep_for(nap);
+    }
 }
 
 #endif // R433_HOST_COMMON_HPP_

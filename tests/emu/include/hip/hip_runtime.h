@@ -226,7 +226,7 @@ typedef int hipError_t;
 typedef void *hipStream_t;
 struct EmuEvent { double t; };
 typedef EmuEvent *hipEvent_t;
-enum { hipSuccess = 0, hipErrorNoDevice = 100, hipErrorInvalidDevice = 101, hipErrorOutOfMemory = 2 };
+enum { hipSuccess = 0, hipErrorNoDevice = 100, hipErrorInvalidDevice = 101, hipErrorOutOfMemory = 2, hipErrorNotReady = 600 };
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum { hipHostMallocDefault = 0 };
 
@@ -257,6 +257,7 @@ hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t st);
 hipError_t hipStreamWaitEvent(hipStream_t st, hipEvent_t e, unsigned flags);
 hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventQuery(hipEvent_t e); /* (launches are synchronous here: always complete) */
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b);
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...)                                                      \

@@ -72,7 +72,7 @@ def test_case_vs_golden_and_oracle(name, default_devices):
     assert np.array_equal(env[0, :n], o["env"])
 
 
-@pytest.mark.parametrize("form", ["pair", "one_wave", "stretches", "strides", "strides_stretches", "skewed_shares", "skewed_one_launch"])
+@pytest.mark.parametrize("form", ["pair", "one_wave", "stretches", "strides", "strides_stretches", "skewed_shares", "skewed_one_launch", "nap_wait"])
 def test_ragged_batch_vs_oracle(form, default_devices):
     """Many captures of different lengths in one launch; every capture must match the oracle run alone.  Both forms of the
     detection kernel: producer / consumer wavefront pairs (launches of up to 1280 captures) and single wavefronts (larger ones)."""
@@ -91,7 +91,7 @@ def test_ragged_batch_vs_oracle(form, default_devices):
             a = synth.ook_stream(1000 + s, max(n, 1))[0][: 2 * n]
         iqs.append(a)
     g = _gpu_run(iqs, 2, 250000, 433920000, devs, debug={"one_wave": 4096, "pair": 32768, "stretches": 8, "strides": 65536, "strides_stretches": 65536 | 8,
-                                                       "skewed_shares": 1048576, "skewed_one_launch": 1048576 | 131072}[form])  # R433_DEBUG_ONE_WAVE / _PAIR / _SMALL_STRETCH / _STATIC_SLICE / _SKEW_SLICE / _ONE_SLICE_LAUNCH
+                                                       "skewed_shares": 1048576, "skewed_one_launch": 1048576 | 131072, "nap_wait": 2097152}[form])  # R433_DEBUG_ONE_WAVE / _PAIR / _SMALL_STRETCH / _STATIC_SLICE / _SKEW_SLICE / _ONE_SLICE_LAUNCH / _NAP_WAIT
     cfg = po.default_flow_cfg(2, 250000, fpdm=0)
     pk_all, ev_all, base = b"", b"", 0
     for s, a in enumerate(iqs):
