@@ -1,7 +1,11 @@
 """bench.py -- IQ Msamples/s end-to-end (cu8 -> decoder callbacks) on N MI355X.
 
-    python bench.py [--gpus 1] [--steps 200] [--warmup 10] [--config 2|3|4|5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` is honoured either way: started by torchrun the process checks WORLD_SIZE == N and stops otherwise; started
+plainly with N > 1 it re-executes itself under torch.distributed.run with N ranks on 127.0.0.1.  `n_gpus` in the line is the
+number of ranks the process group really has (RCCL, one distinct GPU each: checked).
 
 Workloads (BASELINE.json `configs`, recipes in SURVEY.md 8d):
 
@@ -63,6 +67,65 @@ def _issue_note():
 
 
 ISSUE_NOTE = _issue_note()
+
+
+class Backend:
+    """Where the engines run.  "hip" (the only form that measures anything): librtl433hip.so on cuda:<local_rank>, ranks over
+    RCCL ("nccl").  "emu": TEST ONLY (tests/test_bench_launch.py) -- the same kernel sources on the CPU wave emulator of the
+    test suite, ranks over gloo, so that the launcher, the sharding and the gather of THIS file run where there is no GPU; its
+    line says so in `backend` and its numbers mean nothing."""
+
+    def __init__(self, name):
+        import contextlib
+        import torch
+        self.name, self.torch, self.null = name, torch, contextlib.nullcontext()
+        self.emu = name == "emu"
+        if self.emu:
+            from tests.emu import host
+            self.library = host.emu_lib()
+        else:
+            self.library = None  # BatchEngine -> _lib.lib(): raises when librtl433hip.so is missing
+            self.hip = C.CDLL("libamdhip64.so")
+
+    def device(self, local_rank):
+        return self.torch.device("cpu") if self.emu else self.torch.device("cuda", local_rank)
+
+    def set_device(self, local_rank):
+        if not self.emu:
+            self.torch.cuda.set_device(local_rank)
+
+    def sync(self):
+        if not self.emu:
+            self.torch.cuda.synchronize()
+
+    def resident(self, host_array):
+        t = self.torch.from_numpy(host_array)
+        return t if self.emu else t.cuda()
+
+    def pinned(self, host_array):
+        t = self.torch.from_numpy(host_array)
+        return t if self.emu else t.pin_memory()
+
+    def stream(self):
+        """A HIP stream made by hipStreamCreateWithFlags(hipStreamNonBlocking), handed to torch as an ExternalStream.  NOT a
+        stream of torch's pool: a host -> device copy on a pool stream (hipStreamCreateWithPriority) serialises with every
+        device -> host copy in flight -- 1 GiB in + 200 MiB back take 22.3 ms at once on pool streams, 18.7 ms (= the input
+        alone: the link is full duplex) on plain ones (tools/pcie_probe.py, profiles/r05_pcie_duplex.txt)."""
+        if self.emu:
+            return None
+        st = C.c_void_p()
+        if self.hip.hipStreamCreateWithFlags(C.byref(st), 1) != 0:
+            raise RuntimeError("hipStreamCreateWithFlags failed")
+        return self.torch.cuda.ExternalStream(st.value)
+
+    def on(self, st):
+        return self.null if st is None else self.torch.cuda.stream(st)
+
+    def handle(self, st):
+        return 0 if st is None else st.cuda_stream
+
+
+BK = None  # set by main()
 METRIC = "IQ Msamples/sec end-to-end (cu8 -> decoded events)"
 
 
@@ -83,15 +146,20 @@ def pmc_traffic(key, alg_bytes, det_s):
 
 # ---------------------------------------------------------------- synthetic input
 
+CAPTURE_SAMPLES = 65536  # samples per config-2 / config-4 capture (--capture-samples: the emulator test shortens it)
+
+
 def _synth_one(seed):
     """Capture `seed` of the config-2 workload: the SURVEY 8d recipe (one OOK burst, family PWM / PPM / Manchester, random
     payload) -- and for every third seed a transmission of a REAL protocol with a frame its decoder accepts
     (rtl_433_amd/protocols.py: twelve protocols fit a 65536-sample capture), so that the decoders behind the path have
     something to say."""
+    from rtl_433_amd import synth
+    if CAPTURE_SAMPLES != 65536:
+        return synth.ook_stream(seed, CAPTURE_SAMPLES)[0]
     if seed % 3 == 2:
         from rtl_433_amd import protocols
         return protocols.bench_capture(seed)[0]
-    from rtl_433_amd import synth
     return synth.ook_stream(seed)[0]
 
 
@@ -185,7 +253,7 @@ def cpu_baseline_config2(host_iq, devs_expected, gpu_digest, gpu_events, reps=3)
     return one, many, parity
 
 
-def cpu_baseline_real_decoders(host_iq, reps=2):
+def cpu_baseline_real_decoders(host_iq, reps=1, what="the inputs of the LAST step of the timed region"):
     """The unmodified reference (oracle/_ref) with its REAL decoders over the batch, one thread; what the decoders report
     comes back as the JSON lines of the reference's own printer (the text the GPU path's replay is compared with)."""
     from oracle import pyoracle as po
@@ -207,7 +275,7 @@ def cpu_baseline_real_decoders(host_iq, reps=2):
         text = ref.take_text()
     ref.close()
     return dict(value=round(n_streams * n_samples / best / 1e6, 2), unit="Msamples/s", cores=1, kind="reference",
-                sample=f"the same {n_streams} x {n_samples}-sample batch (batch 0 of the run), all 335 default decoders with their real decode_fn, "
+                sample=f"{n_streams} x {n_samples}-sample captures ({what}), all 335 default decoders with their real decode_fn, "
                        f"best of {reps}, single thread (the reference has no other)"), text
 
 
@@ -225,13 +293,13 @@ def other_configs_summary(args):
 
 
 def real_decoders_leg(host_iq, d_iq, devs, threads, local_rank, reps=2, pipe_steps=12):
-    """Both sides with the reference's REAL decoders (src/devices/*.c, taken from oracle/_ref/libr433ref.so): the GPU
-    path replays its bitbuffers into their decode_fn, the CPU side is the reference as it is.  Some decoders keep
-    state between calls (e.g. src/devices/secplus_v1.c:142), so the replay is the ordered one: a decoder stays on one
-    thread and sees its calls in reference order, outputs are committed in reference order
-    (r433_batch_dispatch_ordered).  Measured without and with the device-side pre-filter (r433_batch_probe_prefilter:
-    records a decoder provably refuses on num_rows / bits_per_row[0] never leave the GPU; statistics unchanged), one pass
-    at a time and as the three-engine pipeline of the headline."""
+    """One-pass variants of the replay, with the reference's REAL decoders on both sides: the GPU path replays its bitbuffers
+    into the decode_fn of the plugin library's decoders (dropin/_build/libr433plugins.so -- never the checker's), the CPU
+    side is the unmodified reference as it is (oracle/_ref).  Some decoders keep state between calls (e.g.
+    src/devices/secplus_v1.c:142), so the replay is the ordered one: a decoder stays on one thread and sees its calls in
+    reference order, outputs are committed in reference order (r433_batch_dispatch_ordered).  Measured without and with the
+    device-side pre-filter (r433_batch_probe_prefilter: records a decoder provably refuses on num_rows / bits_per_row[0]
+    never leave the GPU; statistics unchanged)."""
     import torch
 
     from oracle import pyoracle as po
@@ -239,10 +307,11 @@ def real_decoders_leg(host_iq, d_iq, devs, threads, local_rank, reps=2, pipe_ste
     if not po.have_ref():
         return None
     n_streams, n_samples = host_iq.shape[0], host_iq.shape[1] // 2
+    plug = real_decoder_plugins()
+    plain = plug.devices
+    objs = [C.cast(p, C.POINTER(_RDevice())).contents for p in plain]
     ref = po.Ref(call_real=True, record=False)
     ref.set_digest_mode(0)
-    plain = ref.plain_devices()
-    objs = [C.cast(p, C.POINTER(_RDevice())).contents for p in plain]
 
     def stats():
         return [(o.decode_events, o.decode_ok, o.decode_messages, tuple(o.decode_fails)) for o in objs]
@@ -252,11 +321,10 @@ def real_decoders_leg(host_iq, d_iq, devs, threads, local_rank, reps=2, pipe_ste
             o.decode_events = o.decode_ok = o.decode_messages = 0
             for k in range(5):
                 o.decode_fails[k] = 0
-    from rtl_433_amd import plugins
     eng = BatchEngine(flow_cfg(2, 250000), devs)
     if DEBUG_FLAGS:
         eng.set_debug(DEBUG_FLAGS)
-    stateless = plugins.stateless_flags(plain)
+    stateless = plug.stateless()  # the plugin library's own statement about its decoders (r433p_stateless)
     best, decoded, d2h, seen = {}, {}, {}, {}
     t0 = time.perf_counter()
     tables = eng.probe_prefilter(plain)
@@ -276,10 +344,11 @@ def real_decoders_leg(host_iq, d_iq, devs, threads, local_rank, reps=2, pipe_ste
         d2h[mode] = ev_bytes + len(eng.packages()[0])
         seen[mode] = stats()
     eng.close()
+    plug.take()
+    plug.close()
     cpu_best, cpu_events = None, 0
     for _ in range(reps):
         ref.clear()
-        zero()
         t0 = time.perf_counter()
         ev = 0
         for s in range(n_streams):
@@ -332,13 +401,13 @@ class Pipeline:
         from rtl_433_amd.engine import BatchEngine
         self.torch = torch
         self.n_eng = n_eng
-        self.engines = [BatchEngine(cfg_fn(), devs, profiling=True) for _ in range(n_eng)]
+        self.engines = [BatchEngine(cfg_fn(), devs, profiling=True, library=BK.library) for _ in range(n_eng)]
         for e in self.engines:  # the kernels of a step run back to back (the engines take turns on the GPU work of a pass); record
             # copies and the host replay of step k overlap the kernels of step k+1
             e.set_exclusive_detect(EXCLUSIVE)
             if DEBUG_FLAGS:
                 e.set_debug(DEBUG_FLAGS)
-        self.streams = [torch.cuda.Stream() for _ in range(n_eng)]
+        self.streams = [BK.stream() for _ in range(n_eng)]
         self.pool = ThreadPoolExecutor(n_eng - 1)
         self.rdev_arr = rdev_arr
         self.threads = threads
@@ -350,13 +419,13 @@ class Pipeline:
         self.replay_s = []  # the library's replay call alone, per host leg
 
     def gpu_leg(self, k, src, lens=None, h2d_from=None, d_buf=None):
-        self.torch.cuda.set_device(self.local_rank)
+        BK.set_device(self.local_rank)
         e, st = self.engines[k % self.n_eng], self.streams[k % self.n_eng]
         if h2d_from is not None:  # host -> HBM over PCIe on the engine's own stream, overlapping the other engines' kernels
-            with self.torch.cuda.stream(st):
+            with BK.on(st):
                 d_buf.copy_(h2d_from, non_blocking=True)
             src = d_buf
-        return e.run(src, lens, stream=st.cuda_stream), e.timing()
+        return e.run(src, lens, stream=BK.handle(st)), e.timing()
 
     def host_leg(self, k, n_pkgs):
         e = self.engines[k % self.n_eng]
@@ -425,48 +494,31 @@ def replay_threads(world):
     return max(1, min(64, (cpu_quota() * 3 // 2) // max(1, world)))
 
 
-class _RefPlugins:
-    """The reference's decoders taken from oracle/_ref/libr433ref.so (the same sources as libr433plugins.so, the same JSON
-    printer) when dropin/_build did not travel: same interface as rtl_433_amd.plugins.Plugins."""
-
-    def __init__(self):
-        from oracle import pyoracle as po
-        self.ref = po.Ref(call_real=True, record=False)
-        self.ref.set_digest_mode(0)
-        self.ref.text_mode(True)
-        self.devices = self.ref.plain_devices()
-        self.source = "oracle/_ref/libr433ref.so (dropin/_build/libr433plugins.so is missing)"
-
-    def take(self):
-        t = self.ref.take_text()
-        return t, t.count(b"\n")
-
-    def close(self):
-        self.ref.close()
-
-
 def real_decoder_plugins():
+    """The reference's decoders as plugins (dropin/_build/libr433plugins.so: built by `make -C dropin plugins` without the
+    reference's DSP units, linked to librtl433seam.so).  No stand-in: the timed path never loads anything under oracle/."""
     from rtl_433_amd import plugins
-    if plugins.available():
-        p = plugins.Plugins()
-        p.source = "dropin/_build/libr433plugins.so"
-        return p
-    return _RefPlugins()
+    if not plugins.available():
+        raise SystemExit(f"bench.py: {plugins.LIB_PATH} is missing (`make -C dropin plugins` where the reference tree is; the file travels "
+                         "to the GPU box with the snapshot) -- the decoders behind the path are part of the job, there is no substitute")
+    p = plugins.Plugins()
+    p.source = "dropin/_build/libr433plugins.so"
+    return p
 
 
 def timed(dist, torch, fn):
     """barrier + synchronize on both sides, MAX over ranks"""
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    BK.sync()
     t0 = time.perf_counter()
     out = fn()
-    torch.cuda.synchronize()
+    BK.sync()
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if BK.emu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed, out
@@ -485,9 +537,9 @@ def run_batched(args, ctxd):
     from rtl_433_amd import _lib, shard
     from rtl_433_amd.engine import digest_plugin_addr, flow_cfg, load_device_table, make_rdevices
     rank, world, local_rank, dist = ctxd["rank"], ctxd["world"], ctxd["local_rank"], ctxd["dist"]
-    dev = torch.device("cuda", local_rank)
+    dev = BK.device(local_rank)
     strong = args.config == 4
-    n_samples = 65536
+    n_samples = CAPTURE_SAMPLES
     threads = args.threads or replay_threads(world)
     procs = max(1, min(32, (os.cpu_count() or 1) // max(1, world)))
     devs, protocols, names = load_device_table()
@@ -496,10 +548,9 @@ def run_batched(args, ctxd):
     # The job is decoded events: the reference's REAL decoders behind the replay (dropin/_build/libr433plugins.so: the
     # reference's sources as plugins, unchanged behind r_device.decode_fn), what they report as JSON lines printed by the
     # reference's own data_print_jsons -- that text is what the ranks gather and what is compared with the reference.
-    from rtl_433_amd import plugins
     plug = real_decoder_plugins()
     assert len(plug.devices) == len(devs), "the plugin library registers another decoder set than the device table"
-    stateless = plugins.stateless_flags(plug.devices)  # what this host knows about its plugins (r433_batch_set_stateless)
+    stateless = plug.stateless()  # what the plugin library says about its own decoders (r433p_stateless -> r433_batch_set_stateless)
 
     if strong:
         total = args.list_len
@@ -524,8 +575,8 @@ def run_batched(args, ctxd):
         n_streams = n_batch * args.batches     # captures a step submits together (one grid)
         n_rot = 3
         host_batches = [ook_batches((rank * n_rot + b) * n_streams, n_streams, procs if n_streams >= 2048 else 1) for b in range(n_rot)]
-        pinned = [torch.from_numpy(h).pin_memory() for h in host_batches]
-        batches = [torch.from_numpy(h).cuda() for h in host_batches]  # the same inputs resident in HBM (`hbm_resident`)
+        pinned = [BK.pinned(h) for h in host_batches]
+        batches = [BK.resident(h) for h in host_batches]  # the same inputs resident in HBM (`hbm_resident`)
         per_step = 1
 
     records = {}
@@ -567,6 +618,7 @@ def run_batched(args, ctxd):
         """The one collective of the path: per-rank records to rank 0 (RCCL over xGMI), variable length."""
         npk, nmsg, dsum, pkh, texts, nbits, nbytes = records.get("acc", [0, 0, 0, 0, [], 0, 0])
         records["sent"] = (nbits, nbytes)
+        records["last_text"] = b"".join(texts)  # what this rank's decoders said in the LAST step of the timed region
         payload = shard.pack_rank_record(first if strong else rank * n_streams, npk, nmsg, nbits, pkh if strong else nbytes, b"".join(texts))
         got = shard.gather_rank_records(payload, dist is not None, dst=0, device=dev, tail="text")
         if rank == 0:
@@ -576,7 +628,7 @@ def run_batched(args, ctxd):
     for k in range(pipe.n_eng):
         pipe.host_leg(k, pipe.gpu_leg(k, **leg_args(k))[0])
     records.pop("acc", None)
-    solo = [pipe.gpu_leg(0, **leg_args_resident(i))[1] for i in range(5)]  # the kernel alone on the device, HIP events on its stream
+    solo = [pipe.gpu_leg(0, **leg_args_resident(i))[1] for i in range(1 if BK.emu else 5)]  # the kernel alone on the device, HIP events on its stream
     solo_det_ms = float(np.mean([t["detect_ms"] for t in solo]))
     solo_tot_ms = float(np.mean([t["total_ms"] for t in solo]))
     pipe.stagger = solo_tot_ms / 1e3 / (pipe.n_eng - 1)
@@ -651,7 +703,7 @@ def run_batched(args, ctxd):
     pipe_for_extra = pipe
 
     # ---- secondary measurements of the same run (rank 0, N = 1, the default workload only) ----
-    if not strong:
+    if not strong and not BK.emu:
         # the same pipeline with the inputs already resident in HBM (every rank runs it: the ranks share the host)
         k_res = max(3, min(args.steps, 20))
         pipe.run(2, leg_args_resident)
@@ -660,17 +712,35 @@ def run_batched(args, ctxd):
             result["hbm_resident"] = {"value": round(world * n_streams * n_samples * k_res / el / 1e6, 2), "unit": "Msamples/s", "steps": k_res,
                                       "ms_per_step": round(el / k_res * 1e3, 3), "k_wave_ms": round(float(np.mean(det_res)), 3),
                                       "note": "the same pipeline without the H2D copy (inputs resident in HBM when the timed region starts)"}
-    if rank == 0 and world == 1 and not strong and not args.quick:
-        # Parity on one batch (the bounded sample the CPU legs run), two ways: (1) the decoded events -- the JSON lines of the
-        # real decoders behind the GPU path against those of the unmodified reference over the same captures; (2) every
-        # bitbuffer -- a checksum decode_fn on both sides (pre-filter off: the checksum wants every record).
+    if not strong and not args.quick and not args.no_cpu_baseline:
+        # Parity of the timed region's own output, on every rank: the JSON lines this rank's decoders produced in the LAST step
+        # of the timed region (what it sent into the gather) against the unmodified reference (oracle/_ref, its real decoders,
+        # one thread) over the very captures that step read.  The same run is the CPU baseline (rank 0's is reported).
         import hashlib
+        last = host_batches[(args.steps * per_step - 1) % len(host_batches)]
+        real, cpu_text = cpu_baseline_real_decoders(last)
+        mine = records["last_text"]
+        ok = bool(cpu_text is not None and cpu_text == mine)
+        ok_all = ok
+        if dist:
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok_all = bool(int(t.item()))
+        if rank == 0:
+            js = {"captures": int(last.shape[0]), "gpu_sha256": hashlib.sha256(mine).hexdigest(), "gpu_lines": mine.count(b"\n"),
+                  "cpu_sha256": hashlib.sha256(cpu_text).hexdigest() if cpu_text is not None else None,
+                  "cpu_lines": cpu_text.count(b"\n") if cpu_text is not None else None, "equal": ok, "equal_on_every_rank": ok_all,
+                  "note": "gpu = the JSON lines rank 0 put into the gather at the end of the timed region (its last step); cpu = the unmodified "
+                          "reference over the same captures; every rank makes the same comparison for its own batches"}
+            result["cpu_baseline"] = real
+            result["parity"] = ("decoded-json-sha256-match (the timed region's last step, whole)" if ok_all else
+                                "decoded json not compared (oracle/_ref did not travel)" if cpu_text is None else "DECODED JSON MISMATCH")
+            result["parity_detail"] = {"timed_region_last_step": js}
+    if rank == 0 and world == 1 and not strong and not args.quick:
+        # ... and every bitbuffer of one batch: a checksum decode_fn on both sides (pre-filter off: the checksum wants every record)
         e0 = pipe.engines[0]
         pipe.on_host_leg = None
         plug.take()
-        pipe.gpu_leg(0, src=batches[0][:n_batch])
-        e0.dispatch_ordered(plug.devices, pipe.hooks, threads)  # (the replay of the timed region, hook and all)
-        gpu_text, gpu_msgs = plug.take()
         e0.set_prefilter(0)
         ctx.sum = 0
         ctx.events = 0
@@ -683,20 +753,12 @@ def run_batched(args, ctxd):
                 one, many, parity = cpu_baseline_config2(host_batches[0][:n_batch], devs, gpu_digest, gpu_events)
                 result["cpu_baseline_checksum_decode_fn"] = one
                 result["cpu_baseline_nproc"] = many
-                real, cpu_text = cpu_baseline_real_decoders(host_batches[0][:n_batch])
-                result["cpu_baseline"] = real if real else one
-                js = {"gpu_sha256": hashlib.sha256(gpu_text).hexdigest(), "gpu_lines": gpu_text.count(b"\n"),
-                      "cpu_sha256": hashlib.sha256(cpu_text).hexdigest() if cpu_text is not None else None,
-                      "cpu_lines": cpu_text.count(b"\n") if cpu_text is not None else None}
-                js["equal"] = bool(cpu_text is not None and gpu_text == cpu_text)
-                result["parity"] = ("decoded-json-sha256-match" if js["equal"] else "DECODED JSON MISMATCH" if cpu_text is not None else "decoded json not compared") \
-                    + "; bitbuffers: " + parity
-                result["parity_detail"] = {"decoded_json": js, "bitbuffers": parity,
-                                           "sample": f"batch 0: {n_batch} captures, the reference's real decoders on both sides (JSON lines of data_print_jsons); "
-                                                     "checksum decode_fn for the bitbuffers"}
+                if result.get("cpu_baseline") is None:
+                    result["cpu_baseline"] = one
+                result["parity"] = result.get("parity", "") + "; bitbuffers of batch 0: " + parity
+                result.setdefault("parity_detail", {})["bitbuffers"] = {"verdict": parity, "sample": f"batch 0: {n_batch} captures, checksum decode_fn on both sides"}
             except Exception as e:  # the checker must not take the measurement down with it
-                result["cpu_baseline"] = None
-                result["parity"] = f"cpu baseline failed: {e}"
+                result["parity"] = result.get("parity", "") + f"; bitbuffer check failed: {e}"
             try:
                 result["real_decoders"] = real_decoders_leg(host_batches[0][:n_batch], batches[0][:n_batch], devs, threads, local_rank)
             except Exception as e:
@@ -954,7 +1016,12 @@ def run_stream(args, ctxd, parity_prefix=False):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (one process each).  Under torchrun it must equal WORLD_SIZE; "
+                    "started plainly with N > 1 the script re-executes itself under torch.distributed.run with N ranks")
+    ap.add_argument("--backend", default="hip", choices=["hip", "emu"], help="emu: TEST ONLY -- the CPU wave emulator of the test suite + gloo "
+                    "(tests/test_bench_launch.py drives the launcher and the gather with it); measures nothing")
+    ap.add_argument("--capture-samples", type=int, default=65536, help="configs 2 / 4: samples per capture (the emulator test shortens it; "
+                    "any other value than 65536 is not BASELINE's workload and the line says so)")
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
@@ -981,18 +1048,57 @@ def main():
     if args.warmup is None:
         args.warmup = {2: 3, 4: 1, 3: 2, 5: 1}[args.config]
 
+    global BK, CAPTURE_SAMPLES
+    CAPTURE_SAMPLES = args.capture_samples
+    # ---- how many ranks: --gpus N is a promise about the process group, kept or the run stops
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and (args.gpus or 1) > 1:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)  # N ranks of this very command line; rank 0 prints the line
+    # stdout carries ONE line, the result: whatever libraries print on the way (RCCL's version banner goes to stdout) is sent
+    # to stderr, the line is written to the real stdout at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(env_world or 1)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus is not None and args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): refusing to print a line that "
+                         "names another number of GPUs than the run used")
+
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (rtl_433_amd has no CPU path)")
-    torch.cuda.set_device(local_rank)
+    emu = args.backend == "emu"
+    if not emu:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (rtl_433_amd has no CPU path)")
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank}, the node shows {torch.cuda.device_count()} GPU(s)")
+        torch.cuda.set_device(local_rank)
+    BK = Backend(args.backend)
     dist = None
-    if world > 1:
+    seen_gpus = None
+    if env_world is not None:  # started by a launcher: the process group exists for every N, one rank included
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if emu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
+        world = dist.get_world_size()  # what the process group really has
+        # one distinct GPU per rank: every rank names its device, all ranks compare
+        mine = f"emu:{rank}" if emu else f"{os.uname().nodename}/{getattr(torch.cuda.get_device_properties(local_rank), 'uuid', local_rank)}/{local_rank}"
+        names = [None] * world
+        dist.all_gather_object(names, mine)
+        if len(set(names)) != world:
+            raise SystemExit(f"bench.py: {world} ranks on {len(set(names))} distinct GPU(s): {names}")
+        seen_gpus = names
     ctxd = dict(rank=rank, world=world, local_rank=local_rank, dist=dist)
     # Waiting for the GPU spins on this stack (tools/spin_probe.py), and a rank keeps two GPU legs in flight: ranks that share a
     # small CPU quota -- eight on the 16 CPUs these boxes grant -- would burn it on waiting while their decoders starve.  With
@@ -1003,8 +1109,15 @@ def main():
     result = run_batched(args, ctxd) if args.config in (2, 4) else run_stream(args, ctxd)
     if rank == 0 and isinstance(result, dict) and isinstance(result.get("config"), dict):
         result["config"]["gpu_waits"] = "polled with naps (ranks share a small CPU quota)" if DEBUG_FLAGS & NAP_WAIT else "hipEventSynchronize (spins)"
+        result["config"]["ranks"] = {"world_size": world, "launcher": "torch.distributed.run" if env_world is not None else "none (one process)",
+                                     "collective_backend": (None if dist is None else "gloo" if emu else "nccl (RCCL)"), "devices": seen_gpus}
+        if emu:
+            result["backend"] = "CPU wave emulator + gloo: a TEST of the launcher and the gather, not a measurement"
+        if CAPTURE_SAMPLES != 65536:
+            result["config"]["not_baseline_workload"] = f"captures of {CAPTURE_SAMPLES} samples (BASELINE: 65536)"
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
     if dist:
         dist.destroy_process_group()
 

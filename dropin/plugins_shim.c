@@ -3,7 +3,8 @@
  * The decoders are the CONSUMERS of the hot path: unchanged host C behind r_device.decode_fn (reference
  * include/r_device.h:59-92).  A host that is not the rtl_433 CLI -- bench.py's multi-GPU run, a service that decodes
  * uploaded captures -- needs them without the CLI around them: this file, linked with the reference's sources compiled
- * where they lie (dropin/Makefile `plugins`; everything but src/rtl_433.c and src/r_flow.c), registers the default
+ * where they lie (dropin/Makefile `plugins`; everything but src/rtl_433.c, src/r_flow.c and the four DSP units, which
+ * librtl433seam.so replaces), registers the default
  * protocols the way the CLI does (register_all_protocols, src/r_api.c) and hands out the r_device instances.  What the
  * decoders report (data_t) is printed with the reference's own JSON printer (data_print_jsons, src/data.c) into a
  * buffer the host takes, one line per message -- the payload of the final event gather of BASELINE.json configs[3].
@@ -141,21 +142,30 @@ int r433p_devices(void *hv, r_device **out, int cap)
  * that the ordered replay may spread a decoder's calls over its threads.  The plugin library is the one that knows: of the
  * reference's decoders four keep state in file-scope statics (src/devices/secplus_v1.c:142-143, secplus_v2.c:260-266,
  * ikea_sparsnas.c:92, arad_ms_meter.c:256), and every decoder made by a create_fn owns a context (flex, blueline, vivint,
- * arad_ms_meter); all others are functions of the bitbuffer they are handed.  Returns the number of decoders. */
+ * arad_ms_meter); all others are functions of the bitbuffer they are handed.  Returns the number of decoders, -1 if the list
+ * of names below no longer matches the registered decoders. */
 int r433p_stateless(void *hv, unsigned char *flags, int cap)
 {
     static char const *const stateful[] = {"Security+ (Keyfob)", "Security+ 2.0 (Keyfob)", "IKEA Sparsnas Energy Meter Monitor",
             "Arad/Master Meter Dialog3G water utility meter"};
     r433p *h = hv;
     int n    = 0;
+    unsigned matched = 0; /* bit k: stateful[k] is among the registered decoders */
     for (void **it = h->cfg->demod->r_devs.elems; it && *it; ++it, ++n) {
         r_device const *d = *it;
         int keeps         = d->decode_ctx != NULL || d->create_fn != NULL;
         for (size_t k = 0; k < sizeof(stateful) / sizeof(stateful[0]); ++k)
-            keeps |= d->name && strcmp(d->name, stateful[k]) == 0;
+            if (d->name && strcmp(d->name, stateful[k]) == 0) {
+                keeps = 1;
+                matched |= 1u << k;
+            }
         if (flags && n < cap)
             flags[n] = keeps ? 0 : 1;
     }
+    /* fail closed: a name of the list that matches no registered decoder means the list is stale (a decoder was renamed) --
+     * answering then would declare the renamed decoder stateless and let its statics race on the replay threads */
+    if (matched != (1u << (sizeof(stateful) / sizeof(stateful[0]))) - 1)
+        return -1;
     return n;
 }
 

@@ -1080,7 +1080,9 @@ static int pass_replay(r_cfg_t *cfg, pending_pass *d)
     return events;
 }
 
-int hip_sdr_flow_drain(struct r_cfg *cfg)
+/* One pass over what is queued.  From the flow's own batch-limit drain (push_sdr_flow) the pass may stay in flight: it is
+   replayed at the next drain, beside the GPU leg of the pass after it.  The PUBLIC drain below never leaves anything behind. */
+static int drain_queue(struct r_cfg *cfg)
 {
     struct dm_state *demod = cfg->demod;
     if (!demod || (H.n_caps == 0 && !P.active))
@@ -1200,11 +1202,21 @@ int hip_sdr_flow_drain(struct r_cfg *cfg)
 
 /* For builds of the unmodified src/rtl_433.c: compiled with -Dclose_dumpers=hip_sdr_flow_close_dumpers the file loop's
    last act (src/rtl_433.c:1861) first drains what is still queued. */
+/* The integration hook: called by the host once its file loop is over (or whenever it wants every event of
+   what it has pushed so far).  Always complete: the pass in flight is joined and replayed, then the queue runs and is
+   replayed, in that order -- when it returns no pass is in flight, no thread is running and every event has been delivered. */
+int hip_sdr_flow_drain(struct r_cfg *cfg)
+{
+    int const nested = H.final_drain;
+    H.final_drain    = 1; /* pass_may_overlap() says no: nothing is handed to a thread from here */
+    int const events = drain_queue(cfg);
+    H.final_drain    = nested;
+    return events;
+}
+
 void hip_sdr_flow_close_dumpers(struct r_cfg *cfg)
 {
-    H.final_drain = 1; /* the file loop is over: the pass in flight and the queue, in that order, and nothing left behind */
     hip_sdr_flow_drain(cfg);
-    H.final_drain = 0;
     close_dumpers(cfg);
 }
 
@@ -1297,7 +1309,7 @@ int push_sdr_flow(r_cfg_t *cfg, unsigned char *iq_buf, uint32_t len)
         }
         H.open = 0;
         if (H.n_caps >= batch_limit(cfg) || H.stage_len + STAGE_PASS / 16 >= STAGE_PASS)
-            return hip_sdr_flow_drain(cfg);
+            return drain_queue(cfg); /* (the only drain that may leave its pass in flight) */
         return 0;
     }
 

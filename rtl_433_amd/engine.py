@@ -48,6 +48,7 @@ class BatchEngine:
         # `library` is for the test suite's emulator build of the same sources; the product always
         # goes through _lib.lib(), which raises if librtl433hip.so is missing.
         self.L = library if library is not None else _lib.lib()
+        self.emulated = library is not None  # (the emulator's "device" memory is host memory)
         _lib.check(self.L.r433_device_count(), "r433_device_count", self.L)
         self.cfg = cfg
         self.devs = np.zeros(0, dtype=DEV_DTYPE) if devs is None else np.ascontiguousarray(devs, dtype=DEV_DTYPE)
@@ -135,7 +136,7 @@ class BatchEngine:
     def run(self, iq, stream_bytes=None, stream=None):
         """iq: CUDA tensor [n_streams, stride] of uint8 (cu8) or int16 (cs16), contiguous."""
         import torch
-        assert iq.is_cuda and iq.is_contiguous() and iq.dim() == 2
+        assert (iq.is_cuda or self.emulated) and iq.is_contiguous() and iq.dim() == 2 and iq.data_ptr() % 16 == 0
         n_streams = iq.shape[0]
         stride = iq.shape[1] * iq.element_size()
         sb = None
@@ -143,7 +144,7 @@ class BatchEngine:
             sb_arr = np.ascontiguousarray(stream_bytes, dtype=np.uint32)
             assert len(sb_arr) == n_streams
             sb = sb_arr.ctypes.data_as(C.c_void_p)
-        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        st = stream if stream is not None else (torch.cuda.current_stream().cuda_stream if iq.is_cuda else 0)
         rc = self.L.r433_batch_run(self.h, C.c_void_p(iq.data_ptr()), stride, sb, n_streams, C.c_void_p(st))
         return _lib.check(rc, "r433_batch_run", self.L)
 

@@ -15,26 +15,6 @@ def available():
     return os.path.exists(LIB_PATH)
 
 
-# What this host knows about its plugins (r433_batch_set_stateless): of the reference's decoders these keep state between
-# calls in file-scope statics (src/devices/secplus_v1.c:142-143, secplus_v2.c:260-266, ikea_sparsnas.c:92,
-# arad_ms_meter.c:256), and every decoder made by a create_fn (flex, blueline, vivint, arad_ms_meter) owns a context.  All
-# others are functions of the bitbuffer they are handed.  (How the list was made: grep for non-const statics under
-# src/devices of the pinned reference; tests/test_dispatch.py holds the replay to the single-threaded one either way.)
-STATEFUL_NAMES = {"Security+ (Keyfob)", "Security+ 2.0 (Keyfob)", "IKEA Sparsnas Energy Meter Monitor",
-                  "Arad/Master Meter Dialog3G water utility meter"}
-
-
-def stateless_flags(devices):
-    """-> ctypes uint8 array, one flag per r_device* of `devices`: 1 = its decode_fn may be called from several threads"""
-    from ._lib import RDevice
-    flags = (C.c_uint8 * len(devices))()
-    for i, p in enumerate(devices):
-        d = C.cast(p, C.POINTER(RDevice)).contents
-        name = d.name.decode(errors="replace") if d.name else ""
-        flags[i] = 0 if (name in STATEFUL_NAMES or d.decode_ctx or d.create_fn) else 1
-    return flags
-
-
 class Plugins:
     def __init__(self):
         if not available():
@@ -53,11 +33,15 @@ class Plugins:
         assert L.r433p_devices(self.h, self.devices, n) == n
 
     def stateless(self):
-        """-> ctypes uint8 array for r433_batch_set_stateless: what the plugin library says about its own decoders"""
+        """-> ctypes uint8 array for r433_batch_set_stateless: what the plugin library says about its own decoders (the ONE
+        place that knows: dropin/plugins_shim.c r433p_stateless; it answers -1 when a decoder it lists as keeping state is
+        not among the registered ones -- a renamed decoder must not silently become "stateless")"""
         flags = (C.c_uint8 * len(self.devices))()
         self.L.r433p_stateless.restype = C.c_int
         self.L.r433p_stateless.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-        assert self.L.r433p_stateless(self.h, flags, len(flags)) == len(flags)
+        n = self.L.r433p_stateless(self.h, flags, len(flags))
+        if n != len(flags):
+            raise RuntimeError(f"r433p_stateless answered {n} for {len(flags)} decoders: its list of stateful decoders no longer matches the registered set")
         return flags
 
     def hooks(self):

@@ -23,9 +23,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref", "rtl_433_ref")
 EMU = os.path.join(ROOT, "dropin", "_build", "rtl_433_emu")
 HIP = os.path.join(ROOT, "dropin", "_build", "rtl_433_hip")
-# the same with src/baseband.c, src/pulse_detect*.c and src/pulse_slicer.c left out as well: librtl433seam.so stands in
-EMU_SEAM = os.path.join(ROOT, "dropin", "_build", "rtl_433_emu_seam")
-HIP_SEAM = os.path.join(ROOT, "dropin", "_build", "rtl_433_hip_seam")
+# (both are linked WITHOUT src/baseband.c, src/pulse_detect*.c and src/pulse_slicer.c: librtl433seam.so stands in for what the
+# rest of the reference calls by those names -- test_no_reference_dsp_symbol_is_linked)
+PLUGINS = os.path.join(ROOT, "dropin", "_build", "libr433plugins.so")
 # the reference with its OWN src/r_flow.c and src/rtl_433.c, only the four DSP units replaced by librtl433seam.so: every
 # frame goes through envelope_detect / baseband_low_pass_filter / baseband_demod_FM / pulse_detect_package / pulse_slicer_*
 EMU_REFFLOW = os.path.join(ROOT, "dropin", "_build", "rtl_433_refflow_emu")
@@ -46,14 +46,13 @@ def _ensure_built(binary):
         pytest.skip(f"{os.path.relpath(binary, ROOT)} not built and no reference tree to build it from")
     from oracle import pyoracle as po
     po.build_ref()
-    if binary in (EMU, EMU_SEAM, EMU_REFFLOW):
+    if binary in (EMU, EMU_REFFLOW):
         from tests.emu import build_emu
         build_emu.build()
     if binary in (EMU_REFFLOW, HIP_REFFLOW):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "dropin"), "refflow"], stdout=subprocess.DEVNULL)
         return
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "dropin"), "emu" if binary in (EMU, EMU_SEAM) else "hip"]
-                          + (["SEAM=1"] if binary in (EMU_SEAM, HIP_SEAM) else []), stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "dropin"), "emu" if binary == EMU else "hip"], stdout=subprocess.DEVNULL)
 
 
 def run_cli(binary, args, cwd, env=None):
@@ -233,20 +232,40 @@ def check_analyzer(binary, tmp_path):
     assert got == ref
 
 
-def test_emu_seam_variant(tmp_path):
-    _ensure_built(EMU_SEAM)
-    check_kat(EMU_SEAM, tmp_path)
-    check_batch(EMU_SEAM, tmp_path, range(3))
-    check_analyzer(EMU_SEAM, tmp_path)
+def test_emu_analyzer(tmp_path):
+    _ensure_built(EMU)
+    check_analyzer(EMU, tmp_path)
 
 
 @pytest.mark.gpu
-def test_hip_seam_variant(tmp_path):
-    _ensure_built(HIP_SEAM)
-    check_kat(HIP_SEAM, tmp_path)
-    check_batch(HIP_SEAM, tmp_path, range(8))
-    check_analyzer(HIP_SEAM, tmp_path)
-    check_config3(HIP_SEAM, tmp_path)
+def test_hip_analyzer(tmp_path):
+    _ensure_built(HIP)
+    check_analyzer(HIP, tmp_path)
+
+
+REFERENCE_DSP_SYMBOLS = ("envelope_detect", "envelope_detect_nolut", "magnitude_est_cu8", "magnitude_true_cu8", "magnitude_est_cs16",
+                         "magnitude_true_cs16", "baseband_low_pass_filter", "baseband_demod_FM", "baseband_demod_FM_cs16", "baseband_init",
+                         "pulse_detect_create", "pulse_detect_package", "pulse_detect_fsk_classic", "pulse_detect_fsk_minmax",
+                         "pulse_detect_fsk_wrap_up", "pulse_slicer_pcm", "pulse_slicer_ppm", "pulse_slicer_pwm",
+                         "pulse_slicer_manchester_zerobit", "pulse_slicer_dmc", "pulse_slicer_piwm_raw", "pulse_slicer_piwm_dc",
+                         "pulse_slicer_nrzs", "pulse_slicer_osv1", "pulse_slicer_rzi", "push_sdr_flow_reference")
+
+
+@pytest.mark.parametrize("binary", [EMU, HIP, PLUGINS], ids=["rtl_433_emu", "rtl_433_hip", "libr433plugins"])
+def test_no_reference_dsp_symbol_is_linked(binary):
+    """By linkage: neither the drop-in CLI nor the plugin library bench.py and pipeline_host put behind the path DEFINES any
+    function of the reference's src/baseband.c, src/pulse_detect.c, src/pulse_detect_fsk.c or src/pulse_slicer.c -- what the rest
+    of the reference calls by those names is undefined in them and resolved by librtl433seam.so (-> the GPU library)."""
+    if not os.path.exists(binary):
+        pytest.skip(f"{os.path.relpath(binary, ROOT)} not built")
+    syms = subprocess.run(["nm", binary], stdout=subprocess.PIPE, stderr=subprocess.PIPE).stdout.decode() \
+        + subprocess.run(["nm", "-D", binary], stdout=subprocess.PIPE, stderr=subprocess.PIPE).stdout.decode()
+    defined = {l.split()[-1] for l in syms.splitlines() if len(l.split()) == 3 and l.split()[1] in "TtDdBbWwVv"}
+    undefined = {l.split()[-1] for l in syms.splitlines() if len(l.split()) == 2 and l.split()[0] == "U"}
+    assert not defined & set(REFERENCE_DSP_SYMBOLS), sorted(defined & set(REFERENCE_DSP_SYMBOLS))
+    assert {"pulse_detect_create", "baseband_init", "pulse_slicer_pcm"} <= undefined  # r_api.c's calls leave the binary
+    needed = subprocess.run(["readelf", "-d", binary], stdout=subprocess.PIPE).stdout.decode()
+    assert "librtl433seam.so" in needed
 
 
 def check_pulse_dumpers(binary, tmp_path):

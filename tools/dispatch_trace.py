@@ -15,7 +15,7 @@ plug = plugins.Plugins()
 eng = BatchEngine(flow_cfg(2, 250000), devs, profiling=True)
 eng.probe_prefilter(plug.devices)
 if stateless:
-    eng.set_stateless(plugins.stateless_flags(plug.devices))
+    eng.set_stateless(plug.stateless())
 d = torch.from_numpy(host).cuda()
 for rep in range(3):
     if rep == 2:

@@ -33,7 +33,7 @@ if real:
     pipe = bench.Pipeline(lambda: flow_cfg(2, 250000), devs, plug.devices, threads, n_eng, 0, on_host_leg=lambda k, e, n: plug.take(), ordered=True,
                           hooks=plug.hooks() if hasattr(plug, "hooks") else None)
     for e in pipe.engines:
-        e.set_stateless(plugins.stateless_flags(plug.devices))
+        e.set_stateless(plug.stateless())
         e.probe_prefilter(plug.devices)
 else:
     pipe = bench.Pipeline(lambda: flow_cfg(2, 250000), devs, rdev_arr, threads, n_eng, 0)

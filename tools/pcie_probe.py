@@ -1,15 +1,30 @@
-"""What the PCIe link of the box gives: pinned host -> HBM copies of the size of one bench step (1 GiB), alone, as two
-halves on two streams, and with a device -> host copy of 200 MiB running against it.  (The headline `value` is bound by it.)"""
+"""What the PCIe link of the box gives in the setting of bench.py: pinned host -> HBM copies of the size of one bench step (1 GiB)
+with a device -> host copy of 200 MiB running against it -- on torch streams (what bench.py hands the library), on raw HIP streams
+wrapped as torch ExternalStreams, with the D2H on a high-priority stream, and through hipMemcpyAsync called directly.
+tools/ubench/pcie_duplex.hip is the plain-HIP form of the same question (full duplex there: 18.7 ms for both at once)."""
+import ctypes as C
 import time
 
 import torch
 
+hip = C.CDLL("libamdhip64.so")
 n = 1 << 30
+m = 200 << 20
 h = torch.empty(n, dtype=torch.uint8).pin_memory()
 d = torch.empty(n, dtype=torch.uint8, device="cuda")
-h2 = torch.empty(200 << 20, dtype=torch.uint8).pin_memory()
-d2 = torch.empty(200 << 20, dtype=torch.uint8, device="cuda")
-s1, s2, s3 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+h2 = torch.empty(m, dtype=torch.uint8).pin_memory()
+d2 = torch.empty(m, dtype=torch.uint8, device="cuda")
+pool = [torch.cuda.Stream() for _ in range(6)]
+hi = torch.cuda.Stream(priority=-1)
+
+
+def raw_stream():
+    s = C.c_void_p()
+    assert hip.hipStreamCreateWithFlags(C.byref(s), 1) == 0  # hipStreamNonBlocking
+    return torch.cuda.ExternalStream(s.value)
+
+
+raw = [raw_stream() for _ in range(2)]
 
 
 def timed(fn, reps=5):
@@ -23,36 +38,46 @@ def timed(fn, reps=5):
     return best
 
 
-def one():
-    with torch.cuda.stream(s1):
+def pair(s_in, s_out, d2h_first=True):
+    def go():
+        if d2h_first:
+            with torch.cuda.stream(s_out):
+                h2.copy_(d2, non_blocking=True)
+        with torch.cuda.stream(s_in):
+            d.copy_(h, non_blocking=True)
+        if not d2h_first:
+            with torch.cuda.stream(s_out):
+                h2.copy_(d2, non_blocking=True)
+    return go
+
+
+def direct(s_in, s_out):
+    def go():
+        assert hip.hipMemcpyAsync(C.c_void_p(h2.data_ptr()), C.c_void_p(d2.data_ptr()), C.c_size_t(m), 2, C.c_void_p(s_out.cuda_stream)) == 0
+        assert hip.hipMemcpyAsync(C.c_void_p(d.data_ptr()), C.c_void_p(h.data_ptr()), C.c_size_t(n), 1, C.c_void_p(s_in.cuda_stream)) == 0
+    return go
+
+
+cases = [("h2d alone (torch stream)", lambda: pair(pool[0], pool[1])() if False else pool_only()), ]
+
+
+def pool_only():
+    with torch.cuda.stream(pool[0]):
         d.copy_(h, non_blocking=True)
 
 
-def halves():
-    with torch.cuda.stream(s1):
-        d[: n // 2].copy_(h[: n // 2], non_blocking=True)
-    with torch.cuda.stream(s2):
-        d[n // 2:].copy_(h[n // 2:], non_blocking=True)
-
-
-def quarters():
-    for k, st in enumerate((s1, s2, s1, s2)):
-        with torch.cuda.stream(st):
-            d[k * n // 4:(k + 1) * n // 4].copy_(h[k * n // 4:(k + 1) * n // 4], non_blocking=True)
-
-
-def with_d2h():
-    with torch.cuda.stream(s3):
-        h2.copy_(d2, non_blocking=True)
-    one()
-
-
 def d2h_only():
-    with torch.cuda.stream(s3):
+    with torch.cuda.stream(pool[2]):
         h2.copy_(d2, non_blocking=True)
 
 
-for name, fn, nbytes in (("h2d 1 GiB one stream", one, n), ("h2d two halves on two streams", halves, n), ("h2d four quarters on two streams", quarters, n),
-                         ("h2d 1 GiB + d2h 200 MiB", with_d2h, n), ("d2h 200 MiB", d2h_only, 200 << 20)):
-    t = timed(fn)
-    print(f"{name}: {t * 1e3:.2f} ms, {nbytes / t / 1e9:.1f} GB/s")
+print(f"h2d 1 GiB alone: {timed(pool_only) * 1e3:.2f} ms;  d2h 200 MiB alone: {timed(d2h_only) * 1e3:.2f} ms")
+for k in range(1, 6):
+    print(f"torch pool streams 0 (h2d) + {k} (d2h): {timed(pair(pool[0], pool[k])) * 1e3:.2f} ms")
+print(f"torch pool 0 (h2d) + 2 (d2h), h2d issued first: {timed(pair(pool[0], pool[2], False)) * 1e3:.2f} ms")
+print(f"torch pool 0 (h2d) + high-priority stream (d2h): {timed(pair(pool[0], hi)) * 1e3:.2f} ms")
+print(f"raw HIP streams (ExternalStream) h2d + d2h: {timed(pair(raw[0], raw[1])) * 1e3:.2f} ms")
+print(f"torch pool 0 (h2d) + raw HIP stream (d2h): {timed(pair(pool[0], raw[1])) * 1e3:.2f} ms")
+print(f"hipMemcpyAsync called directly, torch pool 0 + 2: {timed(direct(pool[0], pool[2])) * 1e3:.2f} ms")
+print(f"hipMemcpyAsync called directly, raw streams: {timed(direct(raw[0], raw[1])) * 1e3:.2f} ms")
+print(f"h2d on the null stream + d2h on pool 2: {timed(pair(torch.cuda.default_stream(), pool[2])) * 1e3:.2f} ms")
