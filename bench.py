@@ -33,7 +33,7 @@ resident in HBM is measured in the same process and reported next to it (`hbm_re
 with the same real decoders on one core (`cpu_baseline`; its JSON lines for batch 0 are compared with the GPU path's by
 sha256: `parity_detail`), the reference with a checksum decode_fn on one core and on all cores as independent processes
 (every bitbuffer checked: `cpu_baseline_checksum_decode_fn`, `cpu_baseline_nproc`), one-pass variants of the replay
-(`real_decoders`) and short passes of the single-stream workloads (`other_configs`: configs[2] and configs[4]).
+(`real_decoders`) and the single-stream workloads at their full sizes (`other_configs`: configs[2] and configs[4]).
 Configs 3, 4 and 5 keep their inputs resident (their lines say so in `data`).
 
 Prints ONE JSON line on rank 0.
@@ -280,10 +280,11 @@ def cpu_baseline_real_decoders(host_iq, reps=1, what="the inputs of the LAST ste
 
 
 def other_configs_summary(args):
-    """configs[2] and configs[4] (one long cs16 FSK stream; one 2 MS/s mixed stream with -Y autolevel) as short passes in
-    the same process: their detection time, roofline fraction and record parity against the reference on a prefix."""
+    """configs[2] and configs[4] (one long cs16 FSK stream; one 2 MS/s mixed stream with -Y autolevel) at BASELINE's full
+    sizes in the same process: their detection time, roofline fraction and the checksum of every bitbuffer of the whole
+    stream against the unmodified reference (half a minute of the run is making the two streams)."""
     out = {}
-    for cfg_no, n_samples in ((3, 16 << 20), (5, 32 << 20)):
+    for cfg_no, n_samples in ((3, 64 << 20), (5, 256 << 20)):
         a = argparse.Namespace(**vars(args))
         a.config, a.stream_samples, a.steps, a.warmup, a.quick, a.no_cpu_baseline = cfg_no, n_samples, 3, 1, True, True
         r = run_stream(a, dict(rank=0, world=1, local_rank=0, dist=None), parity_prefix=True)
@@ -380,6 +381,75 @@ def real_decoders_leg(host_iq, d_iq, devs, threads, local_rank, reps=2, pipe_ste
 def _RDevice():
     from rtl_433_amd import _lib
     return _lib.RDevice
+
+
+def dropin_legs(host_iq, expect_json, reps=5):
+    """The drop-in itself under this run's clock: the captures of one step written as `.cu8` files (tmpfs), then
+      * dropin/_build/rtl_433_hip -- the reference's unmodified CLI, decoders and JSON printer over dropin/r_flow_hip.c and the
+        GPU library -- `-r f1 -r f2 ... -F json -M level -K FILE`: wall time of the whole process, cold start included, and
+        its output against the stock binary's (oracle/_ref/rtl_433_ref, one run) by SHA-256;
+      * dropin/_build/pipeline_host_hip -- a plain C host over the C ABI and the plugin library, three engines --: wall time
+        of the process and its own clock over the passes; its JSON lines against what the timed region of this run produced
+        for the same captures (`expect_json`)."""
+    import hashlib
+    import shutil
+    import subprocess
+    import tempfile
+    cli, stock = os.path.join(ROOT, "dropin", "_build", "rtl_433_hip"), os.path.join(ROOT, "oracle", "_ref", "rtl_433_ref")
+    ph = os.path.join(ROOT, "dropin", "_build", "pipeline_host_hip")
+    if not os.path.exists(cli):
+        return dict(error="dropin/_build/rtl_433_hip did not travel")
+    n, n_samples = host_iq.shape[0], host_iq.shape[1] // 2
+    d = tempfile.mkdtemp(prefix="r433_cli_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        names = []
+        for k in range(n):
+            names.append(f"s{k:05d}_433.92M_250k.cu8")
+            host_iq[k].tofile(os.path.join(d, names[-1]))
+        args = [a for f in names for a in ("-r", f)] + ["-F", "json", "-M", "level", "-K", "FILE"]
+
+        def run(binary, argv):
+            t0 = time.perf_counter()
+            p = subprocess.run([binary] + argv, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            return (time.perf_counter() - t0) * 1e3, p
+        out = {"files": n, "samples_per_file": n_samples, "where": d.rsplit("/", 1)[0]}
+        walls, shas = [], set()
+        for _ in range(reps):
+            ms, p = run(cli, args)
+            if p.returncode != 0:
+                return dict(error="rtl_433_hip: " + p.stderr.decode(errors="replace")[-300:])
+            walls.append(round(ms, 1))
+            shas.add(hashlib.sha256(p.stdout).hexdigest())
+        cli_out = {"wall_ms": walls, "median_ms": float(np.median(walls)), "max_over_min": round(max(walls) / min(walls), 2),
+                   "value": round(n * n_samples / (float(np.median(walls)) * 1e-3) / 1e6, 1), "unit": "Msamples/s",
+                   "json_lines": p.stdout.count(b"\n"), "same_output_every_run": len(shas) == 1,
+                   "note": "wall time of the whole process (start, GPU opening, file reads, passes, replay, JSON), median of the runs"}
+        if os.path.exists(stock):
+            ms, p = run(stock, args)
+            cli_out["stock_binary_ms"] = round(ms, 1)
+            cli_out["json_sha256_equals_stock_binary"] = bool(p.returncode == 0 and shas == {hashlib.sha256(p.stdout).hexdigest()})
+        out["rtl_433_hip"] = cli_out
+        if os.path.exists(ph):
+            walls, own, ok = [], [], True
+            for _ in range(3):
+                ms, p = run(ph, ["-e", "3", "-b", "1024", "-p"] + names)
+                if p.returncode != 0:
+                    out["pipeline_host_hip"] = dict(error=p.stderr.decode(errors="replace")[-300:])
+                    break
+                walls.append(round(ms, 1))
+                tail = p.stderr.decode(errors="replace")
+                at = tail.rfind("passes over")
+                own.append(float(tail[at:].split(": ", 1)[1].split(" ms", 1)[0]) if at >= 0 else None)
+                ok = ok and (expect_json is None or p.stdout == expect_json)
+            else:
+                out["pipeline_host_hip"] = {"wall_ms": walls, "median_ms": float(np.median(walls)), "passes_ms_by_its_own_clock": own,
+                                            "value": round(n * n_samples / (float(np.median(walls)) * 1e-3) / 1e6, 1), "unit": "Msamples/s",
+                                            "json_equals_timed_region": (bool(ok) if expect_json is not None else None),
+                                            "note": "a C host over include/r433_hip.h + libr433plugins.so, three engines, passes of 1024 files, "
+                                                    "pre-filter on; wall time of the whole process"}
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 # ---------------------------------------------------------------- the software pipeline (configs 2 and 4)
@@ -763,6 +833,11 @@ def run_batched(args, ctxd):
                 result["real_decoders"] = real_decoders_leg(host_batches[0][:n_batch], batches[0][:n_batch], devs, threads, local_rank)
             except Exception as e:
                 result["real_decoders"] = dict(error=str(e))
+            try:  # the drop-in CLI and the C pipeline host over the files of the last step (what a user of `rtl_433 -r` gets)
+                last = host_batches[(args.steps * per_step - 1) % len(host_batches)]
+                result["dropin"] = dropin_legs(last, records.get("last_text"))
+            except Exception as e:
+                result["dropin"] = dict(error=str(e))
             try:  # the other single-stream workloads of BASELINE.json under the same roof (short passes, inputs resident)
                 result["other_configs"] = other_configs_summary(args)
             except Exception as e:

@@ -161,6 +161,9 @@ typedef struct pending_pass {
     int active;
     pthread_t thread;
     r433_batch *eng;
+    r_cfg_t *cfg;
+    r433_flow_cfg fc;
+    int lane;
     hip_capture *caps;
     size_t n;
     uint8_t *stage;
@@ -240,27 +243,122 @@ static void hip_fatal(char const *what)
    that the buffers of a pass (pinned staging here, record mirrors in the library) are cheap to come by */
 #define STAGE_PASS ((size_t)256 << 20)
 
+/* ---- what a process pays once before its first kernel has run, off the file loop's thread --------------------------------
+   Opening the GPU (50-130 ms) and loading the library's kernels (20-150 ms) used to happen inside the first staging
+   allocation and the first engine, on the thread that reads the files -- a third of a run over 8192 captures.  They start on
+   a thread of their own at the first push and are waited for where the first GPU call is made (the first pass -- on its own
+   thread, too, when the list is long: the file loop never stops for them).  RTL433_HIP_WARM=0: as before, inline. */
+static struct {
+    pthread_t thread;
+    int started, joined;
+    double t0;
+} W;
+
+static void *warm_thread(void *arg)
+{
+    (void)arg;
+    (void)r433_warmup(); /* (a failure shows at the first real call, with its message) */
+    return NULL;
+}
+
+static void warm_join(void)
+{
+    if (W.started && !W.joined) {
+        W.joined = 1;
+        pthread_join(W.thread, NULL);
+        if (trace_on())
+            fprintf(stderr, "hip flow: GPU opened and kernels loaded on a thread of their own, ready %.1f ms after the first push\n", trace_now() - W.t0);
+    }
+}
+
+static void warm_start(void)
+{
+    char const *e = getenv("RTL433_HIP_WARM");
+    if (W.started || (e && *e == '0'))
+        return;
+    W.t0 = trace_now();
+    if (pthread_create(&W.thread, NULL, warm_thread, NULL) == 0) {
+        W.started = 1;
+        atexit(warm_join); /* (a process that leaves without a drain must not exit under a thread that is opening the device) */
+    }
+}
+
+/* Staging buffers are plain memory: the file loop's thread fills them without a word to the GPU.  A buffer is REGISTERED with
+   the device (page-locked in place: 13-15 ms per 256 MiB of touched memory, against 46-60 ms for allocating it pinned, and on
+   the thread that starts the pass, not on the one that reads the files) the first time a pass reads from it, and stays so
+   while it is reused.  tools/ubench/h2d_pageable.hip: 256 MiB from registered memory cross in 4.7 ms, from unregistered
+   memory in 23-26 ms. */
+#define STAGE_BUFFERS 8
+static struct {
+    uint8_t *p;
+    size_t cap;
+    int pinned;
+} g_stage_buf[STAGE_BUFFERS];
+static pthread_mutex_t g_stage_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static uint8_t *stage_alloc(size_t cap)
+{
+    void *p = NULL;
+    if (posix_memalign(&p, (size_t)2 << 20, cap) != 0 || !p)
+        FATAL_MALLOC("hip staging buffer");
+    pthread_mutex_lock(&g_stage_lock);
+    for (int k = 0; k < STAGE_BUFFERS; ++k)
+        if (!g_stage_buf[k].p) {
+            g_stage_buf[k].p      = p;
+            g_stage_buf[k].cap    = cap;
+            g_stage_buf[k].pinned = 0;
+            break;
+        }
+    pthread_mutex_unlock(&g_stage_lock);
+    return p;
+}
+
+static void stage_free(uint8_t *p)
+{
+    if (!p)
+        return;
+    pthread_mutex_lock(&g_stage_lock);
+    for (int k = 0; k < STAGE_BUFFERS; ++k)
+        if (g_stage_buf[k].p == p) {
+            if (g_stage_buf[k].pinned)
+                (void)r433_host_unregister(p);
+            g_stage_buf[k].p = NULL;
+        }
+    pthread_mutex_unlock(&g_stage_lock);
+    free(p);
+}
+
+/* before a pass reads from it (any thread; after warm_join) */
+static void stage_pin(uint8_t *p)
+{
+    pthread_mutex_lock(&g_stage_lock);
+    for (int k = 0; k < STAGE_BUFFERS; ++k)
+        if (g_stage_buf[k].p == p && !g_stage_buf[k].pinned) {
+            double const t0 = trace_now();
+            if (r433_host_register(p, g_stage_buf[k].cap) == 0) /* (refused: the copy still works, from pageable memory) */
+                g_stage_buf[k].pinned = 1;
+            if (trace_on())
+                fprintf(stderr, "hip flow: staging buffer of %zu MiB %s in %.1f ms\n", g_stage_buf[k].cap >> 20,
+                        g_stage_buf[k].pinned ? "registered with the device" : "could not be registered (pageable copies)", trace_now() - t0);
+        }
+    pthread_mutex_unlock(&g_stage_lock);
+}
+
 static void stage_reserve(size_t need)
 {
     if (need <= H.stage_cap)
         return;
-    /* Pinning memory costs ~0.2 ms per MiB and a grown buffer has to be copied into: 8 MiB for the lone small file, then
-       straight to the size a pass is cut at (STAGE_PASS below), doubling only for captures that are larger than that.  (Growing
-       by doubling up to 1 GiB took 0.55 s of a 1.1 s run over 8192 captures, RTL433_HIP_TRACE=1.) */
+    /* 8 MiB for the lone small file, then straight to the size a pass is cut at (STAGE_PASS below), doubling only for
+       captures that are larger than that: a grown buffer has to be copied into (and registered again). */
     size_t cap = H.stage_cap ? H.stage_cap : H.lane_seen ? STAGE_PASS : (size_t)8 << 20; /* (a process that hands passes over has a list) */
     if (cap < need && cap < STAGE_PASS)
         cap = STAGE_PASS;
     while (cap < need)
         cap *= 2;
-    double const t_grow = trace_now();
-    uint8_t *p = r433_host_alloc(cap);
-    if (!p)
-        hip_fatal("pinned staging buffer");
+    uint8_t *p = stage_alloc(cap);
     if (H.stage_len)
         memcpy(p, H.stage, H.stage_len);
-    r433_host_free(H.stage);
-    if (trace_on())
-        fprintf(stderr, "hip flow: staging buffer grown to %zu MiB in %.1f ms\n", cap >> 20, trace_now() - t_grow);
+    stage_free(H.stage);
     H.stage     = p;
     H.stage_cap = cap;
 }
@@ -274,6 +372,7 @@ static hip_capture *capture_open(r_cfg_t *cfg)
         if (!H.caps)
             FATAL_REALLOC("hip captures");
     }
+    warm_start(); /* (the first push of the process: the GPU is opened beside the file loop) */
     hip_capture *c = &H.caps[H.n_caps++];
     memset(c, 0, sizeof(*c));
     c->in_filename      = cfg->in_filename;
@@ -535,14 +634,15 @@ static void engine_config(r_cfg_t *cfg, hip_capture const *c, r433_flow_cfg *fc)
     fc->input_format     = capture_input_format(c);
 }
 
-static void engine_ensure(r_cfg_t *cfg, r433_flow_cfg const *fc)
+static void engine_ensure(r_cfg_t *cfg, r433_flow_cfg const *fc, int lane)
 {
     struct dm_state *demod = cfg->demod;
+    warm_join(); /* (the first GPU call of the process is made below) */
     void *first            = demod->r_devs.len ? demod->r_devs.elems[0] : NULL;
     hip_engine *slot       = NULL;
     for (int k = 0; k < HIP_ENGINES; ++k) {
         hip_engine *e = &H.engines[k];
-        if (e->eng && memcmp(fc, &e->cfg, sizeof(*fc)) == 0 && e->devs == demod->r_devs.len && e->first_dev == first && e->lane == H.lane) {
+        if (e->eng && memcmp(fc, &e->cfg, sizeof(*fc)) == 0 && e->devs == demod->r_devs.len && e->first_dev == first && e->lane == lane) {
             e->used = ++H.eng_clock;
             H.cur   = e;
             H.eng   = e->eng;
@@ -588,7 +688,7 @@ static void engine_ensure(r_cfg_t *cfg, r433_flow_cfg const *fc)
     slot->devs      = n;
     slot->first_dev = first;
     slot->used      = ++H.eng_clock;
-    slot->lane      = H.lane;
+    slot->lane      = lane;
     H.cur           = slot;
     H.eng           = slot->eng;
 }
@@ -804,7 +904,7 @@ static int run_group(r_cfg_t *cfg, hip_capture *group, size_t n)
     struct dm_state *demod = cfg->demod;
     r433_flow_cfg fc;
     engine_config(cfg, &group[0], &fc);
-    engine_ensure(cfg, &fc);
+    engine_ensure(cfg, &fc, H.lane);
 
     void const **ptrs = malloc(n * sizeof(*ptrs));
     uint32_t *bytes   = malloc(n * sizeof(*bytes));
@@ -854,6 +954,7 @@ static int run_group(r_cfg_t *cfg, hip_capture *group, size_t n)
     }
     double const t_probe = trace_now();
     engine_prefilter(cfg);
+    stage_pin(H.stage);
     double const t_run = trace_now();
     int n_pkgs = r433_batch_run_host(H.eng, ptrs, bytes, (uint32_t)n);
     if (trace_on())
@@ -974,9 +1075,20 @@ static int same_group(r_cfg_t *cfg, hip_capture const *a, hip_capture const *b)
    a thread (its own engine, its own pinned buffer), and its replay happens at the NEXT drain -- in list order, on the calling
    thread, as ever.  Only for the plain case: one flow configuration in the queue, no dumper, no sample grabber, no -E.
    RTL433_HIP_OVERLAP=0 turns it off, =1 takes every pass (tests); by default passes of 512 captures and more. */
+static void engine_prefilter(r_cfg_t *cfg);
+
 static void *pass_thread(void *arg)
 {
     (void)arg;
+    /* Everything of the pass that talks to the GPU happens here, the wait for the device's opening included (the first pass of
+       a process): the file loop's thread is back at its files meanwhile.  It touches neither the engines nor H.eng / H.cur
+       before it has joined this thread (the next drain). */
+    engine_ensure(P.cfg, &P.fc, P.lane);
+    r433_batch_enable_logic_dump(H.eng, 0);
+    r433_batch_set_taps(H.eng, NULL, NULL, NULL, 0);
+    engine_prefilter(P.cfg);
+    P.eng = H.eng;
+    stage_pin(P.stage);
     P.n_pkgs = r433_batch_run_host(P.eng, P.ptrs, P.bytes, (uint32_t)P.n);
     if (P.n_pkgs < 0)
         snprintf(P.err, sizeof(P.err), "%s", r433_last_error());
@@ -1008,13 +1120,10 @@ static int pass_may_overlap(r_cfg_t *cfg, size_t n_run)
 /* the queue leaves for the GPU on a thread of its own; H gets an empty queue and the other pinned buffer */
 static void pass_start(r_cfg_t *cfg, size_t n)
 {
-    r433_flow_cfg fc;
-    engine_config(cfg, &H.caps[0], &fc);
-    engine_ensure(cfg, &fc); /* (the engine of H.lane) */
-    r433_batch_enable_logic_dump(H.eng, 0);
-    r433_batch_set_taps(H.eng, NULL, NULL, NULL, 0);
-    engine_prefilter(cfg);
-    P.eng   = H.eng;
+    engine_config(cfg, &H.caps[0], &P.fc);
+    P.cfg   = cfg;
+    P.lane  = H.lane; /* (the engine of this lane: made or found by the pass's own thread) */
+    P.eng   = NULL;
     P.ptrs  = malloc(n * sizeof(*P.ptrs));
     P.bytes = malloc(n * sizeof(*P.bytes));
     if (!P.ptrs || !P.bytes)
@@ -1072,7 +1181,7 @@ static int pass_replay(r_cfg_t *cfg, pending_pass *d)
     /* its pinned buffer (if the queue after it has not taken it already) serves a later queue */
     if (d->stage) {
         if (H.spare_stage)
-            r433_host_free(H.spare_stage);
+            stage_free(H.spare_stage);
         H.spare_stage = d->stage;
         H.spare_cap   = d->stage_cap;
     }
@@ -1210,6 +1319,7 @@ int hip_sdr_flow_drain(struct r_cfg *cfg)
     int const nested = H.final_drain;
     H.final_drain    = 1; /* pass_may_overlap() says no: nothing is handed to a thread from here */
     int const events = drain_queue(cfg);
+    warm_join(); /* (a list that was all empty files never made a GPU call: the opening thread is not left behind) */
     H.final_drain    = nested;
     return events;
 }

@@ -148,6 +148,11 @@ int r433_batch_set_split(r433_batch *b, uint32_t segment_samples);
 int r433_batch_set_exclusive_detect(r433_batch *b, int on);
 /* of the last run: wavefront slots planned (segments incl. parity variants), pieces run again after a dropped cut */
 int r433_batch_split_stats(r433_batch *b, uint32_t *segments, uint32_t *pieces_rerun);
+/* How the last detection pass was launched: 45 = the producers of the grid (filters; filtered tiles to HBM) and its consumers
+ * (detector) as two launches, plus a third for the captures that have to run again with every tile filtered (their number is
+ * what r433_batch_split_stats reports as pieces_rerun then); 0 = one launch, the roles of a capture in one workgroup.  Results
+ * do not depend on it (R433_DEBUG_SPLIT_ROLES / R433_DEBUG_NO_SPLIT_ROLES choose; default: grids of 6144 captures and more). */
+int r433_batch_detect_form(r433_batch *b);
 
 /* Kernel timing of the last run measured with HIP events on the caller's stream (ms). */
 typedef struct r433_batch_timing {
@@ -188,6 +193,8 @@ int r433_batch_debug_state(r433_batch *b, void *host_buf, size_t bytes);
 #define R433_DEBUG_SKEW_SLICE 1048576u /* ... and shares by a made-up skew, however small the launch (tests) */
 #define R433_DEBUG_NO_LAZY 262144u /* the detection kernel filters every tile, also those that provably cannot move the detector: same results, for A/B timing */
 #define R433_DEBUG_NO_TRAIN_ENGINE 2048u /* in-package legs through the older per-leg code: same results, for A/B timing */
+#define R433_DEBUG_SPLIT_ROLES 4194304u    /* the detection pass as a launch of producers (filters; filtered tiles to HBM) and a launch of consumers (detector) whatever the size of the grid (default: from 6144 captures on); same results (tests, A/B timing) */
+#define R433_DEBUG_NO_SPLIT_ROLES 8388608u /* ... never: producer / consumer pairs in one workgroup as in round 4 (A/B timing) */
 int r433_batch_set_debug(r433_batch *b, uint32_t flags);
 int r433_batch_get_timing(r433_batch *b, r433_batch_timing *t);
 

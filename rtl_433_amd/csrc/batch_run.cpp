@@ -558,6 +558,13 @@ int run_stitch(RunCtx &r, StreamParams const &sp)
 
 // envelope, filters, pulse detection: packages per slot in the arena (grown and repeated if it overflows)
 constexpr uint32_t kOrderFrom = 2048; // captures in a grid from which on their order is worth a look (1536 pairs fit the chip at once)
+// Captures in a grid from which on the two roles of a capture run as two launches (stream_kernels.hip FORM 4 / FORM 5; measured:
+// 4096 captures 2.02 ms as pairs / 2.39 ms as two launches, 8192 captures 3.71 / 3.44, profiles/r05_b_split_roles.txt): below,
+// a launch lasts as long as its slowest capture and the pair's overlap of filters and detector is what shortens that; above,
+// the grid is several rounds deep and what counts is how many CONSUMERS the chip holds at once (three to a SIMD instead of
+// one and a half).  The tile records are 8.4 KB per tile of 2048 samples: at most kRolesStoreMax bytes of HBM per engine.
+constexpr uint32_t kRolesFrom = 6144;
+constexpr uint64_t kRolesStoreMax = 12ull << 30;
 
 int run_detect(RunCtx &r)
 {
@@ -596,6 +603,24 @@ int run_detect(RunCtx &r)
             sp.wg_slot = b->d_wg.p;
             sp.n_wgs = r.n_streams;
         }
+        if (!r.split && !(b->debug_flags & R433_DEBUG_NO_SPLIT_ROLES) && (r.n_streams >= kRolesFrom || (b->debug_flags & R433_DEBUG_SPLIT_ROLES))) {
+            uint32_t const tiles_cap = (uint32_t)((r.stride_bytes / r.ss + kTileSamples - 1) / kTileSamples);
+            uint64_t const store = (uint64_t)r.n_streams * tiles_cap * kTileRecBytes;
+            if (tiles_cap && store <= kRolesStoreMax) {
+                size_t const n = r.n_streams;
+                if ((rc = b->d_tile_store.ensure(store)) || (rc = b->d_tile_desc.ensure(n * tiles_cap)) || (rc = b->d_tile_words.ensure(4 * n + 4)))
+                    return rc;
+                sp.flags |= RUN_SPLIT_ROLES;
+                sp.tile_store = b->d_tile_store.p;
+                sp.tile_desc = b->d_tile_desc.p;
+                sp.tiles_cap = tiles_cap;
+                sp.tile_over = (int *)b->d_tile_words.p;
+                sp.tile_info = b->d_tile_words.p + n;
+                sp.retry_count = b->d_tile_words.p + 2 * n;
+                sp.retry_list = b->d_tile_words.p + 2 * n + 4;
+                sp.retry_why = b->d_tile_words.p + 3 * n + 4;
+            }
+        }
         if (r.split) {
             HIP_TRY(hipMemcpyAsync(b->d_segs.p, r.segs.data(), r.segs.size() * sizeof(SegDesc), hipMemcpyHostToDevice, r.st));
             sp.segs = b->d_segs.p;
@@ -604,8 +629,11 @@ int run_detect(RunCtx &r)
             sp.wg_slot = b->d_wg.p;
             sp.n_wgs = (uint32_t)wgs.size();
         }
-        launch_stream(sp, r.ss, r.st);
+        b->last_roles = launch_stream(sp, r.ss, r.st);
         HIP_TRY(hipGetLastError());
+        b->h_scal.p[8] = 0;
+        if (b->last_roles) // how many captures the run-again launch took (r433_batch_split_stats)
+            HIP_TRY(hipMemcpyAsync(b->h_scal.p + 8, sp.retry_count, sizeof(uint32_t), hipMemcpyDeviceToHost, r.st));
         if (r.split && (rc = run_stitch(r, sp)))
             return rc;
         if (b->profiling && attempt == 0)
@@ -615,6 +643,8 @@ int run_detect(RunCtx &r)
         HIP_TRY(hipMemcpyAsync(b->h_scal.p, b->d_scal.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, r.st));
         HIP_TRY(stream_wait(b, r.st));
         r.total_pkgs = b->h_scal.p[0];
+        if (b->last_roles)
+            b->last_redone = b->h_scal.p[8];
         leg_stamp(b, "detected");
         if (!b->h_scal.p[1])
             break;

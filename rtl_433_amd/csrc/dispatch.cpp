@@ -686,7 +686,7 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
             free(bits);
         });
         if (corrupt_at.load() != SIZE_MAX)
-            return fail(R433_EHIP, "corrupt event stream at byte %zu", corrupt_at.load());
+            break; // (decoders have run: what they handed out is committed below, in order, before the call reports the stream)
         if (trace)
             fprintf(stderr, "r.dispatch: level %u, %zu decoders in %zu items on %u threads %.3f ms\n", level, devs_of_level.size(), items.size(), nt, since(t_level));
     }
@@ -702,7 +702,7 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
                     dev_count[by[k] + 1] - dev_count[by[k]]);
         fprintf(stderr, "\n");
     }
-    if (by_slice && !failed.load()) { // every slice has been walked once: that was every record of the stream
+    if (by_slice && !failed.load() && corrupt_at.load() == SIZE_MAX) { // every slice has been walked once: that was every record of the stream
         b->n_events = (uint32_t)walked.load();
         b->events_counted = true;
     }
@@ -777,6 +777,8 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
         fprintf(stderr, "r.dispatch: commit %.3f ms, whole replay %.3f ms\n", since(t_commit), since(t_begin));
     if (failed.load())
         return fail(R433_EDECODER, "%s", err.c_str());
+    if (corrupt_at.load() != SIZE_MAX) // (nothing a decoder made is left behind: its outputs went out above, its statistics are booked)
+        return fail(R433_EHIP, "corrupt event stream at byte %zu", corrupt_at.load());
     apply_prefilter_counts(b, devices, n_devices);
     return decoded;
 }

@@ -270,6 +270,9 @@ void r433_batch_destroy(r433_batch *b)
     b->d_tile_max.release();
     b->d_order.release();
     b->d_wg.release();
+    b->d_tile_store.release();
+    b->d_tile_desc.release();
+    b->d_tile_words.release();
     b->d_idx_cnt.release();
     b->d_slice_start.release();
     b->d_slices.release();
@@ -400,6 +403,13 @@ int r433_batch_split_stats(r433_batch *b, uint32_t *segments, uint32_t *pieces_r
     if (pieces_rerun)
         *pieces_rerun = b->last_redone;
     return 0;
+}
+
+int r433_batch_detect_form(r433_batch *b)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    return b->last_roles ? 45 : 0;
 }
 
 int r433_batch_set_profiling(r433_batch *b, int on)

@@ -230,10 +230,15 @@ struct r433_batch {
     PinBuf<uint8_t> h_logic;
     uint64_t logic_stride = 0;
     DevBuf<uint32_t> d_tile_max, d_order, d_wg;
+    // producers and consumers as two launches (StreamParams::tile_store ...): tile records, descriptors, per-slot words, run-again list
+    DevBuf<uint8_t> d_tile_store;
+    DevBuf<int> d_tile_desc;
+    DevBuf<uint32_t> d_tile_words; // [n] over, [n] info, [1] count (+ 3 unused), [n] list, [n] why
     DevBuf<SegDesc> d_segs;
     PinBuf<uint32_t> h_tile_max;
     PinBuf<StreamState> h_state;
     uint32_t last_segments = 0, last_redone = 0;
+    bool last_roles = false; // the last detection pass ran producers and consumers as two launches (r433_batch_detect_form)
     DevBuf<uint32_t> d_dir_stream, d_dir_off, d_rec_bytes, d_rec_off, d_sizes, d_dev_off, d_pkg_bytes, d_pkg_off;
     // the slice index (slicer_kernels.hip k_index_*): per decoder the (offset, bytes) of its slices of the event stream
     DevBuf<uint32_t> d_idx_cnt, d_slice_start;

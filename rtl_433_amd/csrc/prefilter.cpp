@@ -237,7 +237,7 @@ void probe_tiny(r433_r_device *dev, std::vector<uint8_t> &tab, bool &useful, boo
         return;
     unsigned tiny_bits = kTinyBits;
     if (char const *e = getenv("R433_PROBE_TINY_BITS")) // development: cost / yield of the exhaustive part
-        tiny_bits = (unsigned)std::min(atoi(e), (int)kTinyBits);
+        tiny_bits = (unsigned)std::max(0, std::min(atoi(e), (int)kTinyBits)); // (a negative value asks nothing)
     (void)accepts; // (a tiny row it takes is a length left alone, nothing more: unlike a bare head it had the content to go on)
     for (unsigned n = 0; n <= tiny_bits; ++n) {
         if (tab[1 * kPfBits + n] != kPfKeep)
@@ -254,6 +254,12 @@ void probe_tiny(r433_r_device *dev, std::vector<uint8_t> &tab, bool &useful, boo
                 bits->bb[0][0] = (uint8_t)(msb >> 8);
                 bits->bb[0][1] = (uint8_t)msb;
                 int const ret = dev->decode_fn(dev, bits);
+                // a decoder that added or extracted rows before it refused (bitbuffer_add_row, an in-place expansion) must not
+                // leave them for the next question: every row its num_rows / free_row reach is cleared, as the replay's
+                // call_one does between two real bitbuffers (dispatch.cpp); the head and row 0 are rewritten above anyway
+                unsigned const reached = std::min<unsigned>(std::max<unsigned>(bits->num_rows, bits->free_row), R433_BITBUF_ROWS);
+                if (reached > 1)
+                    memset(bits->bb[1], 0, (size_t)(reached - 1) * R433_BITBUF_COLS);
                 if (ret > 0 || ret < R433_DECODE_FAIL_SANITY)
                     same = false;
                 else if (code == INT_MIN)

@@ -72,7 +72,14 @@ enum : uint32_t {
     RUN_ONE_WAVE = 4096u, // development: one wavefront per capture does phases A+B and C in turn (A/B timing, same results)
     RUN_NO_TRAIN_ENGINE = 2048u, // development: in-package legs through the older per-leg code (A/B timing, same results)
     RUN_NO_LAZY = 262144u,       // development: every tile filtered, also the ones that provably cannot move the detector (A/B timing, same results)
+    RUN_SPLIT_ROLES = 524288u,   // launch_stream: producers and consumers as two launches over StreamParams::tile_store (set by the host where it pays; development: forced / forbidden)
+    RUN_RETRY_PASS = 1048576u,   // (set by launch_stream) the run-again launch behind such a pass: pair kernel, every tile filtered, over retry_list
 };
+
+// what a filtered tile hands from the producers' launch to the consumers' (stream_kernels.hip): 2048 filtered envelope samples,
+// 2048 filtered discriminator samples (int16 each), the extrema of the 64 chunks of the envelope (int16 max, int16 min)
+constexpr uint32_t kTileSamples = 2048;
+constexpr uint32_t kTileRecBytes = 2 * kTileSamples * 2 + 2 * 64 * 2;
 
 struct StreamParams {
     uint8_t const *iq;            // n_streams captures, stride_bytes apart (16-byte aligned)
@@ -113,9 +120,24 @@ struct StreamParams {
     // one byte per sample, n_streams * logic_stride bytes, zeroed by the host before the launch
     uint8_t *logic;
     uint64_t logic_stride;
+    // Producers and consumers as two launches (RUN_SPLIT_ROLES; nullptr: not available, launch_stream keeps them in one
+    // workgroup): per (slot, tile) a record of kTileRecBytes and a descriptor word; per slot what the producer has to tell
+    // the consumer beside them (a refused filter carry; attempts | reasons << 8), and the list of the slots whose consumer
+    // found that the capture cannot be carried across its unfiltered tiles (run again by a third launch, every tile filtered).
+    uint8_t *tile_store;          // n_streams * tiles_cap * kTileRecBytes
+    int *tile_desc;               // n_streams * tiles_cap
+    uint32_t tiles_cap;
+    int *tile_over;               // n_streams
+    uint32_t *tile_info;          // n_streams
+    uint32_t *retry_count;        // device scalar, zeroed by launch_stream
+    uint32_t *retry_list;         // n_streams
+    uint32_t *retry_why;          // n_streams
+    uint32_t const *wg_count;     // (the run-again launch) workgroups at and beyond *wg_count leave at once
 };
 
-void launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st);
+// -> true: the pass went out as a launch of producers, a launch of consumers and the run-again launch (RUN_SPLIT_ROLES asked for
+// it and nothing -- taps, logic dump, pieces, sample files that are not IQ -- stood against it)
+bool launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st);
 // phases A + B only, one frame, state in and out: the function-level seam of include/baseband.h
 void launch_filters(StreamParams const &p, uint32_t sample_size, hipStream_t st);
 

@@ -12,6 +12,12 @@
 //                                  sample: it completes the seam -- the reference's own src/r_flow.c links and decodes
 //                                  over it, `make -C dropin refflow` -- and is no fast path; that is push_sdr_flow)
 //
+//   include/r_api.h:50-52          run_ook_demods / run_fsk_demods (src/r_api.c:438-550): the decoder fan-out of ONE package as ONE
+//                                  launch -- every registered decoder's slicer over the package (r433_batch_run_pulses) and
+//                                  the replay in the reference's order (priority levels, registration order, account_event:
+//                                  r433_batch_dispatch_hooks) -- where the reference's own loop over the ten pulse_slicer_*
+//                                  exports above is one launch and one round trip per DECODER
+//
 // Every function is a thin host wrapper: host pointers in, the work on the GPU through librtl433hip.so's C ABI
 // (r433_envelope_host, r433_filter_frame, r433_batch_run_pulses + r433_batch_dispatch), host pointers out.  Nothing is
 // computed here.  A per-call round trip over PCIe makes these slower than the CPU code they replace -- they exist so the
@@ -338,6 +344,118 @@ static int slice_one(pulse_data_t const *pulses, r_device *device, unsigned modu
 }
 
 } // namespace
+
+// ---- include/r_api.h:50-52: the fan-out of one package over every registered decoder ----
+
+typedef struct list { // include/list.h:18-22
+    void **elems;
+    size_t size;
+    size_t len;
+} list_t;
+
+namespace {
+
+struct FanoutEngine {
+    uint32_t rate;
+    std::vector<r433_dev_timing> rows; // what the decoders of the list looked like when the engine was made
+    r433_batch *b;
+};
+static std::vector<FanoutEngine> g_fanouts;
+
+// account_event names the slicer that made the bitbuffer (src/pulse_slicer.c:26-66 is handed __func__)
+static char const *slicer_name(unsigned modulation)
+{
+    switch (modulation) {
+    case 3: case 18: return "pulse_slicer_manchester_zerobit";
+    case 4: case 16: return "pulse_slicer_pcm";
+    case 5: return "pulse_slicer_ppm";
+    case 6: case 17: return "pulse_slicer_pwm";
+    case 8: return "pulse_slicer_piwm_raw";
+    case 9: return "pulse_slicer_dmc";
+    case 10: return "pulse_slicer_osv1";
+    case 11: return "pulse_slicer_piwm_dc";
+    case 12: return "pulse_slicer_nrzs";
+    case 13: return "pulse_slicer_rzi";
+    default: return "pulse_slicer";
+    }
+}
+
+static void on_fanout_event(void *, r433_r_device *dev, int ret, r433_bitbuffer const *bits)
+{
+    EventHook hook = {slicer_name(dev->modulation)};
+    on_event(&hook, dev, ret, bits);
+}
+
+static int run_demods(list_t *r_devs, pulse_data_t const *pulse_data, bool fsk, char const *func)
+{
+    uint32_t const rate = pulse_data->sample_rate;
+    if (!r_devs || rate == 0)
+        return 0;
+    std::vector<r433_r_device *> devs;
+    std::vector<r433_dev_timing> rows;
+    for (void **iter = r_devs->elems; iter && *iter; ++iter) {
+        r_device *d = (r_device *)*iter;
+        // (the reference reports these from inside its loop, once per priority level it walks: src/r_api.c:494,546)
+        bool const known = (d->modulation >= 3 && d->modulation <= 6) || (d->modulation >= 8 && d->modulation <= 13) || (d->modulation >= 16 && d->modulation <= 18);
+        if (!known)
+            fprintf(stderr, "Unknown modulation %u in protocol!\n", d->modulation);
+        r433_dev_timing row;
+        memset(&row, 0, sizeof(row));
+        row.modulation = d->modulation;
+        row.short_width = d->short_width;
+        row.long_width = d->long_width;
+        row.reset_limit = d->reset_limit;
+        row.gap_limit = d->gap_limit;
+        row.sync_width = d->sync_width;
+        row.tolerance = d->tolerance;
+        row.priority = d->priority;
+        devs.push_back(d);
+        rows.push_back(row);
+    }
+    if (devs.empty())
+        return 0;
+    r433_batch *b = nullptr;
+    for (auto &e : g_fanouts)
+        if (e.rate == rate && e.rows.size() == rows.size() && memcmp(e.rows.data(), rows.data(), rows.size() * sizeof(rows[0])) == 0)
+            b = e.b;
+    if (!b) {
+        if (g_fanouts.size() >= 8) { // (a host that keeps changing its decoders: the oldest engine goes)
+            r433_batch_destroy(g_fanouts.front().b);
+            g_fanouts.erase(g_fanouts.begin());
+        }
+        r433_flow_cfg cfg;
+        r433_flow_cfg_default(&cfg, 2, rate);
+        b = r433_batch_create(&cfg, rows.data(), (uint32_t)rows.size());
+        if (!b)
+            die(func);
+        g_fanouts.push_back({rate, rows, b});
+    }
+    // The package's kind is the caller's statement, not the package's (src/r_flow.c:292-309 hands its OOK list to
+    // run_ook_demods and its FSK list to run_fsk_demods whatever estimates they carry): r433_batch_run_pulses reads it off
+    // fsk_f2_est like the `.ook` file loop does (src/rtl_433.c:1774), so the copy says what the caller said.
+    static pulse_data_t copy;
+    copy = *pulse_data;
+    if (!fsk)
+        copy.fsk_f2_est = 0;
+    else if (copy.fsk_f2_est == 0)
+        copy.fsk_f2_est = 1;
+    if (r433_batch_run_pulses(b, &copy, 1, NULL) < 0)
+        die(func);
+    r433_dispatch_hooks hooks = {NULL, NULL, on_fanout_event, NULL, NULL, NULL};
+    int const events = r433_batch_dispatch_hooks(b, devs.data(), (uint32_t)devs.size(), &hooks);
+    if (events == R433_EDECODER) {
+        fprintf(stderr, "%s: %s: notify maintainer\n", func, r433_last_error()); // src/pulse_slicer.c:44-47
+        exit(1);
+    }
+    if (events < 0)
+        die(func);
+    return events;
+}
+
+} // namespace
+
+int run_ook_demods(list_t *r_devs, pulse_data_t *pulse_data) { return run_demods(r_devs, pulse_data, false, __func__); } // src/r_api.c:438-500
+int run_fsk_demods(list_t *r_devs, pulse_data_t *fsk_pulse_data) { return run_demods(r_devs, fsk_pulse_data, true, __func__); } // src/r_api.c:502-550
 
 // enum modulation_types, include/r_device.h:24-40 (the OOK number selects the slicer; FSK packages take the same code)
 int pulse_slicer_pcm(pulse_data_t const *pulses, r_device *device) { return slice_one(pulses, device, 4, __func__); }

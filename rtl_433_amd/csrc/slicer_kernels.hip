@@ -588,7 +588,7 @@ void launch_slice_count(SliceParams const &p_in, uint32_t grid_pkgs, hipStream_t
             DealShares d;
             share_out(d.first, chunks, grid.x, p.chunk_deal && shares ? shares + 16 * which : nullptr, least);
             ++which;
-            q->deal_grid = d.first[chunks] == grid.x ? grid.x : 0u;
+            q->deal_grid = chunks <= 16 && d.first[chunks] == grid.x ? grid.x : 0u; // (first[] has 17 entries: more chunks get no deal)
             if (q->deal_grid)
                 hipLaunchKernelGGL(k_deal, dim3((grid.x + 255) / 256), dim3(256), 0, st, d, chunks, grid.x, q->chunk_deal);
         }
@@ -614,7 +614,7 @@ void launch_slice_count(SliceParams const &p_in, uint32_t grid_pkgs, hipStream_t
     SliceParams one = p;
     DealShares d;
     share_out(d.first, chunks, grid.x, p.draw && p.chunk_deal ? shares : nullptr, least);
-    one.deal_grid = d.first[chunks] == grid.x ? grid.x : 0u;
+    one.deal_grid = chunks <= 16 && d.first[chunks] == grid.x ? grid.x : 0u;
     if (one.deal_grid)
         hipLaunchKernelGGL(k_deal, dim3((grid.x + 255) / 256), dim3(256), 0, st, d, chunks, grid.x, one.chunk_deal);
     if (p.stage)

@@ -59,6 +59,11 @@ constexpr int kHead = 512;                  // ... and how far into the next til
 constexpr int kQuietTile = (int)0x80000000, kPostQuiet = 0x40000000;
 constexpr int kPitchOut = kChunk * 2;       // filtered samples: time-linear, read by sample index (the padded pitch buys
                                              // nothing there and 8 wavefronts' LDS must fit one CU: 8 x 20 KB = 160 KB)
+// FORM 4 -> FORM 5 (the two roles as two kernels): what a tile hands from the filters to the detector, per (capture, tile)
+// in HBM -- the filtered envelope and discriminator as the consumer reads them (2 x 64 chunks x 64 bytes, time-linear), the
+// per-chunk extrema of the filtered envelope (64 + 64 shorts) -- and one descriptor word per tile beside it (quiet | bound ...)
+constexpr int kTileRecAm = 0, kTileRecFm = 64 * kPitchOut, kTileRecMax = 2 * 64 * kPitchOut, kTileRecMin = kTileRecMax + 128;
+static_assert(kTileRecMin + 128 == (int)kTileRecBytes, "the tile record of r433_internal.hpp");
 
 __device__ __forceinline__ int rl0(int v)
 {
@@ -294,17 +299,34 @@ __device__ __forceinline__ void ema_groups(v2s &x, int rot, int nb)
 // capture, which exist in two parity variants of the assumed noise floor: the filters do not depend on the variant.
 // Separate kernels, because the forms want different register budgets: in a pair or a triple a wavefront runs one role
 // only and fits three to a SIMD, the lone wavefront carries both roles' state across the tile loop.
+// FORM 4 and FORM 5 (round 5): the two roles of a pair as TWO LAUNCHES of one-wavefront workgroups.  A producer of a pair
+// idles 60 % of its time at the tile barrier once most tiles go by unfiltered, and holds a wavefront slot (and its share of
+// the LDS) while it does: of the three wavefronts a SIMD holds, one and a half are consumers.  FORM 4 runs the producers
+// alone -- nobody to wait for -- and leaves every tile's filtered samples, chunk extrema and descriptor in HBM
+// (StreamParams::tile_store / tile_desc: 8.4 KB per FILTERED tile written once and read once; the chip's HBM is at 3 % of
+// its bandwidth in this kernel, its issue slots are what is scarce); FORM 5 runs the consumers alone, three to a SIMD, each
+// copying a filtered tile into its own 8 KB of LDS and walking it as ever.  A capture whose unfiltered tiles cannot be
+// carried exactly (st_retry in the pair) is started over by the producer itself where the producer finds out, and put on
+// StreamParams::retry_list where the consumer does: a third launch (the pair kernel, every tile filtered, workgroups
+// that find nothing on the list leave at once) runs those again.
+#ifndef R433_CONSUMER_WAVES
+#define R433_CONSUMER_WAVES 3
+#endif
+#ifndef R433_PRODUCER_WAVES
+#define R433_PRODUCER_WAVES 4
+#endif
 #ifdef R433_EMU
 #define R433_WAVES_PER_SIMD(n)
 #else
 #define R433_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #endif
-template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global__ __launch_bounds__(FORM * 64)
-        R433_WAVES_PER_SIMD(FORM == 1 ? 2 : 3) void k_wave(StreamParams p) // (cs16 at 168 VGPRs spills a dozen dwords; at two per SIMD and 208 VGPRs a 64 Mi-sample stream took 10.4 ms against 8.1)
+template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global__ __launch_bounds__((FORM >= 4 ? 1 : FORM) * 64)
+        R433_WAVES_PER_SIMD(FORM == 1 ? 2 : FORM == 4 ? (SS == 4 && FM ? 3 : R433_PRODUCER_WAVES) : FORM == 5 ? R433_CONSUMER_WAVES : 3) void k_wave(StreamParams p) // (cs16 at 168 VGPRs spills a dozen dwords; at two per SIMD and 208 VGPRs a 64 Mi-sample stream took 10.4 ms against 8.1)
 {
     using G = Geom<SS>;
+    constexpr bool to_hbm = FORM == 4, from_hbm = FORM == 5; // the producers / the consumers of a grid as a launch of their own
     __shared__ __attribute__((aligned(16))) uint8_t s_env[64 * kPitch16];
-    __shared__ __attribute__((aligned(16))) uint8_t s_f[64 * G::f_pitch];
+    __shared__ __attribute__((aligned(16))) uint8_t s_f[from_hbm ? 16 : 64 * G::f_pitch]; // (the consumers never stage a discriminator)
     // Two wavefronts per capture when launched with 128 threads: wavefront 0 PRODUCES (phases A + B of tile t + 1 into
     // buffer (t + 1) & 1) while wavefront 1 CONSUMES (phase C of tile t from buffer t & 1); one workgroup barrier per tile.
     // The two sit on different SIMDs of the CU (a workgroup's wavefronts are dealt out round-robin), each next to a
@@ -335,23 +357,29 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
     int const lane = (int)threadIdx.x & 63;
     int const wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6); // (a scalar: the role branches below are scalar branches)
     constexpr bool solo = FORM == 1; // one wavefront does both halves
-    uint8_t *const s_am = s_tiles, *const s_fm = s_tiles + (solo ? 1 : 2) * (64 * kPitchOut);
+    constexpr bool lone = FORM == 1 || FORM >= 4; // workgroups of one wavefront: one tile buffer, no workgroup barriers
+    uint8_t *const s_am = s_tiles, *const s_fm = s_tiles + (lone ? 1 : 2) * (64 * kPitchOut);
     // am.s16 / fm.s16 input files (RUN_AM_IS_INPUT / RUN_FM_IS_INPUT; the launch adds the room): the tile's words as they came
-    uint8_t *const s_raw = s_tiles + (solo ? 2 : 4) * (64 * kPitchOut);
+    uint8_t *const s_raw = s_tiles + (lone ? 2 : 4) * (64 * kPitchOut);
     bool const raw_in = SS == 2 && !SEAM && (p.flags & (RUN_AM_IS_INPUT | RUN_FM_IS_INPUT)) != 0;
     // role 0 produces, role 1 consumes.  Workgroups alternate which wavefront takes which role, so that the two wavefronts
     // that end up on one SIMD are one of each kind, and the consumer -- the serial critical path -- issues first.
-    int const role = solo ? 0 : FORM == 3 ? (wave + (int)(blockIdx.x % 3u)) % 3
-                                          : (wave ^ ((p.flags & RUN_NO_ROLE_SWAP) ? 0 : (int)(blockIdx.x & 1u)));
-    if (!solo && role != 0 && !(p.flags & RUN_NO_PRIO))
+    int const role = lone ? (from_hbm ? 1 : 0) : FORM == 3 ? (wave + (int)(blockIdx.x % 3u)) % 3
+                                                           : (wave ^ ((p.flags & RUN_NO_ROLE_SWAP) ? 0 : (int)(blockIdx.x & 1u)));
+    if (!lone && role != 0 && !(p.flags & RUN_NO_PRIO))
         __builtin_amdgcn_s_setprio(3);
+    // the run-again launch behind a FORM 4 / FORM 5 pass: workgroups beyond the list the consumers left have nothing to do
+    if (FORM == 2 && p.wg_count && blockIdx.x >= *p.wg_count)
+        return;
     if (threadIdx.x == 0) {
         s_pover = 0;
         st_desc(0) = st_desc(1) = 0;
         st_retry(0) = st_retry(1) = 0;
     }
-    if (!solo)
+    if (!lone)
         __syncthreads(); // (whichever wavefront produces may raise these flags in its first tile)
+    else
+        wave_sync();
     // workgroup = one capture, or one piece of a split capture (in both parity variants: consumers 1 and 2 of a triple)
     uint32_t const wg = p.wg_slot ? p.wg_slot[blockIdx.x] : blockIdx.x;
     bool const idle = FORM == 3 && role == 2 && !(wg >> 31); // a triple whose piece has one variant only: the third wavefront just keeps the barriers
@@ -375,6 +403,10 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
     uint32_t const tile_first = seg_first ? 0u : seg_start / kTile - 1u;
     uint32_t const tile_end = (seg_end + kTile - 1) / kTile;
     int seg_fail = 0, seg_init_low = 0, seg_init_high = 0;
+    // FORM 4 / FORM 5: this capture's tile records and descriptors in HBM
+    uint8_t *const g_tiles = (to_hbm || from_hbm) ? p.tile_store + (uint64_t)s * p.tiles_cap * kTileRecBytes : nullptr;
+    int *const g_desc = (to_hbm || from_hbm) ? p.tile_desc + (uint64_t)s * p.tiles_cap : nullptr;
+    int self_retry = 0; // FORM 4: the producer found that the capture cannot be carried across its unfiltered tiles
 
     // ---- detector: wave-uniform.  Every lane carries the same scalar state and takes the same
     // branches, in the fast paths and in the general step alike; lane 0 alone touches the arena and
@@ -423,6 +455,10 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
     int lz_fail = 0;             // why the capture has to run again (the codes of r433_batch_debug_state: 4.. the consumer's)
     int retry_why = 0;
     int p_fail = 0, p_over = 0;  // producer side of seg_fail / det.overflow
+    if (FORM == 2 && (p.flags & RUN_RETRY_PASS)) { // the run-again launch behind a FORM 4 / FORM 5 pass: what the first attempt found
+        attempts = 1;
+        retry_why = (int)p.retry_why[s];
+    }
 
     // (Two of them: what a role keeps across tiles must be dead in the other role's loop, or the pair kernel does not fit its
     // 168 registers -- with one shared start-over loop every scalar of both roles was alive around its back edge, the
@@ -580,7 +616,14 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
         uint32_t const t0 = tile * kTile;                        // absolute sample index of the tile
         int const n_t = (int)min((uint32_t)kTile, seg_end - t0); // valid samples in it
         bool const warm = !seg_first && tile == tile_first;      // the establishing tile of a later segment
-        uint8_t *const p_am = s_am + buf * (64 * kPitchOut), *const p_fm = s_fm + buf * (64 * kPitchOut);
+        uint8_t *const p_am = to_hbm ? g_tiles + (uint64_t)tile * kTileRecBytes + kTileRecAm : s_am + buf * (64 * kPitchOut);
+        uint8_t *const p_fm = to_hbm ? g_tiles + (uint64_t)tile * kTileRecBytes + kTileRecFm : s_fm + buf * (64 * kPitchOut);
+        auto put_desc = [&](int d) { // (lane 0)
+            if (to_hbm)
+                g_desc[tile] = d;
+            else
+                st_desc(buf) = d;
+        };
         int p_retry = 0;
         bool const post_q = lazy && prev_quiet;  // the tile before went by unfiltered: this one's first kVirtual samples are taken by their bound
         bool const est = lazy && !carry_known;   // ... and left the two filter states unknown: every lane warms up from extremes
@@ -733,7 +776,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                 prev_quiet = true;
                 prev_bound = qmax;
                 if (lane == 0)
-                    st_desc(buf) = kQuietTile | qmax;
+                    put_desc(kQuietTile | qmax);
                 issue_loads(tile + 1, true);
                 issue_head(tile + 2);
                 return;
@@ -1181,15 +1224,29 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
             if (post_q && lane < kVirtual / kChunk) // the consumer never looks at these samples
                 cmax = vbound, cmin = 0;
             if (lane == 0) {
-                st_desc(buf) = post_q ? (kPostQuiet | vbound) : 0;
-                if (p_retry)
+                put_desc(post_q ? (kPostQuiet | vbound) : 0);
+                if (p_retry && !to_hbm)
                     st_retry(retry_slot) = p_retry;
             }
+            if (to_hbm)
+                self_retry |= p_retry;
         }
-        st_cmax(buf, lane) = (short)max(cmax, -32768); // (an empty chunk keeps its sentinels, clamped to 16 bits)
-        st_cmin(buf, lane) = (short)min(cmin, 32767);
-        if (p_over && lane == 0)
-            s_pover = p_over;
+        else if (to_hbm && lane == 0) {
+            put_desc(0);
+        }
+        if (to_hbm) {
+            short *const ext = (short *)(g_tiles + (uint64_t)tile * kTileRecBytes);
+            ext[kTileRecMax / 2 + lane] = (short)max(cmax, -32768);
+            ext[kTileRecMin / 2 + lane] = (short)min(cmin, 32767);
+            if (p_over && lane == 0)
+                p.tile_over[s] = p_over;
+        }
+        else {
+            st_cmax(buf, lane) = (short)max(cmax, -32768); // (an empty chunk keeps its sentinels, clamped to 16 bits)
+            st_cmin(buf, lane) = (short)min(cmin, 32767);
+            if (p_over && lane == 0)
+                s_pover = p_over;
+        }
 
         if (warm) {
             // ---- establishing tile of a later segment: no detection here.  The carries just taken must be
@@ -2400,7 +2457,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
     // before the barrier after the next -- and start the capture over with every tile filtered.)
     // what both roles do between two attempts: everybody has seen the flag, it is cleared, every tile is filtered from now on
     auto start_over = [&]() {
-        if (!solo)
+        if (!lone)
             __syncthreads();
         if (threadIdx.x == 0) {
             st_retry(0) = st_retry(1) = 0;
@@ -2409,12 +2466,69 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
         }
         lazy = false;
         attempts += 1;
-        if (solo)
+        if (lone)
             wave_sync();
         else
             __syncthreads();
     };
-    if constexpr (solo) {
+    if constexpr (to_hbm) {
+        // ---- the producers of a grid as a launch of their own: every tile's record and descriptor to HBM, nobody to wait for
+        for (;;) {
+            init_producer();
+            self_retry = 0;
+            if (lane == 0)
+                p.tile_over[s] = 0;
+            issue_loads(tile_first);
+            if (lazy)
+                issue_head(tile_first + 1u);
+            for (uint32_t tile = tile_first; tile < tile_end && !self_retry; ++tile)
+                produce(tile, 0);
+            if (!self_retry)
+                break;
+            retry_why |= self_retry; // (carries that do not settle after unfiltered tiles: again, every tile filtered)
+            lazy = false;
+            attempts += 1;
+        }
+        if (lane == 0)
+            p.tile_info[s] = (uint32_t)attempts | ((uint32_t)retry_why << 8);
+        return;
+    }
+    else if constexpr (from_hbm) {
+        // ---- the consumers of a grid as a launch of their own, behind the producers' launch
+        init_consumer();
+        for (uint32_t tile = tile_first; tile < tile_end; ++tile) {
+            int const desc = uni(g_desc[tile]);
+            if (lane == 0)
+                st_desc(0) = desc;
+            if (!(desc & kQuietTile)) { // a filtered tile: its record into this wavefront's LDS, laid out as a pair's buffer 0
+                uint8_t const *const rec = g_tiles + (uint64_t)tile * kTileRecBytes;
+#pragma unroll
+                for (int k = 0; k < 2 * 64 * kPitchOut / 1024; ++k)
+                    *(uint4 *)(s_tiles + k * 1024 + lane * 16) = *(uint4 const *)(rec + k * 1024 + lane * 16);
+                st_cmax(0, lane) = ((short const *)rec)[kTileRecMax / 2 + lane];
+                st_cmin(0, lane) = ((short const *)rec)[kTileRecMin / 2 + lane];
+            }
+            wave_sync();
+            consume(tile, 0);
+            wave_sync(); // (the tile is done with before the next one's record lands on it)
+            if (lz_fail) {
+                // the capture cannot be carried exactly across its unfiltered tiles: onto the list of the run-again launch
+                if (lane == 0) {
+                    uint32_t const at = atomicAdd(p.retry_count, 1u);
+                    p.retry_list[at] = s;
+                    p.retry_why[s] = (uint32_t)lz_fail;
+                }
+                return; // (that launch writes this capture's state and packages afresh)
+            }
+        }
+        uint32_t const info = p.tile_info[s];
+        attempts = (int)(info & 0xffu);
+        retry_why = (int)(info >> 8);
+        if (lane == 0)
+            s_pover = p.tile_over[s];
+        wave_sync();
+    }
+    else if constexpr (solo) {
         for (;;) {
             init_consumer();
             init_producer();
@@ -2612,10 +2726,10 @@ __global__ __launch_bounds__(64) void k_gather_packages(uint8_t const *arena, ui
 
 } // namespace
 
-void launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st)
+bool launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st)
 {
     if (p.n_streams == 0)
-        return;
+        return false;
     // Two wavefronts per capture (producer + consumer), three of them to a SIMD (the pair kernel is built for 168 VGPRs, a
     // workgroup's 26 KB of LDS make six workgroups to a CU): 1536 captures in flight.  One wavefront doing both in turn needs
     // the registers of both roles (two to a SIMD, 2048 captures in flight) and only wins where exactly that many more
@@ -2626,8 +2740,12 @@ void launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st)
     // split captures come with their workgroup list: a producer and (where a piece has both parity variants) two consumers
     // (a workgroup list without pieces is only an order: launch_capture_order)
     bool const triple = p.wg_slot != nullptr && p.segs != nullptr && !(p.flags & RUN_ONE_WAVE);
+    // the two roles as two launches (FORM 4, FORM 5) and a third for what has to run again: whole captures only, no taps,
+    // no logic dump, IQ input
+    bool const split_roles = (p.flags & RUN_SPLIT_ROLES) && p.tile_store && !p.segs && !p.tap_env && !p.tap_am && !p.logic
+            && !(p.flags & (RUN_AM_IS_INPUT | RUN_FM_IS_INPUT | RUN_ENV_RAW16 | RUN_ONE_WAVE | RUN_DBG_TIMING));
     dim3 grid(p.wg_slot ? p.n_wgs : p.n_streams), block(triple ? 192 : pair ? 128 : 64);
-    uint32_t const lds = (pair || triple ? 4u : 2u) * 64u * (uint32_t)kPitchOut // the tile buffers (s_tiles)
+    uint32_t lds = (pair || triple ? 4u : 2u) * 64u * (uint32_t)kPitchOut // the tile buffers (s_tiles)
             + ((p.flags & (RUN_AM_IS_INPUT | RUN_FM_IS_INPUT)) ? 64u * (uint32_t)kPitch16 : 0u); // + s_raw
     // FAST: no filter step can wrap and both feedback coefficients are non-negative (see Track16).
     // The AM filter always qualifies (13993 + 2*1195 <= 16384); the FM filter does for every cutoff
@@ -2638,30 +2756,62 @@ void launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st)
     else
         fast = !p.enable_fm || (p.a32 >= 0 && p.b32 >= 0 && p.a32 + 2 * p.b32 <= (1ll << 30));
     bool const fm = p.enable_fm != 0;
-#define R433_LAUNCH_WAVE(SS, FORM)                                                                                     \
+#define R433_LAUNCH_WAVE(SS, FORM, P)                                                                                  \
     do {                                                                                                               \
         if (fast && fm)                                                                                                \
-            hipLaunchKernelGGL((k_wave<SS, true, true, false, FORM>), grid, block, lds, st, p);                          \
+            hipLaunchKernelGGL((k_wave<SS, true, true, false, FORM>), grid, block, lds, st, P);                          \
         else if (fast)                                                                                                 \
-            hipLaunchKernelGGL((k_wave<SS, true, false, false, FORM>), grid, block, lds, st, p);                         \
+            hipLaunchKernelGGL((k_wave<SS, true, false, false, FORM>), grid, block, lds, st, P);                         \
         else if (fm)                                                                                                   \
-            hipLaunchKernelGGL((k_wave<SS, false, true, false, FORM>), grid, block, lds, st, p);                         \
+            hipLaunchKernelGGL((k_wave<SS, false, true, false, FORM>), grid, block, lds, st, P);                         \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_wave<SS, false, false, false, FORM>), grid, block, lds, st, p);                        \
+            hipLaunchKernelGGL((k_wave<SS, false, false, false, FORM>), grid, block, lds, st, P);                        \
     } while (0)
-    if (sample_size == 2 && triple)
-        R433_LAUNCH_WAVE(2, 3);
+    if (split_roles) {
+        (void)hipMemsetAsync(p.retry_count, 0, sizeof(uint32_t), st);
+        block = dim3(64);
+        lds = 0; // the producers stage in the static arrays only
+        if (sample_size == 2)
+            R433_LAUNCH_WAVE(2, 4, p);
+        else
+            R433_LAUNCH_WAVE(4, 4, p);
+        lds = 2u * 64u * (uint32_t)kPitchOut; // the consumers: one tile
+        if (sample_size == 2)
+            R433_LAUNCH_WAVE(2, 5, p);
+        else
+            R433_LAUNCH_WAVE(4, 5, p);
+        // what a consumer could not carry across its unfiltered tiles runs again as a pair, every tile filtered (the frame
+        // sums were added by the first launch); a grid of the chip's size, strided over the list by further launches only if
+        // it ever were longer (it never is: one capture in tens of thousands)
+        StreamParams q = p;
+        q.flags = (p.flags | RUN_NO_LAZY | RUN_RETRY_PASS) & ~(uint32_t)RUN_SPLIT_ROLES;
+        q.frame_sums = nullptr;
+        q.wg_slot = p.retry_list;
+        q.n_wgs = p.n_streams;
+        q.wg_count = p.retry_count;
+        grid = dim3(p.n_streams);
+        block = dim3(128);
+        lds = 4u * 64u * (uint32_t)kPitchOut;
+        if (sample_size == 2)
+            R433_LAUNCH_WAVE(2, 2, q);
+        else
+            R433_LAUNCH_WAVE(4, 2, q);
+        return true;
+    }
+    else if (sample_size == 2 && triple)
+        R433_LAUNCH_WAVE(2, 3, p);
     else if (sample_size == 2 && pair)
-        R433_LAUNCH_WAVE(2, 2);
+        R433_LAUNCH_WAVE(2, 2, p);
     else if (sample_size == 2)
-        R433_LAUNCH_WAVE(2, 1);
+        R433_LAUNCH_WAVE(2, 1, p);
     else if (triple)
-        R433_LAUNCH_WAVE(4, 3);
+        R433_LAUNCH_WAVE(4, 3, p);
     else if (pair)
-        R433_LAUNCH_WAVE(4, 2);
+        R433_LAUNCH_WAVE(4, 2, p);
     else
-        R433_LAUNCH_WAVE(4, 1);
+        R433_LAUNCH_WAVE(4, 1, p);
 #undef R433_LAUNCH_WAVE
+    return false;
 }
 
 void launch_filters(StreamParams const &p, uint32_t sample_size, hipStream_t st)

@@ -176,7 +176,7 @@ class BatchEngine:
     def split_stats(self):
         a, b = C.c_uint32(), C.c_uint32()
         _lib.check(self.L.r433_batch_split_stats(self.h, C.byref(a), C.byref(b)), "r433_batch_split_stats", self.L)
-        return dict(segments=a.value, pieces_rerun=b.value)
+        return dict(segments=a.value, pieces_rerun=b.value, detect_form=_lib.check(self.L.r433_batch_detect_form(self.h), "r433_batch_detect_form", self.L))
 
     def enable_taps(self, n_streams, n_samples):
         import torch

@@ -67,7 +67,7 @@ def test_the_timed_path_does_not_know_the_checker():
     src = open(BENCH).read()
     assert "_RefPlugins" not in src
     funcs = re.split(r"\n(?=def |class )", src)
-    allowed = ("def _ref_worker_init", "def cpu_baseline_config2", "def cpu_baseline_real_decoders", "def real_decoders_leg", "def run_batched",
+    allowed = ("def _ref_worker_init", "def cpu_baseline_config2", "def cpu_baseline_real_decoders", "def real_decoders_leg", "def run_batched", "def dropin_legs",
                "def run_stream", '"""bench.py')
     for f in funcs:
         if "pyoracle" in f or "_ref/" in f.split('"""')[-1]:

@@ -319,6 +319,23 @@ def test_reference_flow_over_the_function_seam(binary, tmp_path):
         ref = run_cli(REF, args, tmp_path)
         assert ref.count("\n") >= 5
         assert run_cli(binary, args, tmp_path) == ref
+    # run_ook_demods / run_fsk_demods (include/r_api.h:50-52) are the seam's too: the reference's r_flow.c hands every package
+    # to librtl433seam.so, which runs ALL registered decoders' slicers over it in one launch and replays them in the
+    # reference's order -- with every default decoder registered (335 slicers per package; one launch and one round trip
+    # EACH through the pulse_slicer_* exports, which is what this binary did before)
+    syms = subprocess.run(["nm", binary], stdout=subprocess.PIPE).stdout.decode()
+    assert " U run_ook_demods" in syms and " U run_fsk_demods" in syms
+    import time
+    args = ["-r", "o_433.92M_250k.cu8", "-r", "g001_433.92M_250k.cu8", "-r", "f_433.92M_250k.cu8"] + FLEX + ["-F", "json", "-M", "level", "-K", "FILE"]
+    ref = run_cli(REF, args, tmp_path)  # (no -R: every default decoder is registered, the three generic ones behind them)
+    t0 = time.perf_counter()
+    got = run_cli(binary, args, tmp_path)
+    dt = time.perf_counter() - t0
+    assert got == ref and ref.count("\n") >= 5
+    out = os.path.join(ROOT, "gpurun_out")
+    if binary == HIP_REFFLOW and os.path.isdir(out):
+        with open(os.path.join(out, "refflow_seam_timing.txt"), "a") as f:
+            f.write(f"rtl_433_refflow_hip, three captures, all default decoders, fan-out through the seam's run_ook_demods / run_fsk_demods: {dt * 1e3:.0f} ms\n")
 
 
 OPTION_SETS = [

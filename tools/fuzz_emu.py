@@ -87,6 +87,7 @@ def make_capture(rng, ss, rate):
     return out
 
 
+STATS = {"cases": 0, "roles": 0, "run_again": 0}  # cases run, of them as two launches, captures their run-again launch took
 BIG = False  # --gpu: some cases are captures long enough for the automatic split (>= 2^20 samples)
 
 
@@ -155,6 +156,9 @@ def one_case(seed, run=None):
         form |= 1048576  # R433_DEBUG_SKEW_SLICE: the chunks of devices get unequal shares of the sizing pass's workgroups
     if seed % 13 == 6:
         form |= 131072  # R433_DEBUG_ONE_SLICE_LAUNCH: the slicers' sizing pass as one launch instead of large / small packages apart
+    if seed % 4 == 2 and not (form & 4096):
+        form |= 4194304  # R433_DEBUG_SPLIT_ROLES: producers and consumers as two launches over tile records in HBM (+ the run-again launch)
+    form |= int(os.environ.get("R433_FUZZ_DEBUG", "0"), 0)  # (exploring: a switch for every case of a sweep)
     # One case in three with the sample taps; without them the detection kernel leaves tiles that cannot move the detector
     # unfiltered (lazy tiles), and the per-frame envelope sums are compared instead.
     taps = seed % 3 == 0
@@ -175,6 +179,9 @@ def one_case(seed, run=None):
         pk += o["packages"]
         ev += o["events"]
         base += o["n_packages"]
+    STATS["cases"] += 1
+    STATS["roles"] += int(g.get("split", {}).get("detect_form", 0) == 45)
+    STATS["run_again"] += int(g.get("split", {}).get("pieces_rerun", 0)) if g.get("split", {}).get("detect_form", 0) == 45 else 0
     if g["packages"][0] != pk:
         return f"packages differ ({g['n_packages']} vs {base})"
     if g["events"][0] != ev:
@@ -226,4 +233,4 @@ if __name__ == "__main__":
             print(f"seed {seed}: {r}", flush=True)
         if (seed - first + 1) % 50 == 0:
             print(f"... {seed - first + 1} cases, {len(bad)} failures so far, {time.time() - t0:.0f} s", flush=True)
-    print(f"{n_cases} cases, {len(bad)} failures {bad} in {time.time() - t0:.0f} s")
+    print(f"{n_cases} cases, {len(bad)} failures {bad} in {time.time() - t0:.0f} s; {STATS}")

@@ -64,7 +64,8 @@ for r in range(a.reps):
     n = eng.run(ds[r % len(ds)])
     ts.append(eng.timing())
 best = min(ts, key=lambda t: t["detect_ms"])
-print("detect_ms per rep:", [round(t["detect_ms"], 3) for t in ts])
+import zlib
+print("detect_ms per rep:", [round(t["detect_ms"], 3) for t in ts], "packages crc %08x" % zlib.crc32(eng.packages()[0]), eng.split_stats())
 print(f"flags={a.debug} streams={a.streams} samples={a.samples} pkgs={n} " +
       " ".join(f"{k}={v:.3f}" for k, v in best.items()) + (f" split={eng.split_stats()}" if a.split else ""))
 
