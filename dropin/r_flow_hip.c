@@ -70,6 +70,7 @@
 #include "r433_hip.h"
 
 #include <pthread.h>
+#include <sys/mman.h>
 
 /* the three structs that cross the boundary are the reference's own (include/r433_abi.h mirrors them) */
 _Static_assert(sizeof(r433_r_device) == sizeof(r_device), "r_device layout");
@@ -223,14 +224,28 @@ static double trace_now(void)
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
+static double g_t_loaded; /* when this translation unit was loaded: the process's start, near enough */
+static void trace_exit(void);
+__attribute__((constructor)) static void trace_loaded(void)
+{
+    g_t_loaded = trace_now();
+}
+
 static int trace_on(void)
 {
     static int on = -1;
     if (on < 0) {
         char const *e = getenv("RTL433_HIP_TRACE");
         on            = e && *e && *e != '0';
+        if (on)
+            atexit(trace_exit);
     }
     return on;
+}
+
+static void trace_exit(void)
+{
+    fprintf(stderr, "hip flow: exit handlers begin %.1f ms after the program was loaded\n", trace_now() - g_t_loaded);
 }
 
 static void hip_fatal(char const *what)
@@ -267,7 +282,8 @@ static void warm_join(void)
         W.joined = 1;
         pthread_join(W.thread, NULL);
         if (trace_on())
-            fprintf(stderr, "hip flow: GPU opened and kernels loaded on a thread of their own, ready %.1f ms after the first push\n", trace_now() - W.t0);
+            fprintf(stderr, "hip flow: [%.1f ms] GPU opened and kernels loaded on a thread of their own (started at the first push, %.1f ms)\n",
+                    trace_now() - g_t_loaded, W.t0 - g_t_loaded);
     }
 }
 
@@ -301,6 +317,11 @@ static uint8_t *stage_alloc(size_t cap)
     void *p = NULL;
     if (posix_memalign(&p, (size_t)2 << 20, cap) != 0 || !p)
         FATAL_MALLOC("hip staging buffer");
+#ifdef MADV_HUGEPAGE
+    /* (fresh memory is faulted in by the file loop's own copies: 65 536 faults per 256 MiB in 4 KiB pages -- the first two
+       passes' worth of files took 70 ms to read against 25 ms later --, 128 in 2 MiB pages where the system grants them) */
+    (void)madvise(p, cap, MADV_HUGEPAGE);
+#endif
     pthread_mutex_lock(&g_stage_lock);
     for (int k = 0; k < STAGE_BUFFERS; ++k)
         if (!g_stage_buf[k].p) {
@@ -634,7 +655,9 @@ static void engine_config(r_cfg_t *cfg, hip_capture const *c, r433_flow_cfg *fc)
     fc->input_format     = capture_input_format(c);
 }
 
-static void engine_ensure(r_cfg_t *cfg, r433_flow_cfg const *fc, int lane)
+/* the engine of a flow configuration and a lane: found or made.  Touches H.engines only (the thread of a pass in flight calls it
+   for its own lane while the file loop's thread replays the pass before: H.cur / H.eng are the caller's to set) */
+static hip_engine *engine_get(r_cfg_t *cfg, r433_flow_cfg const *fc, int lane)
 {
     struct dm_state *demod = cfg->demod;
     warm_join(); /* (the first GPU call of the process is made below) */
@@ -644,9 +667,7 @@ static void engine_ensure(r_cfg_t *cfg, r433_flow_cfg const *fc, int lane)
         hip_engine *e = &H.engines[k];
         if (e->eng && memcmp(fc, &e->cfg, sizeof(*fc)) == 0 && e->devs == demod->r_devs.len && e->first_dev == first && e->lane == lane) {
             e->used = ++H.eng_clock;
-            H.cur   = e;
-            H.eng   = e->eng;
-            return;
+            return e;
         }
         /* where a new engine would go: the first empty place, else the one that rested longest */
         if (!slot || (slot->eng && (!e->eng || e->used < slot->used)))
@@ -689,8 +710,13 @@ static void engine_ensure(r_cfg_t *cfg, r433_flow_cfg const *fc, int lane)
     slot->first_dev = first;
     slot->used      = ++H.eng_clock;
     slot->lane      = lane;
-    H.cur           = slot;
-    H.eng           = slot->eng;
+    return slot;
+}
+
+static void engine_ensure(r_cfg_t *cfg, r433_flow_cfg const *fc, int lane)
+{
+    H.cur = engine_get(cfg, fc, lane);
+    H.eng = H.cur->eng;
 }
 
 /* The replay is quiet and spread over threads (see the dispatch below): then no hook looks at single decoder calls, and the
@@ -706,7 +732,7 @@ static int replay_is_chatty(struct dm_state *demod)
     return 0;
 }
 
-static void engine_prefilter(r_cfg_t *cfg)
+static void engine_prefilter_of(r_cfg_t *cfg, hip_engine *cur)
 {
     struct dm_state *demod = cfg->demod;
     char const *env        = getenv("RTL433_HIP_PREFILTER");
@@ -717,15 +743,20 @@ static void engine_prefilter(r_cfg_t *cfg)
        half-way.  So: from 8 GiB of samples on, or when told to (RTL433_HIP_PREFILTER=1; =0: never). */
     int const worth        = (env && env[0] == '1') || H.staged_total >= ((size_t)1 << 33);
     int const want         = !(env && env[0] == '0') && worth && !H.sync_active && replay_threads() > 1 && !replay_is_chatty(demod) && demod->r_devs.len;
-    if (want && !H.cur->probed) {
-        H.cur->probed = 1;
-        int const t   = r433_batch_probe_prefilter(H.eng, (r433_r_device *const *)demod->r_devs.elems, (uint32_t)demod->r_devs.len);
+    if (want && !cur->probed) {
+        cur->probed = 1;
+        int const t = r433_batch_probe_prefilter(cur->eng, (r433_r_device *const *)demod->r_devs.elems, (uint32_t)demod->r_devs.len);
         if (t < 0)
             hip_fatal("r433_batch_probe_prefilter");
-        H.cur->tables = t;
+        cur->tables = t;
     }
-    if (H.cur->tables > 0 && r433_batch_set_prefilter(H.eng, want) < 0)
+    if (cur->tables > 0 && r433_batch_set_prefilter(cur->eng, want) < 0)
         hip_fatal("r433_batch_set_prefilter");
+}
+
+static void engine_prefilter(r_cfg_t *cfg)
+{
+    engine_prefilter_of(cfg, H.cur);
 }
 
 /* -E quit / -E hop: src/rtl_433.c:1136-1143 acts on the events of each push, so a push cannot be left for later.  The capture as
@@ -1075,19 +1106,17 @@ static int same_group(r_cfg_t *cfg, hip_capture const *a, hip_capture const *b)
    a thread (its own engine, its own pinned buffer), and its replay happens at the NEXT drain -- in list order, on the calling
    thread, as ever.  Only for the plain case: one flow configuration in the queue, no dumper, no sample grabber, no -E.
    RTL433_HIP_OVERLAP=0 turns it off, =1 takes every pass (tests); by default passes of 512 captures and more. */
-static void engine_prefilter(r_cfg_t *cfg);
-
 static void *pass_thread(void *arg)
 {
     (void)arg;
     /* Everything of the pass that talks to the GPU happens here, the wait for the device's opening included (the first pass of
-       a process): the file loop's thread is back at its files meanwhile.  It touches neither the engines nor H.eng / H.cur
-       before it has joined this thread (the next drain). */
-    engine_ensure(P.cfg, &P.fc, P.lane);
-    r433_batch_enable_logic_dump(H.eng, 0);
-    r433_batch_set_taps(H.eng, NULL, NULL, NULL, 0);
-    engine_prefilter(P.cfg);
-    P.eng = H.eng;
+       a process): the file loop's thread is back at its files meanwhile, and at the next drain it replays the pass before
+       this one through H.eng / H.cur -- which this thread therefore leaves alone: its engine is in `mine` and P.eng. */
+    hip_engine *const mine = engine_get(P.cfg, &P.fc, P.lane);
+    r433_batch_enable_logic_dump(mine->eng, 0);
+    r433_batch_set_taps(mine->eng, NULL, NULL, NULL, 0);
+    engine_prefilter_of(P.cfg, mine);
+    P.eng = mine->eng;
     stage_pin(P.stage);
     P.n_pkgs = r433_batch_run_host(P.eng, P.ptrs, P.bytes, (uint32_t)P.n);
     if (P.n_pkgs < 0)
@@ -1210,7 +1239,8 @@ static int drain_queue(struct r_cfg *cfg)
     static double t_last_drain;
     double const t_drain = trace_now();
     if (trace_on())
-        fprintf(stderr, "hip flow: %zu captures queued over %.1f ms (since the start / the pass before)\n", n_run, t_last_drain ? t_drain - t_last_drain : 0.0);
+        fprintf(stderr, "hip flow: [%.1f ms] %zu captures queued over %.1f ms (since the start / the pass before)\n", t_drain - g_t_loaded, n_run,
+                t_last_drain ? t_drain - t_last_drain : 0.0);
     if (pass_may_overlap(cfg, n_run)) {
         /* this queue to the GPU, THEN the replay of the pass before it -- beside it */
         if (P.active)

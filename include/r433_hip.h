@@ -105,6 +105,14 @@ int r433_batch_run(r433_batch *b, void const *d_iq, uint64_t stride_bytes, uint3
  * memory works.  Returns the number of packages. */
 void *r433_host_alloc(size_t bytes);
 void r433_host_free(void *p);
+/* ... or memory of the host's own, page-locked in place (0 = done): 13-15 ms per 256 MiB of touched memory where allocating the
+ * same pinned costs 46-60 ms, and it can be done late, on the thread that starts the pass (dropin/r_flow_hip.c stages into
+ * plain memory and registers a buffer the first time a pass reads from it).  Unregister before the memory is freed. */
+int r433_host_register(void *p, size_t bytes);
+int r433_host_unregister(void *p);
+/* Opens the device and loads the library's kernels (what the first call of a process otherwise pays: 70-280 ms), so that a host
+ * can do it on a thread beside its own start-up.  0, or R433_ENODEV / R433_EHIP. */
+int r433_warmup(void);
 int r433_batch_run_host(r433_batch *b, void const *const *h_captures, uint32_t const *capture_bytes, uint32_t n_captures);
 
 /* Host views of the last run (valid until the next run/destroy). */

@@ -1021,6 +1021,29 @@ void r433_host_free(void *p)
         (void)hipHostFree(p);
 }
 
+int r433_host_register(void *p, size_t bytes)
+{
+    if (!p || !bytes)
+        return fail(R433_EINVAL, "nothing to register");
+    hipError_t const e = hipHostRegister(p, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(e == hipErrorNoDevice ? R433_ENODEV : R433_EHIP, "hipHostRegister(%zu bytes): %s", bytes, hipGetErrorString(e));
+    }
+    return 0;
+}
+
+int r433_host_unregister(void *p)
+{
+    if (!p)
+        return 0;
+    if (hipHostUnregister(p) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(R433_EHIP, "hipHostUnregister");
+    }
+    return 0;
+}
+
 int r433_batch_run_host(r433_batch *b, void const *const *h_captures, uint32_t const *capture_bytes, uint32_t n_captures)
 {
     if (!b)

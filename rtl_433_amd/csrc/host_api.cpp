@@ -147,6 +147,32 @@ float r433_level_db(uint32_t sum, uint32_t n, int is_magnitude)
 
 r433_batch *r433_batch_create_on(int device, r433_flow_cfg const *cfg, r433_dev_timing const *devs, uint32_t n_devs);
 
+namespace {
+__global__ void k_warm(int *p)
+{
+    if (p)
+        *p = 1;
+}
+} // namespace
+
+// What a process pays once before its first kernel has run -- opening the device (50-130 ms on the MI355X boxes), loading this
+// library's code object (20-150 ms at the first launch) -- as a call of its own, so that a host can make it on a thread beside
+// its file loop (dropin/r_flow_hip.c does).
+int r433_warmup(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(R433_ENODEV, "no HIP device");
+    }
+    hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, nullptr, (int *)nullptr);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(R433_EHIP, "the library's kernels do not load on this device");
+    }
+    return 0;
+}
+
 r433_batch *r433_batch_create(r433_flow_cfg const *cfg, r433_dev_timing const *devs, uint32_t n_devs)
 {
     int cur = 0;

@@ -252,6 +252,8 @@ hipError_t hipFree(void *p)
 }
 hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
 hipError_t hipHostFree(void *p) { return hipFree(p); }
+hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; } // (the emulator's device reads host memory as it is)
+hipError_t hipHostUnregister(void *) { return hipSuccess; }
 hipError_t hipMemcpy(void *d, void const *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void *d, void const *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }

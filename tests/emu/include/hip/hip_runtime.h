@@ -234,6 +234,9 @@ hipError_t hipMalloc(void **p, size_t n);
 hipError_t hipFree(void *p);
 hipError_t hipHostMalloc(void **p, size_t n, unsigned flags);
 hipError_t hipHostFree(void *p);
+enum { hipHostRegisterPortable = 1 };
+hipError_t hipHostRegister(void *p, size_t n, unsigned flags);
+hipError_t hipHostUnregister(void *p);
 hipError_t hipMemcpy(void *d, void const *s, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void *d, void const *s, size_t n, hipMemcpyKind k, hipStream_t st);
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t st);
