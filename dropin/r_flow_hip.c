@@ -705,6 +705,29 @@ static hip_engine *engine_get(r_cfg_t *cfg, r433_flow_cfg const *fc, int lane)
     free(rows);
     if (!slot->eng)
         hip_fatal("r433_batch_create");
+    /* Which of these decoders keep nothing between two calls: the ordered replay may then spread one decoder's calls over its
+       threads instead of keeping each decoder on one (a busy TPMS decoder alone was most of a replay).  The program that
+       registered the decoders is the one that knows: of the reference's, four keep state in file-scope statics
+       (src/devices/secplus_v1.c:142-143, secplus_v2.c:260-266, ikea_sparsnas.c:92, arad_ms_meter.c:256), and everything made by
+       a create_fn (flex decoders among them) or carrying a decode_ctx owns a context.  A name of the list that is not among
+       the registered decoders while its neighbours are means the list is stale: then nobody is declared stateless. */
+    {
+        static char const *const stateful[] = {"Security+ (Keyfob)", "Security+ 2.0 (Keyfob)", "IKEA Sparsnas Energy Meter Monitor",
+                "Arad/Master Meter Dialog3G water utility meter"};
+        uint8_t *flags = calloc(n ? n : 1, 1);
+        if (!flags)
+            FATAL_CALLOC("hip stateless flags");
+        for (size_t i = 0; i < n; ++i) {
+            r_device const *d = demod->r_devs.elems[i];
+            int keeps         = d->decode_ctx != NULL || d->create_fn != NULL || !d->decode_fn;
+            for (size_t k = 0; k < sizeof(stateful) / sizeof(stateful[0]); ++k)
+                keeps |= d->name && strcmp(d->name, stateful[k]) == 0;
+            flags[i] = keeps ? 0 : 1;
+        }
+        if (r433_batch_set_stateless(slot->eng, flags, (uint32_t)n) < 0)
+            hip_fatal("r433_batch_set_stateless");
+        free(flags);
+    }
     slot->cfg       = *fc;
     slot->devs      = n;
     slot->first_dev = first;

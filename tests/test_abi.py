@@ -94,3 +94,28 @@ def test_public_headers_are_plain_c_and_mirrors_match(tmp_path):
     want = [C.sizeof(_lib.Analysis), C.sizeof(_lib.Histogram), C.sizeof(_lib.Grab), C.sizeof(_lib.PulseData), C.sizeof(_lib.FlowCfg),
             _lib.Analysis.device.offset, _lib.Grab.byte_len.offset, C.sizeof(_lib.DevTimingRow)]
     assert got == want
+
+
+def test_the_stateful_decoder_lists_match_the_reference_sources():
+    """dropin/plugins_shim.c and dropin/r_flow_hip.c tell the library which decoders keep nothing between two calls
+    (r433_batch_set_stateless: their calls may then run on several replay threads) from a list of the ones that DO.  Held to
+    the reference's sources where the tree is present: a decoder whose file has a mutable static (file scope or inside a
+    function) must be on both lists under its registered name, and nothing else is."""
+    import glob
+    import re
+    ref = "/root/reference/src/devices"
+    if not os.path.isdir(ref):
+        pytest.skip("no reference tree here")
+    keeps = set()
+    for path in glob.glob(os.path.join(ref, "*.c")):
+        src = open(path, errors="replace").read()
+        mutable = [l for l in src.splitlines() if re.match(r"^\s*static\s+(?!const\b)[^()]*(=|;)\s*(//.*)?$", l) and "const" not in l]
+        if mutable:
+            keeps |= set(re.findall(r"\.name\s*=\s*\"([^\"]+)\"", src))
+    assert len(keeps) >= 4
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for user in ("dropin/plugins_shim.c", "dropin/r_flow_hip.c"):
+        src = open(os.path.join(root, user)).read()
+        m = re.search(r"static char const \*const stateful\[\] = \{(.*?)\};", src, re.S)
+        assert m, user
+        assert set(re.findall(r"\"([^\"]+)\"", m.group(1))) == keeps, user
