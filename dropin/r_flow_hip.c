@@ -287,16 +287,38 @@ static void warm_join(void)
     }
 }
 
+/* At exit() the GPU runtime's library destructors give back, piece by piece, what the kernel reclaims in one go when the
+   process is gone: device memory of the engines, a gigabyte of page-locked host memory, queues, code objects -- 100-180 ms at
+   the end of a 0.5 s run over 8192 files.  The program has written and closed its outputs by then (src/rtl_433.c:1861-1866:
+   close_dumpers, r_free_cfg before main returns; the reference registers no exit handler of its own), so the flow's handler
+   flushes what stdio still holds and leaves through _exit() with the program's own status.  RTL433_HIP_FAST_EXIT=0: the
+   long way. */
+static void flow_exit(int status, void *arg)
+{
+    (void)arg;
+    warm_join(); /* (a process that leaves without a drain must not exit under a thread that is opening the device) */
+    char const *e = getenv("RTL433_HIP_FAST_EXIT");
+    if (e && *e == '0')
+        return;
+    if (trace_on())
+        fprintf(stderr, "hip flow: [%.1f ms] leaving through _exit(%d)\n", trace_now() - g_t_loaded, status);
+    fflush(NULL);
+    _exit(status);
+}
+
 static void warm_start(void)
 {
+    static int exit_hooked;
+    if (!exit_hooked) {
+        exit_hooked = 1;
+        on_exit(flow_exit, NULL);
+    }
     char const *e = getenv("RTL433_HIP_WARM");
     if (W.started || (e && *e == '0'))
         return;
     W.t0 = trace_now();
-    if (pthread_create(&W.thread, NULL, warm_thread, NULL) == 0) {
+    if (pthread_create(&W.thread, NULL, warm_thread, NULL) == 0)
         W.started = 1;
-        atexit(warm_join); /* (a process that leaves without a drain must not exit under a thread that is opening the device) */
-    }
 }
 
 /* Staging buffers are plain memory: the file loop's thread fills them without a word to the GPU.  A buffer is REGISTERED with
@@ -705,6 +727,8 @@ static hip_engine *engine_get(r_cfg_t *cfg, r433_flow_cfg const *fc, int lane)
     free(rows);
     if (!slot->eng)
         hip_fatal("r433_batch_create");
+    if (getenv("RTL433_HIP_DEBUG")) /* development: R433_DEBUG_* switches of include/r433_hip.h for every engine of the flow (32: the replay's own trace) */
+        (void)r433_batch_set_debug(slot->eng, (uint32_t)strtoul(getenv("RTL433_HIP_DEBUG"), NULL, 0));
     /* Which of these decoders keep nothing between two calls: the ordered replay may then spread one decoder's calls over its
        threads instead of keeping each decoder on one (a busy TPMS decoder alone was most of a replay).  The program that
        registered the decoders is the one that knows: of the reference's, four keep state in file-scope statics

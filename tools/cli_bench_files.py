@@ -15,6 +15,6 @@ args = [a for f in names for a in ("-r", f)] + ["-F", "json", "-M", "level", "-K
 cli = os.path.join(bench.ROOT, "dropin", "_build", "rtl_433_hip")
 for rep in range(4):
     t0 = time.perf_counter()
-    p = subprocess.run([cli] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, RTL433_HIP_TRACE="1" if rep == 3 else "0"))
+    p = subprocess.run([cli] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, RTL433_HIP_TRACE="1" if rep == 3 else "0", **({"RTL433_HIP_DEBUG": "32"} if rep == 3 else {})))
     print(f"rep {rep}: {(time.perf_counter() - t0) * 1e3:.0f} ms, {p.stdout.count(10)} lines")
 print(p.stderr.decode(errors="replace"))
