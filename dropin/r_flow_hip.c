@@ -137,6 +137,10 @@ static struct {
     int warned_grab_mode;
     int32_t *quality;   /* -S undecoded: pulse_analyzer_check's verdict on every package of the pass nobody decoded */
     size_t quality_cap, quality_n;
+    r433_analysis *analysis; /* -A: the pulse analyzer's histograms and guess for every package of the pass (r433_batch_analyze: one launch) */
+    size_t analysis_cap, analysis_n;
+    char *text;         /* what the library renders for a package: the analyzer's report, a `.ook` record, VCD lines */
+    size_t text_cap;
     /* answering every push at once (-E: the file loop acts on the event count of a push) */
     int sync_active, sync_flush, warned_sync_grab;
     uint32_t sync_frame;            /* the frame just pushed */
@@ -593,6 +597,85 @@ static void on_event_done(void *user, r433_r_device *dev, int ret, r433_bitbuffe
     }
 }
 
+static char *text_reserve(size_t need)
+{
+    if (need > H.text_cap) {
+        free(H.text);
+        H.text_cap = need + (need >> 2) + 4096;
+        H.text     = malloc(H.text_cap);
+        if (!H.text)
+            FATAL_MALLOC("hip report text");
+    }
+    return H.text;
+}
+
+/* `-w file.ook` / `-w file.vcd` (src/r_flow.c:276-287,318-329 -> pulse_data_dump / pulse_data_print_vcd, src/pulse_data.c:102-224):
+   the package as the library renders it (r433_pulse_text_dump / r433_pulse_vcd), written where the reference writes it */
+static void dump_package(file_info_t const *dumper, pulse_data_t const *pd, int is_ook)
+{
+    char time_str[LOCAL_TIME_BUFLEN];
+    for (int pass = 0; pass < 2; ++pass) { /* (snprintf convention: the second time round the buffer is large enough) */
+        int const n = dumper->format == VCD_LOGIC
+                ? r433_pulse_vcd((r433_pulse_data const *)pd, is_ook ? '\'' : '"', H.text, H.text_cap)
+                : r433_pulse_text_dump((r433_pulse_data const *)pd, usecs_time_str(time_str, NULL, 1, 0), H.text, H.text_cap);
+        if (n < 0)
+            hip_fatal("pulse text");
+        if ((size_t)n < H.text_cap) {
+            if (fwrite(H.text, 1, (size_t)n, dumper->file) != (size_t)n)
+                print_log(LOG_ERROR, __func__, "Short write, disk full?");
+            return;
+        }
+        text_reserve((size_t)n + 1);
+    }
+}
+
+/* `-A` (src/r_flow.c:295-298,313-316 -> pulse_analyzer, src/pulse_analyzer.c:279-560): the histograms and the modulation
+   guess of every package of the pass were made on the device in one launch (r433_batch_analyze, replay_group); here the
+   report of one package is rendered (r433_analysis_text: "Analyzing pulses..." through the flex-decoder suggestion) and the
+   trial demodulation the reference ends with is run -- the guessed timings through the slicer the guess names
+   (pulse_slicer_* = librtl433seam.so -> the GPU library), whose bitbuffer the analyzer's device logs like any decoder without
+   a decode_fn (src/pulse_slicer.c:49-59). */
+static void analyzer_report(r_cfg_t *cfg, pulse_data_t *pd, uint32_t pkg)
+{
+    r433_analysis const *a = &H.analysis[pkg];
+    for (int pass = 0; pass < 2; ++pass) {
+        int const n = r433_analysis_text(H.eng, pkg, a, H.text, H.text_cap);
+        if (n < 0)
+            hip_fatal("r433_analysis_text");
+        if ((size_t)n < H.text_cap) {
+            fwrite(H.text, 1, (size_t)n, stderr);
+            break;
+        }
+        text_reserve((size_t)n + 1);
+    }
+    if (a->num_pulses == 0)
+        return; /* "No pulses detected." (src/pulse_analyzer.c:281-284) */
+    if (a->device.modulation) {
+        r_device device    = {.log_fn = log_device_handler, .output_ctx = cfg};
+        device.name        = "Analyzer Device"; /* src/pulse_analyzer.c:348-349 */
+        device.verbose     = 2;
+        device.modulation  = a->device.modulation;
+        device.short_width = a->device.short_width;
+        device.long_width  = a->device.long_width;
+        device.reset_limit = a->device.reset_limit;
+        device.gap_limit   = a->device.gap_limit;
+        device.sync_width  = a->device.sync_width;
+        device.tolerance   = a->device.tolerance;
+        double const to_us = 1e6 / pd->sample_rate;
+        if (device.modulation != FSK_PULSE_PCM && pd->num_pulses)
+            pd->gap[pd->num_pulses - 1] = device.reset_limit / to_us + 1; /* "Be sure to terminate package", :530-550 */
+        switch (device.modulation) {
+        case FSK_PULSE_PCM: pulse_slicer_pcm(pd, &device); break;
+        case OOK_PULSE_PPM: pulse_slicer_ppm(pd, &device); break;
+        case OOK_PULSE_PWM:
+        case FSK_PULSE_PWM: pulse_slicer_pwm(pd, &device); break;
+        case OOK_PULSE_MANCHESTER_ZEROBIT: pulse_slicer_manchester_zerobit(pd, &device); break;
+        default: break; /* "Unsupported" has been said */
+        }
+    }
+    fprintf(stderr, "\n");
+}
+
 static void on_package_end(void *user, r433_pkg_rec const *rec, int p_events)
 {
     (void)user;
@@ -622,12 +705,8 @@ static void on_package_end(void *user, r433_pkg_rec const *rec, int p_events)
 
     for (void **iter = demod->dumper.elems; iter && *iter; ++iter) {
         file_info_t const *dumper = *iter;
-        if (dumper->format == VCD_LOGIC) {
-            pulse_data_print_vcd(dumper->file, pd, is_ook ? '\'' : '"');
-        }
-        if (dumper->format == PULSE_OOK) {
-            pulse_data_dump(dumper->file, pd);
-        }
+        if ((dumper->format == VCD_LOGIC || dumper->format == PULSE_OOK) && dumper->file)
+            dump_package(dumper, pd, is_ook);
     }
     if (demod->verbosity >= LOG_TRACE) {
         pulse_data_print(pd);
@@ -637,8 +716,10 @@ static void on_package_end(void *user, r433_pkg_rec const *rec, int p_events)
         event_occurred_handler(cfg, data);
     }
     if (demod->analyze_pulses && (demod->grab_mode <= 1 || (demod->grab_mode == 2 && p_events == 0) || (demod->grab_mode == 3 && p_events > 0))) {
-        r_device device = {.log_fn = log_device_handler, .output_ctx = cfg};
-        pulse_analyzer(pd, is_ook ? PULSE_DATA_OOK : PULSE_DATA_FSK, &device);
+        r433_dispatch_info at;
+        if (r433_dispatch_current(&at) < 0 || at.package >= H.analysis_n)
+            hip_fatal("pulse analyzer: no result for this package");
+        analyzer_report(cfg, pd, at.package);
     }
 }
 
@@ -1105,6 +1186,21 @@ static int replay_group(r_cfg_t *cfg, hip_capture *group, size_t n, int n_pkgs)
         H.quality_cap = (size_t)n_pkgs;
     }
     r433_batch_frame_sums(H.eng, &H.frame_sums, &H.sums_cap);
+    text_reserve(1 << 16);
+    H.analysis_n = 0;
+    if (demod->analyze_pulses && n_pkgs > 0) { /* -A: every package of the pass through the analyzer kernel, one launch */
+        if ((size_t)n_pkgs > H.analysis_cap) {
+            free(H.analysis);
+            H.analysis = calloc((size_t)n_pkgs, sizeof(*H.analysis));
+            if (!H.analysis)
+                FATAL_CALLOC("hip analyzer results");
+            H.analysis_cap = (size_t)n_pkgs;
+        }
+        int const got = r433_batch_analyze(H.eng, H.analysis, (uint32_t)n_pkgs, NULL);
+        if (got < 0)
+            hip_fatal("r433_batch_analyze");
+        H.analysis_n = (size_t)got;
+    }
     /* The replay.  account_event's debug printout (a decoder without decode_fn, -vv) needs every bitbuffer after its
        decoder ran: then everything stays on this thread.  Otherwise the decoders are spread over host threads -- each
        decoder on one thread, its calls in reference order -- and what they hand to output_fn is committed here in

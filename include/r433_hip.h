@@ -308,7 +308,8 @@ int r433_batch_set_prefilter(r433_batch *b, int on);
 int r433_batch_prefilter_counts(r433_batch *b, uint32_t const **counts, uint32_t *n_devices);
 
 /* What the dispatcher is handing to decode_fn right now, for plugins that want to tag their output
- * (the reference's `output_tag FILE` needs the capture; time stamps need start_ago).  Thread-local. */
+ * (the reference's `output_tag FILE` needs the capture; time stamps need start_ago).  Thread-local.  Inside the package hooks
+ * of r433_dispatch_hooks (package_begin / package_end) stream, package, package_type and start_ago describe the hook's package. */
 typedef struct r433_dispatch_info {
     uint32_t stream;       /* capture index in the batch */
     uint32_t package;      /* canonical package index */

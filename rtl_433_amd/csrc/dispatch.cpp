@@ -108,6 +108,11 @@ int dispatch_range(r433_batch *b, r433_r_device *const *devices, uint32_t n_devi
             fill_levels(b->cfg, *pd);
             if (pkg_cb)
                 pkg_cb(user, ph.stream, ph.type, pd);
+            // (r433_dispatch_current inside the package hooks: which package of the run this is; device / ordinal as the last event left them)
+            g_current.stream = ph.stream;
+            g_current.package = pkg;
+            g_current.package_type = ph.type;
+            g_current.start_ago = ph.start_ago;
             if (hooks && hooks->package_begin)
                 hooks->package_begin(hooks->user, &ph, pd);
         }
@@ -750,6 +755,10 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
             pd->fsk_f1_est = ph.fsk_f1;
             pd->fsk_f2_est = ph.fsk_f2;
             fill_levels(b->cfg, *pd);
+            g_current.stream = ph.stream;
+            g_current.package = p;
+            g_current.package_type = ph.type;
+            g_current.start_ago = ph.start_ago;
             hooks->package_begin(hooks->user, &ph, pd);
         }
         for (; ci < all.size() && all[ci].pkg == p; ++ci) {
@@ -769,8 +778,13 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
                 rd->output_fn(rd, c.payload);
             }
         }
-        if (hooks && hooks->package_end && !failed.load())
+        if (hooks && hooks->package_end && !failed.load()) {
+            g_current.stream = ph.stream;
+            g_current.package = p;
+            g_current.package_type = ph.type;
+            g_current.start_ago = ph.start_ago;
             hooks->package_end(hooks->user, &ph, pe);
+        }
     }
     free(pd);
     if (trace)

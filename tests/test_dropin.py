@@ -519,3 +519,17 @@ def test_stop_after_successful_events(binary, tmp_path):
                       + sum((["-W", x] for x in dumps), []), d)
         got[who] = (out, {x: (d / x).read_bytes() for x in dumps})
     assert got["ref"] == got["new"]
+
+
+def test_the_flow_renders_reports_through_the_library():
+    """-A and -w x.ook / x.vcd in the drop-in go through the GPU library (r433_batch_analyze + r433_analysis_text,
+    r433_pulse_text_dump, r433_pulse_vcd), not through the reference's host pulse_analyzer / pulse_data_dump /
+    pulse_data_print_vcd: the CLI tests above (check_analyzer, check_pulse_dumpers) compare the library's text with the stock
+    binary's.  (-S undecoded still asks the reference's pulse_analyzer_check, a yes / no heuristic outside SURVEY 8f.)"""
+    import re
+    src = open(os.path.join(ROOT, "dropin", "r_flow_hip.c")).read()
+    code = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    for name in ("pulse_analyzer(", "pulse_data_dump(", "pulse_data_print_vcd("):
+        assert name not in code, name
+    for name in ("r433_batch_analyze(", "r433_analysis_text(", "r433_pulse_text_dump(", "r433_pulse_vcd("):
+        assert name in code, name
