@@ -457,6 +457,7 @@ def dropin_legs(host_iq, expect_json, reps=5):
 EXCLUSIVE = 2    # --exclusive: 1 the engines take turns on the detection kernel, 2 on the slicer kernels as well, 0 no turns
 DEBUG_FLAGS = 0  # --debug: R433_DEBUG_* for every engine (development, A/B timing)
 NAP_WAIT = 2097152  # R433_DEBUG_NAP_WAIT (include/r433_hip.h)
+H2D_NAP = False     # --h2d-wait nap: the GPU leg's thread sleeps through its input copy instead of spinning (measured: no gain, 22.0-22.15 against 21.85 ms per step: the replay threads take what it frees)
 
 
 class Pipeline:
@@ -494,6 +495,14 @@ class Pipeline:
         if h2d_from is not None:  # host -> HBM over PCIe on the engine's own stream, overlapping the other engines' kernels
             with BK.on(st):
                 d_buf.copy_(h2d_from, non_blocking=True)
+                if H2D_NAP and st is not None:
+                    # The copy takes 18.7 ms and the library's first wait of the pass would SPIN through all of it
+                    # (hipEventSynchronize spins on this stack, tools/spin_probe.py): two legs in flight = two of the 16 CPUs
+                    # the box grants, taken from the decoders.  Sleep through the copy instead; the kernels' waits stay as they are.
+                    done = self.torch.cuda.Event()
+                    done.record(st)
+                    while not done.query():
+                        time.sleep(0.0004)
             src = d_buf
         return e.run(src, lens, stream=BK.handle(st)), e.timing()
 
@@ -1112,10 +1121,12 @@ def main():
     ap.add_argument("--debug", type=lambda x: int(x, 0), default=0, help="development: R433_DEBUG_* flags for the engines (A/B timing)")
     ap.add_argument("--resident", action="store_true", help="config 2: inputs resident in HBM for the timed region (what `hbm_resident` reports); "
                     "the profile run uses it: under rocprofv3 the H2D copies of the default run become blit kernels that share the CUs with k_wave")
+    ap.add_argument("--h2d-wait", default="spin", choices=["nap", "spin"], help="config 2: how a GPU leg's thread waits for its input copy (A/B)")
     ap.add_argument("--quick", action="store_true", help="the headline measurement only (no PCIe / CPU / real-decoder legs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
-    global DEBUG_FLAGS, EXCLUSIVE
+    global DEBUG_FLAGS, EXCLUSIVE, H2D_NAP
+    H2D_NAP = args.h2d_wait == "nap"
     DEBUG_FLAGS = args.debug
     EXCLUSIVE = args.exclusive
     if args.steps is None:

@@ -216,14 +216,14 @@ def _random_case(seed, n_dev):
 EMU_SEEDS = (0, 1, 7, 9)  # (7: the case that fails when BitSink::fire forgets the sync count of a tiny row)
 
 
-@pytest.mark.parametrize("seed", [pytest.param(s, marks=[] if s in EMU_SEEDS else [pytest.mark.gpu]) for s in range(12)])
+# (every seed on the GPU, four of them on the emulator as well: spelled out as pairs so that no combination is collected only to be skipped)
+@pytest.mark.parametrize("backend, seed", [pytest.param(b, s, marks=b.marks, id=f"{b.values[0]}-{s}") for b in BACKENDS for s in range(12)
+                                          if b.values[0] != "emu" or s in EMU_SEEDS])
 def test_prefilter_random_decoders(backend, plugins, seed):
     """Decoders drawn at random: 16 timing rows of the OOK line codes, each with a program of one to six first-line tests of
     the kinds the reference's decoders open with (head, other rows, sync count, content after an in-place inversion, a search, a
     checksum).  Whatever the probe makes of them -- head tables, tiny-row tables, nothing -- statistics, events per package and
     the calls that still arrive are those of the unfiltered run minus exactly what the device says it dropped."""
-    if backend == "emu" and seed not in EMU_SEEDS:
-        pytest.skip("the other seeds run on the GPU")
     n_dev = 16
     devs, progs = _random_case(1000 + seed, n_dev)
     iqs = [synth.ook_stream(5000 + 17 * seed + k, 50000)[0] for k in range(14)] + [synth.random_cu8(300 + seed, 6000)]
