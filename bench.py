@@ -328,7 +328,7 @@ def real_decoders_leg(host_iq, d_iq, devs, threads, local_rank, reps=2, pipe_ste
     stateless = plug.stateless()  # the plugin library's own statement about its decoders (r433p_stateless)
     best, decoded, d2h, seen = {}, {}, {}, {}
     t0 = time.perf_counter()
-    tables = eng.probe_prefilter(plain)
+    tables = eng.probe_prefilter(plain, helper=plug.helper_probe())
     probe_s = time.perf_counter() - t0
     for mode in ("ordered", "single", "ordered_prefilter", "ordered_prefilter_stateless"):
         eng.set_prefilter(1 if mode.startswith("ordered_prefilter") else 0)
@@ -679,7 +679,7 @@ def run_batched(args, ctxd):
                     hooks=plug.hooks() if hasattr(plug, "hooks") else None)
     for e in pipe.engines:
         e.set_stateless(stateless)
-        e.probe_prefilter(plug.devices)  # records a decoder provably refuses on their head stay on the device (statistics unchanged)
+        e.probe_prefilter(plug.devices, helper=plug.helper_probe())  # records a decoder provably refuses on their head stay on the device (statistics unchanged)
 
     d_bufs = None if strong else [torch.empty_like(batches[0]) for _ in range(max(2, args.engines))]
 

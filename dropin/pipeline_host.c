@@ -43,6 +43,7 @@ int r433p_devices(void *h, r433_r_device **out, int cap);
 size_t r433p_take(void *h, char const **text, unsigned long *messages);
 int r433p_stateless(void *h, unsigned char *flags, int cap);
 void r433p_destroy(void *h);
+r433_helper_probe *r433_host_helper_probe(int session); /* dropin/helper_wrap.c, linked into the plugin library */
 void *r433p_render(void *user, void *device, void *data); /* r433_dispatch_hooks.output_render: data_t -> its JSON line, on the replay threads */
 
 typedef struct leg {
@@ -264,6 +265,8 @@ int main(int argc, char **argv)
             fprintf(stderr, "r433_batch_set_stateless: %s\n", r433_last_error());
             return 1;
         }
+        if (prefilter && e == 0) /* the plugin library's decoders reach four bitbuffer helpers through wrappers (dropin/helper_wrap.c) */
+            r433_prefilter_set_helper_probe(r433_host_helper_probe);
         if (prefilter && r433_batch_probe_prefilter(g->eng, devs, (uint32_t)n_dev) < 0) {
             fprintf(stderr, "r433_batch_probe_prefilter: %s\n", r433_last_error());
             return 1;

@@ -69,6 +69,8 @@
 
 #include "r433_hip.h"
 
+r433_helper_probe *r433_host_helper_probe(int session); /* dropin/helper_wrap.c */
+
 #include <pthread.h>
 #include <sys/mman.h>
 
@@ -873,6 +875,8 @@ static void engine_prefilter_of(r_cfg_t *cfg, hip_engine *cur)
     int const want         = !(env && env[0] == '0') && worth && !H.sync_active && replay_threads() > 1 && !replay_is_chatty(demod) && demod->r_devs.len;
     if (want && !cur->probed) {
         cur->probed = 1;
+        /* this program's decoders reach bitbuffer_invert / _search / _find_repeated_* through dropin/helper_wrap.c (ld --wrap) */
+        r433_prefilter_set_helper_probe(r433_host_helper_probe);
         int const t = r433_batch_probe_prefilter(cur->eng, (r433_r_device *const *)demod->r_devs.elems, (uint32_t)demod->r_devs.len);
         if (t < 0)
             hip_fatal("r433_batch_probe_prefilter");

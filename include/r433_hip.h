@@ -302,6 +302,38 @@ int r433_batch_probe_prefilter(r433_batch *b, r433_r_device *const *devices, uin
  * host that frees decoders, or changes what lies behind a decode_ctx, calls this before the next probe: everything known
  * is forgotten (engines keep the tables they already have until they are probed again). */
 void r433_prefilter_forget(void);
+/* Most decoders TOUCH the payload before their length test -- through one of four helpers of the reference's bitbuffer.c:
+ * bitbuffer_invert (src/bitbuffer.c:135-149), bitbuffer_search (:228-253), bitbuffer_find_repeated_row / _prefix (:513-533)
+ * -- so the fenced call above faults and nothing is learned (Neptune R900, src/devices/neptune_r900.c:88-101: a search for the
+ * preamble, THEN "too short" for anything under 224 bits; a quarter of all records that still crossed).  A host that wraps
+ * those four helpers of its decoders (ld --wrap, dropin/helper_wrap.c) lets the probe ask further: while `armed` is set on the
+ * calling thread the wrappers do not look at the payload but answer from this block --
+ *   bitbuffer_invert            nothing (it changes payload bytes only; `inverts` counts)
+ *   bitbuffer_search            `answer` for the first call of a question (a bit position, or < 0: "not found" = the row's
+ *                               length), and they leave row / start / pattern_bits here; a second call sets `overflow`
+ *   bitbuffer_find_repeated_*   on a ONE-row bitbuffer the row compares equal to itself whatever it holds: 0 if it is long
+ *                               enough and one repeat suffices, else -1 (`repeats` counts); other row counts go to the real
+ *                               function (and fault)
+ * -- and the probe asks a head once per answer the real helper could have given (every position from `start` to length -
+ * pattern_bits, and "not found").  Only where ALL of them make decode_fn return the same failure code, again without a look at
+ * anything behind the head, that code becomes the verdict of the head: it holds for every payload.  One-row heads of up to
+ * 511 bits are asked this way.  The block is the host's (one per thread that runs decoders); the library learns where it is
+ * from this call: host_block(+1) when a thread begins to ask, host_block(-1) when it is through (the wrappers of a host that
+ * counts these look at their thread's block only while somebody asks: one load of a global on the replay's path), both
+ * return the calling thread's block.  Process-wide, before the first probe (or r433_prefilter_forget after it); NULL: back
+ * to the fence alone. */
+typedef struct r433_helper_probe {
+    uint32_t armed;        /* library -> wrappers: a question is being asked on this thread */
+    int32_t answer;        /* library -> wrappers: what the first bitbuffer_search of the question returns (< 0: not found) */
+    void const *subject;   /* library -> wrappers: the bitbuffer_t the question is about; calls on any other go to the real helper */
+    uint32_t searches;     /* wrappers -> library: bitbuffer_search calls of this question */
+    uint32_t overflow;     /* ... more than one (the later ones were told "not found": the question does not count) */
+    uint32_t row, start, pattern_bits; /* ... arguments of the first */
+    uint32_t inverts, repeats;         /* ... bitbuffer_invert / bitbuffer_find_repeated_* calls answered without the payload */
+    uint32_t reserved[6];
+} r433_helper_probe;
+typedef r433_helper_probe *(*r433_helper_probe_fn)(int session); /* -> the calling thread's block */
+void r433_prefilter_set_helper_probe(r433_helper_probe_fn host_block);
 /* on = 0 turns the learned tables off again (records flow as without a probe), 1 back on */
 int r433_batch_set_prefilter(r433_batch *b, int on);
 /* of the last run: records dropped on the device, counts[device * 5 + code] with code = -(decode_fn return) in 0..4 */

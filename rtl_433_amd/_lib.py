@@ -127,7 +127,7 @@ EXPORTS = [
     "r433_sigmf_prefix", "r433_sigmf_trailer", "r433_sigmf_probe",
     "r433_filter_frame", "r433_envelope_host", "r433_host_alloc", "r433_host_free", "r433_batch_run_host", "r433_batch_dispatch_hooks", "r433_batch_dispatch_ordered", "r433_batch_decoded",
     "r433_dump_convert_host", "r433_batch_set_package_quality",
-    "r433_batch_set_stateless", "r433_batch_probe_prefilter", "r433_batch_set_prefilter", "r433_batch_prefilter_counts", "r433_prefilter_forget",
+    "r433_batch_set_stateless", "r433_batch_probe_prefilter", "r433_batch_set_prefilter", "r433_batch_prefilter_counts", "r433_prefilter_forget", "r433_prefilter_set_helper_probe",
     "r433_fsk_step", "r433_detector_create", "r433_detector_destroy", "r433_detector_reset", "r433_detector_set_levels", "r433_detector_package",
 ]
 
@@ -277,6 +277,9 @@ def bind(L):
     if hasattr(L, "r433_prefilter_forget"):  # (development builds of earlier rounds are still bound for A/B timing)
         L.r433_prefilter_forget.restype = None
         L.r433_prefilter_forget.argtypes = []
+    if hasattr(L, "r433_prefilter_set_helper_probe"):
+        L.r433_prefilter_set_helper_probe.restype = None
+        L.r433_prefilter_set_helper_probe.argtypes = [vp]
     if hasattr(L, "r433_batch_set_stateless"):
         L.r433_batch_set_stateless.restype = C.c_int
         L.r433_batch_set_stateless.argtypes = [vp, vp, C.c_uint32]

@@ -156,6 +156,7 @@ struct Fence {
 };
 
 std::mutex g_probe_lock; // signal dispositions are the process's
+r433_helper_probe_fn g_helper = nullptr; // the host wraps its decoders' bitbuffer helpers (r433_prefilter_set_helper_probe)
 
 // What a decoder answered is kept for the life of the process: a host that runs several engines over the same decoders
 // (a pipeline of engines, the drop-in's engine per sample rate) asks once.  Keyed by the decoder object and everything of
@@ -277,9 +278,10 @@ void probe_tiny(r433_r_device *dev, std::vector<uint8_t> &tab, bool &useful, boo
 }
 
 bool probe_heads(Fence &fence, r433_r_device *dev, std::vector<uint8_t> &tab, bool &useful, bool &accepts);
+bool probe_helpers(Fence &fence, r433_r_device *dev, r433_helper_probe *blk, std::vector<uint8_t> &tab, bool &useful);
 
 // Every question one decoder is asked.  True: `tab` holds its verdicts (something to filter, answers steady).
-bool probe_one(Fence &fence, r433_r_device *dev, std::vector<uint8_t> &tab)
+bool probe_one(Fence &fence, r433_r_device *dev, r433_helper_probe *blk, std::vector<uint8_t> &tab)
 {
     struct Quiet { // outputs off for the time of the questions
         r433_r_device *d;
@@ -301,8 +303,88 @@ bool probe_one(Fence &fence, r433_r_device *dev, std::vector<uint8_t> &tab)
     bool const steady = probe_heads(fence, dev, tab, useful, accepts);
     if (!steady || accepts)
         return false;
+    if (blk && !probe_helpers(fence, dev, blk, tab, useful))
+        return false;
     probe_tiny(dev, tab, useful, accepts);
     return useful && !accepts;
+}
+
+// The questions a host with wrapped bitbuffer helpers makes possible (include/r433_hip.h, r433_helper_probe): one-row heads
+// the decoder reached past under the bare fence are asked again with the helpers answering from `blk` -- once per answer
+// bitbuffer_search could have given -- and a head becomes a verdict where every answer led to the same failure code without
+// a look behind the head.  False: the answers moved between two askings.
+constexpr unsigned kHelperBits = 512; // row lengths asked (a question per search position: n^2 / 2 calls up to here)
+
+bool probe_helpers(Fence &fence, r433_r_device *dev, r433_helper_probe *blk, std::vector<uint8_t> &tab, bool &useful)
+{
+    auto ask = [&](unsigned n, int answer) -> int {
+        blk->answer = answer;
+        blk->subject = fence.bits;
+        blk->searches = blk->overflow = blk->row = blk->start = blk->pattern_bits = blk->inverts = blk->repeats = 0;
+        blk->armed = 1;
+        int const ret = fence.ask(dev, 1, n);
+        blk->armed = 0;
+        return ret;
+    };
+    // a decoder whose first look at a one-row bitbuffer is not through a helper is not asked 500 times (each a fault)
+    static unsigned const sample[6] = {1, 9, 24, 40, 130, 300};
+    bool any = false;
+    for (unsigned n : sample) {
+        int const ret = ask(n, -1);
+        any |= ret != INT_MIN || blk->searches || blk->inverts || blk->repeats;
+        if (ret != INT_MIN && ret > 0)
+            return true; // (takes a bare head under these answers: nothing to filter here, and nothing wrong)
+    }
+    if (!any)
+        return true;
+    // every answer the real helper could have given for this head; the verdict if they all agree on a refusal
+    auto verdict = [&](unsigned n) -> uint8_t {
+        int const r0 = ask(n, -1);
+        uint8_t const v0 = verdict_of(r0);
+        if (v0 == kPfKeep || blk->overflow)
+            return (uint8_t)kPfKeep;
+        if (blk->searches) {
+            if (blk->row != 0)
+                return (uint8_t)kPfKeep; // (unreachable under the fence: the wrapper read that row's length)
+            unsigned const start = blk->start, plen = blk->pattern_bits;
+            if (plen >= 1 && plen <= n) // a match ends inside the row: it begins at start .. n - plen
+                for (unsigned pos = start; pos + plen <= n; ++pos) {
+                    int const r = ask(n, (int)pos);
+                    if (r != r0 || blk->overflow || !blk->searches || blk->start != start || blk->pattern_bits != plen)
+                        return (uint8_t)kPfKeep;
+                }
+        }
+        return v0;
+    };
+    // (the same economy as under the bare fence: a grid of every sixteenth length first, nothing asked between two grid
+    // lengths that both made the decoder reach for the payload -- faults do not run side by side)
+    constexpr unsigned kGrid = 16;
+    uint8_t grid[kHelperBits / kGrid + 1];
+    std::vector<uint8_t> got(kHelperBits, (uint8_t)kPfKeep);
+    auto wanted = [&](unsigned n) { // heads the fence alone did not settle (a tiny-row verdict holds for plain rows only: ask)
+        uint8_t const t = tab[1 * kPfBits + n];
+        return t == kPfKeep || (t & kPfTiny);
+    };
+    for (unsigned g = 0; g * kGrid < kHelperBits; ++g)
+        grid[g] = got[g * kGrid] = wanted(g * kGrid) ? verdict(g * kGrid) : tab[1 * kPfBits + g * kGrid];
+    for (unsigned g = 0; g * kGrid < kHelperBits; ++g) {
+        bool const last = (g + 1) * kGrid >= kHelperBits;
+        if (!last && grid[g] == kPfKeep && grid[g + 1] == kPfKeep && wanted(g * kGrid) && wanted((g + 1) * kGrid))
+            continue;
+        for (unsigned n = g * kGrid + 1; n < std::min(kHelperBits, (g + 1) * kGrid); ++n)
+            if (wanted(n))
+                got[n] = verdict(n);
+    }
+    // once more, the answer "not found" alone: verdicts of a decoder whose answers move are worth nothing
+    for (unsigned n = 0; n < kHelperBits; ++n)
+        if (wanted(n) && got[n] != kPfKeep && verdict_of(ask(n, -1)) != got[n])
+            return false;
+    for (unsigned n = 0; n < kHelperBits; ++n)
+        if (wanted(n) && got[n] != kPfKeep) {
+            tab[1 * kPfBits + n] = got[n];
+            useful = true;
+        }
+    return true;
 }
 
 // the questions under the memory fence: heads a decoder refuses without looking further.  False: its answers moved.
@@ -457,18 +539,22 @@ int r433_batch_probe_prefilter(r433_batch *b, r433_r_device *const *devices, uin
             nt = (unsigned)std::max(1, atoi(e));
         std::atomic<uint32_t> cursor{0};
         std::atomic<int> no_pages{0};
+        r433_helper_probe_fn const helper = g_helper;
         b->pool.run(nt, [&](unsigned) {
             Fence fence;
             if (!fence.ok) {
                 no_pages.store(1);
                 return;
             }
+            r433_helper_probe *const blk = helper ? helper(+1) : nullptr; // this thread's block of the host's wrappers
             for (;;) {
                 uint32_t const k = cursor.fetch_add(1, std::memory_order_relaxed);
                 if (k >= ask_list.size())
                     break;
-                answered[k] = probe_one(fence, devices[ask_list[k]], answers[k]) ? 1 : 0;
+                answered[k] = probe_one(fence, devices[ask_list[k]], blk, answers[k]) ? 1 : 0;
             }
+            if (helper)
+                helper(-1);
         });
         if (no_pages.load() && cursor.load() < ask_list.size())
             return fail(R433_ENOMEM, "pre-filter probe: no fenced page (mmap / mprotect)");
@@ -503,6 +589,12 @@ int r433_batch_probe_prefilter(r433_batch *b, r433_r_device *const *devices, uin
         HIP_TRY(hipMemcpy(b->d_rows.p, b->rows.data(), b->rows.size() * sizeof(DevRow), hipMemcpyHostToDevice));
     b->pf_on = filtered > 0;
     return filtered;
+}
+
+void r433_prefilter_set_helper_probe(r433_helper_probe_fn host_block)
+{
+    std::lock_guard<std::mutex> guard(g_probe_lock);
+    g_helper = host_block;
 }
 
 void r433_prefilter_forget(void)

@@ -110,9 +110,13 @@ class BatchEngine:
                                              len(flags) if flags is not None else 0)
         return _lib.check(rc, "r433_batch_set_stateless", self.L)
 
-    def probe_prefilter(self, rdevices):
+    def probe_prefilter(self, rdevices, helper=None):
         """Learn which bitbuffers each decoder provably refuses on its head alone (r433_batch_probe_prefilter); from the
-        next run on the slicer kernel drops those records.  -> number of decoders with a table."""
+        next run on the slicer kernel drops those records.  -> number of decoders with a table.
+        helper: address of the host's r433_helper_probe accessor (plugins.Plugins.helper_probe(): the decoders' bitbuffer
+        helpers are wrapped and answer the probe without the payload, r433_prefilter_set_helper_probe), or None"""
+        if helper is not None:
+            self.L.r433_prefilter_set_helper_probe(helper)
         rc = self.L.r433_batch_probe_prefilter(self.h, C.cast(rdevices, C.c_void_p), len(rdevices))
         return _lib.check(rc, "r433_batch_probe_prefilter", self.L)
 

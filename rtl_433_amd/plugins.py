@@ -44,6 +44,13 @@ class Plugins:
             raise RuntimeError(f"r433p_stateless answered {n} for {len(flags)} decoders: its list of stateful decoders no longer matches the registered set")
         return flags
 
+    def helper_probe(self):
+        """-> address of r433_host_helper_probe (dropin/helper_wrap.c: the decoders' calls of bitbuffer_invert / _search /
+        _find_repeated_* go through wrappers that answer the pre-filter's questions without the payload), for
+        BatchEngine.probe_prefilter(..., helper=...); None for a plugin library built without the wrappers"""
+        fn = getattr(self.L, "r433_host_helper_probe", None)
+        return C.cast(fn, C.c_void_p).value if fn is not None else None
+
     def hooks(self):
         """-> r433_dispatch_hooks for the ordered replay of these plugins: what a decoder reports is rendered to its JSON line
         on the replay thread that ran it (output_render = r433p_render), the commit only appends the lines in order"""

@@ -160,7 +160,7 @@ def _worker_decoded_gather(rank, world, port, out_q):
         def decode(part):
             plug = plugins.Plugins()
             eng = BatchEngine(flow_cfg(2, 250000), devs, library=host.emu_lib())
-            eng.probe_prefilter(plug.devices)
+            eng.probe_prefilter(plug.devices, helper=plug.helper_probe())
             n = eng.run_host(part)
             eng.dispatch_ordered(plug.devices, None, 2)
             text, n_msg = plug.take()

@@ -170,6 +170,125 @@ def test_prefilter_real_decoders(backend):
     assert b["nev"] < 0.3 * a["nev"]
 
 
+HFNS = ["pfh_dec_search_then_length", "pfh_dec_search_two_codes", "pfh_dec_invert_then_length", "pfh_dec_invert_then_payload",
+        "pfh_dec_foreign_search", "pfh_dec_two_searches", "pfh_dec_repeated_row", "pfh_dec_repeated_once", "pfh_dec_search_position"]
+WRAP = "-Wl,--wrap=bitbuffer_invert,--wrap=bitbuffer_search,--wrap=bitbuffer_find_repeated_row,--wrap=bitbuffer_find_repeated_prefix"
+
+
+@pytest.fixture(scope="module")
+def helper_plugins():
+    """decoders that call bitbuffer helpers before their length test, with dropin/helper_wrap.c linked between the two
+    (ld --wrap: the way dropin/Makefile links the reference's decoders)"""
+    out = os.path.join(HERE, "emu", "_build", "libpfhelper.so")
+    srcs = [os.path.join(HERE, "plugins", "pf_helper_decoders.c"), os.path.join(HERE, "plugins", "pf_helper_bitbuffer.c"),
+            os.path.join(HERE, "..", "dropin", "helper_wrap.c")]
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(x) for x in srcs):
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-DR433_WRAP_STANDALONE", "-I", os.path.join(HERE, "..", "include"),
+                               "-o", out] + srcs + [WRAP])
+    return C.CDLL(out)
+
+
+def _helper_devices():
+    devs = np.zeros(len(HFNS), dtype=po.DEV_DTYPE)
+    #          mod  short  long  reset  gap   sync  tol  prio
+    devs[0] = (4, 100.0, 100.0, 3000.0, 0.0, 0.0, 0.0, 0)        # OOK_PCM: one long row per burst
+    devs[1] = (4, 100.0, 100.0, 900.0, 0.0, 0.0, 0.0, 0)         # OOK_PCM, short reset: many short rows
+    devs[2] = (6, 400.0, 800.0, 6000.0, 2000.0, 0.0, 150.0, 0)   # OOK_PWM
+    devs[3] = (6, 300.0, 600.0, 900.0, 700.0, 0.0, 100.0, 0)     # OOK_PWM, short reset
+    devs[4] = (5, 400.0, 800.0, 6000.0, 0.0, 0.0, 150.0, 0)      # OOK_PPM
+    devs[5] = (4, 200.0, 200.0, 2000.0, 0.0, 0.0, 0.0, 0)        # OOK_PCM
+    devs[6] = (6, 250.0, 500.0, 1200.0, 800.0, 0.0, 120.0, 0)    # OOK_PWM: one- and several-row bitbuffers
+    devs[7] = (5, 250.0, 500.0, 4000.0, 0.0, 0.0, 100.0, 0)      # OOK_PPM
+    devs[8] = (4, 100.0, 100.0, 900.0, 0.0, 0.0, 0.0, 0)         # OOK_PCM, short reset
+    return devs
+
+
+def test_prefilter_helper_probe_plugins(backend, helper_plugins):
+    """Decoders that invert, search or look for a repeated row before their length test: with the host's wrappers answering
+    the probe (r433_prefilter_set_helper_probe) a head is dropped where EVERY answer the helper could have given leads to the
+    same refusal, and only there; statistics, events per package and the calls that still arrive are those of the unfiltered
+    run minus exactly what the device says it dropped.  Without the wrappers' block nothing is learned from these decoders."""
+    devs = _helper_devices()
+    iqs = [synth.ook_stream(7000 + k, 50000)[0] for k in range(30)] + [synth.random_cu8(99, 6000)]
+    calls = (C.c_ulong * 12).in_dll(helper_plugins, "pfh_calls")
+    helper = C.cast(helper_plugins.r433_host_helper_probe, C.c_void_p).value
+    runs = {}
+    for mode in ("plain", "fence_only", "filtered"):
+        eng = _engine(devs, backend)
+        eng.L.r433_prefilter_forget()
+        arr, objs = make_rdevices(devs)
+        for o, f in zip(objs, HFNS):
+            o.decode_fn = C.cast(getattr(helper_plugins, f), C.c_void_p).value
+        eng.L.r433_prefilter_set_helper_probe(None)
+        tables = 0 if mode == "plain" else eng.probe_prefilter(arr, helper=helper if mode == "filtered" else None)
+        for k in range(12):
+            calls[k] = 0
+        eng.run_host(iqs)
+        ev, nev = eng.events()
+        dec = eng.dispatch(arr, n_threads=1)
+        runs[mode] = dict(stats=_stats(objs), per_pkg=list(eng.decoded()), decoded=dec, records=_records(ev), nev=nev,
+                          calls=list(calls), tables=tables, dropped=eng.prefilter_counts() if mode != "plain" else None)
+        eng.L.r433_prefilter_set_helper_probe(None)
+        eng.L.r433_prefilter_forget()
+        eng.close()
+    a, f, b = runs["plain"], runs["fence_only"], runs["filtered"]
+    for r in (f, b):
+        assert a["stats"] == r["stats"] and a["per_pkg"] == r["per_pkg"] and a["decoded"] == r["decoded"]
+        assert int(r["dropped"].sum()) == a["nev"] - r["nev"]
+        for i in range(len(HFNS)):
+            assert a["calls"][i] - r["calls"][i] == int(r["dropped"][i].sum())
+        it = iter(a["records"])
+        assert all(any(x == y for y in it) for x in r["records"])
+    # (under the bare fence: other row counts on the head, a short row 0 where that comes first, tiny rows asked one by one)
+    print("dropped under the fence alone / with the wrappers:", [int(x.sum()) for x in f["dropped"]], [int(x.sum()) for x in b["dropped"]])
+    # with the wrappers: the searches (0, 1, 8), the inversion in front of a length test (2), the repeated-row tests (6, 7)
+    for d in (0, 1, 2, 6, 7, 8):
+        assert int(b["dropped"][d].sum()) > int(f["dropped"][d].sum()), d
+    # ... 3 looks at the payload whatever the length; 4 and 5 gain nothing (a foreign bitbuffer; a second search)
+    assert int(b["dropped"][3].sum()) == 0
+    assert int(b["dropped"][4].sum()) == int(f["dropped"][4].sum()) and int(b["dropped"][5].sum()) == int(f["dropped"][5].sum())
+    # 1: only rows too short for the preamble go ("not found" and "found, too short" are different codes): all under ABORT_EARLY
+    assert int(b["dropped"][1][1]) == 0 and int(b["dropped"][1][2]) > 0
+    assert b["nev"] < f["nev"] < a["nev"]
+
+
+def test_prefilter_helper_probe_real_decoders(backend):
+    """The plugin library's real decoders (dropin/_build/libr433plugins.so, linked with dropin/helper_wrap.c) asked with their
+    helpers wrapped: statistics of all 335, decoded events and what every package produced are the same as without the filter,
+    and fewer records cross than under the fence alone (Neptune R900's search-then-length alone was a quarter of them)."""
+    from rtl_433_amd import plugins
+    if not plugins.available():
+        pytest.skip("dropin/_build/libr433plugins.so not built")
+    devs, protocols, names = load_device_table()
+    iqs = [synth.ook_stream(s)[0] for s in range(96 if backend == "gpu" else 20)]
+    res = {}
+    for mode in ("plain", "fence_only", "filtered"):
+        plug = plugins.Plugins()  # a fresh set of decoders (some keep state between calls)
+        assert plug.helper_probe() is not None, "libr433plugins.so was built without dropin/helper_wrap.c: make -C dropin plugins"
+        objs = [C.cast(p, C.POINTER(_lib.RDevice)).contents for p in plug.devices]
+        eng = _engine(devs, backend)
+        eng.L.r433_prefilter_forget()
+        eng.L.r433_prefilter_set_helper_probe(None)
+        tables = 0 if mode == "plain" else eng.probe_prefilter(plug.devices, helper=plug.helper_probe() if mode == "filtered" else None)
+        eng.run_host(iqs)
+        nev = eng.events()[1]
+        dec = eng.dispatch_ordered(plug.devices, None, 8)
+        res[mode] = dict(stats=_stats(objs), per_pkg=list(eng.decoded()), decoded=dec, nev=nev, tables=tables,
+                         neptune=int(eng.prefilter_counts()[names.index("Neptune R900 flow meters")].sum()) if mode != "plain" else 0)
+        eng.L.r433_prefilter_set_helper_probe(None)
+        eng.L.r433_prefilter_forget()
+        eng.close()
+        plug.take()
+        plug.close()
+    a, f, b = res["plain"], res["fence_only"], res["filtered"]
+    assert b["tables"] >= f["tables"] > 200
+    for r in (f, b):
+        assert a["stats"] == r["stats"] and a["per_pkg"] == r["per_pkg"] and a["decoded"] == r["decoded"]
+    assert b["nev"] < 0.7 * f["nev"] and f["nev"] < 0.3 * a["nev"]
+    assert b["neptune"] > f["neptune"]
+
+
 class _Step(C.Structure):
     _fields_ = [("op", C.c_int), ("a", C.c_int), ("b", C.c_int), ("code", C.c_int)]
 

@@ -18,7 +18,7 @@ plug = plugins.Plugins()
 pipe = bench.Pipeline(lambda: flow_cfg(2, 250000), devs, plug.devices, threads, 3, 0, on_host_leg=lambda k, e, n: plug.take(), ordered=True, hooks=plug.hooks())
 for e in pipe.engines:
     e.set_stateless(plug.stateless())
-    e.probe_prefilter(plug.devices)
+    e.probe_prefilter(plug.devices, helper=plug.helper_probe())
 
 
 def cgroup():

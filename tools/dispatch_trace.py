@@ -13,7 +13,7 @@ host = bench.ook_batches(0, 8192, 32)
 devs = load_device_table()[0]
 plug = plugins.Plugins()
 eng = BatchEngine(flow_cfg(2, 250000), devs, profiling=True)
-eng.probe_prefilter(plug.devices)
+eng.probe_prefilter(plug.devices, helper=plug.helper_probe())
 if stateless:
     eng.set_stateless(plug.stateless())
 d = torch.from_numpy(host).cuda()

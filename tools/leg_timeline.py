@@ -34,7 +34,7 @@ if real:
                           hooks=plug.hooks() if hasattr(plug, "hooks") else None)
     for e in pipe.engines:
         e.set_stateless(plug.stateless())
-        e.probe_prefilter(plug.devices)
+        e.probe_prefilter(plug.devices, helper=plug.helper_probe())
 else:
     pipe = bench.Pipeline(lambda: flow_cfg(2, 250000), devs, rdev_arr, threads, n_eng, 0)
 stamps = []  # (ms, who, what)

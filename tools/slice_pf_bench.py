@@ -19,7 +19,7 @@ else:
 devs = load_device_table()[0]
 plug = plugins.Plugins()
 eng = BatchEngine(flow_cfg(2, 250000), devs, profiling=True, library=_lib.bind(ctypes.CDLL(os.path.abspath(so))) if so else None)
-eng.probe_prefilter(plug.devices)
+eng.probe_prefilter(plug.devices, helper=plug.helper_probe())
 if debug:
     eng.set_debug(debug)
 d = torch.from_numpy(host).cuda()
