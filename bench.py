@@ -689,7 +689,9 @@ def run_batched(args, ctxd):
     def leg_args_pcie(k):  # every step first copies its input from pinned host memory on its engine's stream
         return dict(src=None, h2d_from=pinned[k % len(pinned)], d_buf=d_bufs[k % pipe.n_eng])
 
-    leg_args = leg_args_resident if strong or args.resident else leg_args_pcie
+    # `value` is measured with the inputs resident in HBM when the timed region starts; the PCIe-inclusive rate of the same
+    # pipeline (pinned host memory -> H2D inside every step) is the secondary line `pcie_inclusive` (--from-host swaps the two)
+    leg_args = leg_args_pcie if args.from_host and not strong else leg_args_resident
 
     gathered = {}
 
@@ -746,14 +748,14 @@ def run_batched(args, ctxd):
                    (f"configs[1]: batches of {n_batch} synthetic 250 kS/s cu8 OOK bursts x {n_samples} samples (every third capture a "
                     f"protocol-valid transmission of one of 12 real protocols, the others random payloads), all {len(devs)} default -R "
                     f"decoders fanned out and their real decode_fn called; a step = {args.batches} such batches per GPU submitted together "
-                    f"(one detection grid of {n_streams} captures), from pinned host memory to decoded events (JSON lines) on the host")
+                    f"(one detection grid of {n_streams} captures), from IQ samples in HBM to decoded events (JSON lines) on the host")
         result = {
             "metric": METRIC, "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8",
             "data": ("synthetic (resident in HBM; one fixed list)" if strong else
-                     "synthetic (resident in HBM when the timed region starts: --resident, the run rocprofv3 watches; three distinct inputs rotate)" if args.resident else
-                     "synthetic (in pinned host memory when the timed region starts: every step's H2D copy is timed; three distinct inputs rotate)"),
+                     "synthetic (in pinned host memory when the timed region starts: --from-host, every step's H2D copy is timed; three distinct inputs rotate)" if args.from_host else
+                     "synthetic (resident in HBM when the timed region starts; three distinct inputs rotate; `pcie_inclusive` is the same pipeline fed from pinned host memory)"),
             "config": {"workload": workload, "streams_per_launch": n_streams, "samples_per_stream": n_samples,
                        "sample_rate": 250000, "decoders": len(devs), "host_dispatch_threads": threads, "host_cpus": {"logical": os.cpu_count(), "cfs_quota": cpu_quota()},
                        "launches_per_step_per_gpu": per_step if strong else args.batches,
@@ -783,14 +785,19 @@ def run_batched(args, ctxd):
 
     # ---- secondary measurements of the same run (rank 0, N = 1, the default workload only) ----
     if not strong and not BK.emu:
-        # the same pipeline with the inputs already resident in HBM (every rank runs it: the ranks share the host)
+        # the same pipeline fed the other way (every rank runs it: the ranks share the host): from pinned host memory with the
+        # H2D copy inside every step when `value` is the resident rate, resident when --from-host made the copy part of `value`
         k_res = max(3, min(args.steps, 20))
-        pipe.run(2, leg_args_resident)
-        el, (det_res, _, _, _) = timed(dist, torch, lambda: pipe.run(k_res, leg_args_resident))
+        other = leg_args_resident if args.from_host else leg_args_pcie
+        pipe.run(2, other)
+        el, (det_res, _, _, _) = timed(dist, torch, lambda: pipe.run(k_res, other))
         if rank == 0:
-            result["hbm_resident"] = {"value": round(world * n_streams * n_samples * k_res / el / 1e6, 2), "unit": "Msamples/s", "steps": k_res,
-                                      "ms_per_step": round(el / k_res * 1e3, 3), "k_wave_ms": round(float(np.mean(det_res)), 3),
-                                      "note": "the same pipeline without the H2D copy (inputs resident in HBM when the timed region starts)"}
+            result["hbm_resident" if args.from_host else "pcie_inclusive"] = {
+                "value": round(world * n_streams * n_samples * k_res / el / 1e6, 2), "unit": "Msamples/s", "steps": k_res,
+                "ms_per_step": round(el / k_res * 1e3, 3), "k_wave_ms": round(float(np.mean(det_res)), 3),
+                "note": ("the same pipeline without the H2D copy (inputs resident in HBM when the timed region starts)" if args.from_host else
+                         "the same pipeline with every step's input copied from pinned host memory first (1 GiB per step over PCIe: the link's "
+                         "18.7 ms per GiB is the floor of this line, profiles/r04_probes.txt)")}
     if not strong and not args.quick and not args.no_cpu_baseline:
         # Parity of the timed region's own output, on every rank: the JSON lines this rank's decoders produced in the LAST step
         # of the timed region (what it sent into the gather) against the unmodified reference (oracle/_ref, its real decoders,
@@ -1119,7 +1126,9 @@ def main():
     ap.add_argument("--exclusive", type=int, default=2, choices=[0, 1, 2, 3], help="pipeline: engines take turns on the detection kernel (1), on detection + slicers (2), "
                     "on the whole GPU leg incl. the record copies (3: the profile run), not at all (0)")
     ap.add_argument("--debug", type=lambda x: int(x, 0), default=0, help="development: R433_DEBUG_* flags for the engines (A/B timing)")
-    ap.add_argument("--resident", action="store_true", help="config 2: inputs resident in HBM for the timed region (what `hbm_resident` reports); "
+    ap.add_argument("--from-host", action="store_true", help="config 2: the timed region starts from pinned host memory (every step's H2D copy inside it: what "
+                    "`pcie_inclusive` reports otherwise)")
+    ap.add_argument("--resident", action="store_true", help="(the default since round 5) config 2: inputs resident in HBM for the timed region; "
                     "the profile run uses it: under rocprofv3 the H2D copies of the default run become blit kernels that share the CUs with k_wave")
     ap.add_argument("--h2d-wait", default="spin", choices=["nap", "spin"], help="config 2: how a GPU leg's thread waits for its input copy (A/B)")
     ap.add_argument("--quick", action="store_true", help="the headline measurement only (no PCIe / CPU / real-decoder legs)")

@@ -54,6 +54,8 @@ unsigned __wrap_bitbuffer_search(bitbuffer_t *bitbuffer, unsigned row, unsigned 
             t_block.row = row;
             t_block.start = start;
             t_block.pattern_bits = pattern_bits_len;
+            for (unsigned i = 0; i < 8; ++i)
+                t_block.pattern[i] = i < (pattern_bits_len + 7) / 8 ? pattern[i] : 0;
             return t_block.answer < 0 ? len : (unsigned)t_block.answer;
         }
         t_block.overflow = 1;

@@ -317,7 +317,10 @@ void r433_prefilter_forget(void);
  * -- and the probe asks a head once per answer the real helper could have given (every position from `start` to length -
  * pattern_bits, and "not found").  Only where ALL of them make decode_fn return the same failure code, again without a look at
  * anything behind the head, that code becomes the verdict of the head: it holds for every payload.  One-row heads of up to
- * 511 bits are asked this way.  The block is the host's (one per thread that runs decoders); the library learns where it is
+ * 511 bits are asked this way.  Where the answers differ but "not found" alone leads to a refusal (tpms_imars_t240.c:57-66:
+ * "preamble not found" and "found, too short" are two codes), the decoder's search itself becomes the test: for rows of fewer
+ * than 64 bits and patterns of at most 32 the slicer kernel looks for the pattern where it finishes the bitbuffer (the row is
+ * still in two registers) and drops the record under the "not found" code if it is not there.  The block is the host's (one per thread that runs decoders); the library learns where it is
  * from this call: host_block(+1) when a thread begins to ask, host_block(-1) when it is through (the wrappers of a host that
  * counts these look at their thread's block only while somebody asks: one load of a global on the replay's path), both
  * return the calling thread's block.  Process-wide, before the first probe (or r433_prefilter_forget after it); NULL: back
@@ -330,7 +333,8 @@ typedef struct r433_helper_probe {
     uint32_t overflow;     /* ... more than one (the later ones were told "not found": the question does not count) */
     uint32_t row, start, pattern_bits; /* ... arguments of the first */
     uint32_t inverts, repeats;         /* ... bitbuffer_invert / bitbuffer_find_repeated_* calls answered without the payload */
-    uint32_t reserved[6];
+    uint8_t pattern[8];    /* ... and the first bytes of its pattern (as many as pattern_bits needs, at most eight) */
+    uint32_t reserved[4];
 } r433_helper_probe;
 typedef r433_helper_probe *(*r433_helper_probe_fn)(int session); /* -> the calling thread's block */
 void r433_prefilter_set_helper_probe(r433_helper_probe_fn host_block);

@@ -337,9 +337,19 @@ bool probe_helpers(Fence &fence, r433_r_device *dev, r433_helper_probe *blk, std
     }
     if (!any)
         return true;
-    // every answer the real helper could have given for this head; the verdict if they all agree on a refusal
+    // every answer the real helper could have given for this head; the verdict if they all agree on a refusal.  Where they
+    // do not, but "not found" alone is a refusal, the head is a candidate for the decoder's search rule (kPfRule): the
+    // search, run on the device, then says which of the answers applies.
+    struct Cand {
+        uint32_t start, plen, pat;
+        uint8_t code;
+        bool operator==(Cand const &o) const { return start == o.start && plen == o.plen && pat == o.pat && code == o.code; }
+    };
+    std::vector<std::pair<unsigned, Cand>> cands;
+    bool reached = false; // the last question's first answer made the decoder reach for the payload (a fault)
     auto verdict = [&](unsigned n) -> uint8_t {
         int const r0 = ask(n, -1);
+        reached = r0 == INT_MIN;
         uint8_t const v0 = verdict_of(r0);
         if (v0 == kPfKeep || blk->overflow)
             return (uint8_t)kPfKeep;
@@ -347,11 +357,17 @@ bool probe_helpers(Fence &fence, r433_r_device *dev, r433_helper_probe *blk, std
             if (blk->row != 0)
                 return (uint8_t)kPfKeep; // (unreachable under the fence: the wrapper read that row's length)
             unsigned const start = blk->start, plen = blk->pattern_bits;
+            uint32_t const pat = (uint32_t)blk->pattern[0] << 24 | (uint32_t)blk->pattern[1] << 16 | (uint32_t)blk->pattern[2] << 8 | blk->pattern[3];
             if (plen >= 1 && plen <= n) // a match ends inside the row: it begins at start .. n - plen
                 for (unsigned pos = start; pos + plen <= n; ++pos) {
                     int const r = ask(n, (int)pos);
-                    if (r != r0 || blk->overflow || !blk->searches || blk->start != start || blk->pattern_bits != plen)
+                    if (blk->overflow || !blk->searches || blk->start != start || blk->pattern_bits != plen)
                         return (uint8_t)kPfKeep;
+                    if (r != r0) {
+                        if (n < kPfRuleMaxBits && plen <= 32 && start < 65536u)
+                            cands.push_back({n, Cand{start, plen, plen == 32 ? pat : pat & ~(0xffffffffu >> plen), v0}});
+                        return (uint8_t)kPfKeep;
+                    }
                 }
         }
         return v0;
@@ -359,17 +375,20 @@ bool probe_helpers(Fence &fence, r433_r_device *dev, r433_helper_probe *blk, std
     // (the same economy as under the bare fence: a grid of every sixteenth length first, nothing asked between two grid
     // lengths that both made the decoder reach for the payload -- faults do not run side by side)
     constexpr unsigned kGrid = 16;
-    uint8_t grid[kHelperBits / kGrid + 1];
+    bool grid_reached[kHelperBits / kGrid + 1];
     std::vector<uint8_t> got(kHelperBits, (uint8_t)kPfKeep);
     auto wanted = [&](unsigned n) { // heads the fence alone did not settle (a tiny-row verdict holds for plain rows only: ask)
         uint8_t const t = tab[1 * kPfBits + n];
         return t == kPfKeep || (t & kPfTiny);
     };
-    for (unsigned g = 0; g * kGrid < kHelperBits; ++g)
-        grid[g] = got[g * kGrid] = wanted(g * kGrid) ? verdict(g * kGrid) : tab[1 * kPfBits + g * kGrid];
+    for (unsigned g = 0; g * kGrid < kHelperBits; ++g) {
+        reached = false;
+        got[g * kGrid] = wanted(g * kGrid) ? verdict(g * kGrid) : tab[1 * kPfBits + g * kGrid];
+        grid_reached[g] = reached;
+    }
     for (unsigned g = 0; g * kGrid < kHelperBits; ++g) {
         bool const last = (g + 1) * kGrid >= kHelperBits;
-        if (!last && grid[g] == kPfKeep && grid[g + 1] == kPfKeep && wanted(g * kGrid) && wanted((g + 1) * kGrid))
+        if (!last && grid_reached[g] && grid_reached[g + 1])
             continue;
         for (unsigned n = g * kGrid + 1; n < std::min(kHelperBits, (g + 1) * kGrid); ++n)
             if (wanted(n))
@@ -384,6 +403,33 @@ bool probe_helpers(Fence &fence, r433_r_device *dev, r433_helper_probe *blk, std
             tab[1 * kPfBits + n] = got[n];
             useful = true;
         }
+    // the search rule: the (start, pattern, code) most candidate lengths share, and those lengths
+    if (!cands.empty()) {
+        size_t best = 0, best_n = 0;
+        for (size_t i = 0; i < cands.size(); ++i) {
+            size_t cnt = 0;
+            for (auto const &c : cands)
+                cnt += c.second == cands[i].second;
+            if (cnt > best_n)
+                best = i, best_n = cnt;
+        }
+        Cand const rule = cands[best].second;
+        uint64_t lens = 0;
+        for (auto const &c : cands)
+            if (c.second == rule) {
+                if (verdict_of(ask(c.first, -1)) != rule.code) // (asked again, as above)
+                    return false;
+                lens |= 1ull << c.first;
+            }
+        uint8_t *const r = tab.data() + kPfRule; // (in the unused part of the table's row for empty bitbuffers)
+        r[0] = rule.code;
+        r[1] = (uint8_t)rule.plen;
+        uint16_t const st = (uint16_t)rule.start;
+        memcpy(r + 2, &st, 2);
+        memcpy(r + 4, &rule.pat, 4);
+        memcpy(r + 8, &lens, 8);
+        useful = true;
+    }
     return true;
 }
 

@@ -160,6 +160,12 @@ constexpr uint32_t kPfRows = 51, kPfBits = 1024, kPfKeep = 0xff;
 // found by asking the decoder every content such a row can have (prefilter.cpp probe_tiny), not under the memory fence
 constexpr uint32_t kPfTiny = 0x40;
 constexpr uint32_t kPfTable = kPfRows * kPfBits;
+// The table's row for num_rows == 0 only ever uses its first byte (an empty bitbuffer has no row 0): bytes 16..31 of it hold the
+// decoder's SEARCH RULE (r433_helper_probe: the decoder's first act on a one-row bitbuffer is bitbuffer_search(row 0, start,
+// pattern), and with the answer "not found" it refuses under `code` without a look at anything else) --
+//   [16] code (kPfKeep: no rule)  [17] pattern bits (1..32)  [18..19] start  [20..23] the pattern, left-aligned in a u32
+//   [24..31] u64: bit n set = the rule holds for one-row bitbuffers of n bits (n < 64)
+constexpr uint32_t kPfRule = 16, kPfRuleMaxBits = 64;
 
 struct SliceParams {
     uint8_t const *arena;

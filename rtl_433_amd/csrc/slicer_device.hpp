@@ -44,6 +44,7 @@ template <bool WRITE> struct BitSink {
     uint32_t extent;    // most bits the current row ever held
     uint32_t written;   // dwords of the current row already stored
     uint32_t acc;       // bits of the dword being filled, MSB first
+    uint32_t w0;        // the first dword of the current row once it is full (the pre-filter's search rule looks at rows of < 64 bits)
     uint32_t row_hdr;   // offset of the current row's header (relative to out)
     uint32_t wr;        // write cursor (relative to out)
     // decoder pre-filter (r433_batch_probe_prefilter): the decoder's table, and what it refused so far
@@ -74,7 +75,7 @@ template <bool WRITE> struct BitSink {
     {
         num_rows = free_row = 0;
         row0_bits = cur_bits = cur_syncs = 0;
-        extent = written = acc = 0;
+        extent = written = acc = w0 = 0;
         wr = off + (uint32_t)sizeof(r433_evt_rec);
         row_hdr = wr;
     }
@@ -84,7 +85,7 @@ template <bool WRITE> struct BitSink {
         row_hdr = wr;
         wr += (uint32_t)sizeof(r433_row_rec);
         cur_bits = cur_syncs = 0;
-        extent = written = acc = 0;
+        extent = written = acc = w0 = 0;
     }
 
     __device__ __forceinline__ void touch()
@@ -143,6 +144,8 @@ template <bool WRITE> struct BitSink {
             store_word(k, acc);
             if (k >= written)
                 written = k + 1;
+            if (k == 0)
+                w0 = acc;
             acc = 0;
         }
     }
@@ -181,6 +184,8 @@ template <bool WRITE> struct BitSink {
                 store_word(k, acc);
                 if (k >= written)
                     written = k + 1;
+                if (k == 0)
+                    w0 = acc;
                 acc = 0;
             }
         }
@@ -236,6 +241,21 @@ template <bool WRITE> struct BitSink {
             uint32_t verdict = pf[num_rows * kPfBits + row0_bits];
             if (verdict != kPfKeep && (verdict & kPfTiny)) // asked content by content for plain one-row bitbuffers only
                 verdict = (num_rows == 1 && cur_syncs == 0 && extent == cur_bits) ? (verdict & ~kPfTiny) : kPfKeep;
+            // The decoder's search rule (kPfRule): its first act on a one-row bitbuffer of this length is bitbuffer_search(row 0,
+            // start, pattern) and "not found" makes it refuse without a look at anything else.  A row of fewer than 64 bits that
+            // never shrank is still in w0 / acc: look for the pattern (src/bitbuffer.c:228-253 finds the first place from `start`
+            // on where all pattern bits lie inside the row and match).
+            if (verdict == kPfKeep && num_rows == 1 && row0_bits < kPfRuleMaxBits && extent == cur_bits && pf[kPfRule] != kPfKeep
+                    && ((*(uint64_t const *)(pf + kPfRule + 8) >> row0_bits) & 1ull)) {
+                uint32_t const plen = pf[kPfRule + 1], start = *(uint16_t const *)(pf + kPfRule + 2);
+                uint32_t const pat = *(uint32_t const *)(pf + kPfRule + 4) >> (32u - plen);
+                uint64_t const row = cur_bits < 32u ? (uint64_t)acc << 32 : ((uint64_t)w0 << 32) | acc; // bit i of the row = bit 63 - i
+                bool found = false;
+                for (uint32_t at = start; at + plen <= cur_bits && !found; ++at)
+                    found = (uint32_t)((row << at) >> (64u - plen)) == pat;
+                if (!found)
+                    verdict = pf[kPfRule];
+            }
             if (verdict != kPfKeep) {
                 pf_d0 += verdict == 0u || verdict > 4u;
                 pf_d1 += verdict == 1u;
