@@ -253,6 +253,19 @@ def test_prefilter_helper_probe_plugins(backend, helper_plugins):
     assert b["nev"] < f["nev"] < a["nev"]
 
 
+def test_wrapped_bitbuffer_search_is_the_reference_one():
+    """dropin/helper_wrap.c answers the decoders' bitbuffer_search calls with a word-parallel search of its own outside the
+    probe: it must return what src/bitbuffer.c:228-253 returns, for every row, start and pattern (the library holds both and
+    compares them on random cases: rows around every length edge, patterns cut from the row itself half of the time)."""
+    from rtl_433_amd import plugins
+    if not plugins.available():
+        pytest.skip("dropin/_build/libr433plugins.so not built")
+    L = C.CDLL(os.path.abspath(plugins.LIB_PATH))
+    L.r433_host_wrap_selftest.restype = C.c_uint
+    for seed in range(3):
+        assert L.r433_host_wrap_selftest(seed, 1000000) == 0
+
+
 def test_prefilter_helper_probe_real_decoders(backend):
     """The plugin library's real decoders (dropin/_build/libr433plugins.so, linked with dropin/helper_wrap.c) asked with their
     helpers wrapped: statistics of all 335, decoded events and what every package produced are the same as without the filter,
@@ -285,7 +298,7 @@ def test_prefilter_helper_probe_real_decoders(backend):
     assert b["tables"] >= f["tables"] > 200
     for r in (f, b):
         assert a["stats"] == r["stats"] and a["per_pkg"] == r["per_pkg"] and a["decoded"] == r["decoded"]
-    assert b["nev"] < 0.7 * f["nev"] and f["nev"] < 0.3 * a["nev"]
+    assert b["nev"] < 0.8 * f["nev"] and f["nev"] < 0.3 * a["nev"]  # (the wrapped search is lazier than the reference's: the fence alone learns the rows a pattern cannot fit in)
     assert b["neptune"] > f["neptune"]
 
 
