@@ -287,9 +287,10 @@ int r433_batch_decoded(r433_batch *b, int const **per_package, uint32_t *count);
  * decoder that is a function of its arguments then returns that code for every bitbuffer with that head.  From the next run
  * on the slicer kernel drops such records where it builds them (they are neither staged, copied to the host nor replayed)
  * and counts them per decoder and code; the dispatch functions add the counts to decode_events / decode_fails exactly as
- * account_event would have, so `-M stats` is unchanged.  Only decoders of the lowest priority level are filtered (the others
- * are not called for every package, src/r_api.c:442-451), only with verbose == 0 (account_event prints refused bitbuffers at
- * -vv), and never together with an event_done hook or a package_filter.  One-row bitbuffers of at most 14 bits are asked
+ * account_event would have, so `-M stats` is unchanged.  Decoders of later priority levels are not called for every package
+ * (src/r_api.c:442-451): what they provably refuse crosses as a 16-byte stub (R433_EVT_STUB, include/r433_records.h) that the
+ * replay books without a call where it reaches that level.  Only decoders with verbose == 0 are filtered (account_event prints
+ * refused bitbuffers at -vv), and never together with an event_done hook or a package_filter.  One-row bitbuffers of at most 14 bits are asked
  * content by content as well: every one of the 2^n rows on an ordinary cleared bitbuffer_t, twice; where all of them get the
  * same failure code, a bitbuffer of exactly that shape (one row, no sync pulses before it, nothing ever written behind its
  * bits) is dropped under that code too.  decode_fn is called n times per decoder here (~50 000 heads and up to 65 534 tiny

@@ -62,6 +62,13 @@ typedef struct r433_evt_rec {
     uint16_t free_row;    /* bitbuffer_t.free_row */
 } r433_evt_rec;
 
+/* With the decoder pre-filter on (r433_batch_probe_prefilter) a record may be a STUB: an r433_evt_rec alone (total_bytes 16)
+ * with num_rows = R433_EVT_STUB and the failure code (0..4 = -return value) in free_row.  It stands for a bitbuffer that its
+ * decoder provably refuses with that code, where the decoder sits on a later priority level (reference src/r_api.c:442-451):
+ * whether the refusal counts in the decoder's statistics depends on what the levels before it decode of the package, which
+ * only the replay knows -- it books a stub it reaches like the refusal, without a call. */
+#define R433_EVT_STUB 0xffffu
+
 typedef struct r433_row_rec {
     uint16_t bits;   /* bits_per_row[r] */
     uint16_t syncs;  /* syncs_before_row[r] */

@@ -151,6 +151,20 @@ int dispatch_range(r433_batch *b, r433_r_device *const *devices, uint32_t n_devi
                     uint8_t const *rec = ev + refs[first[dev] + k];
                     r433_evt_rec eh;
                     memcpy(&eh, rec, sizeof(eh));
+                    if (eh.num_rows == kPfStubRows) { // a bitbuffer the pre-filter proved refused (a decoder of a later level: kPfStub)
+                        unsigned const code = std::min<unsigned>(eh.free_row, 4u);
+                        if (hooks) { // (the hooks form moves the r_device's counters as it goes)
+                            if (rd) {
+                                rd->decode_events += 1;
+                                rd->decode_fails[code] += 1;
+                            }
+                        }
+                        else {
+                            stats[dev].events += 1;
+                            stats[dev].fails[code] += 1;
+                        }
+                        continue;
+                    }
                     // inflate into the reference bitbuffer layout
                     bits->num_rows = eh.num_rows;
                     bits->free_row = eh.free_row;
@@ -481,6 +495,11 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
     };
     auto call_one = [&](uint32_t dev, uint8_t const *rec, r433_evt_rec const &eh, r433_bitbuffer *bits, Tally &t) -> bool {
         r433_r_device *rd = devices[dev];
+        if (eh.num_rows == kPfStubRows) { // a bitbuffer the pre-filter proved refused, of a decoder on a later level (kPfStub)
+            t.n_ev += 1;
+            t.fails[std::min<unsigned>(eh.free_row, 4u)] += 1;
+            return true;
+        }
         inflate_bits(bits, rec, eh);
         uint32_t used_rows = std::max<uint32_t>(eh.num_rows, eh.free_row);
         g_current.stream = pkg_stream[eh.pkg];

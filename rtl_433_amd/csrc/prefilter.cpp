@@ -559,8 +559,9 @@ int r433_batch_probe_prefilter(r433_batch *b, r433_r_device *const *devices, uin
     std::vector<uint8_t> eligible(n_devices, 0);
     for (uint32_t d = 0; d < n_devices; ++d) {
         r433_r_device *dev = devices[d];
-        // only decoders that are called for every package, and quietly (account_event prints refused bitbuffers at -vv)
-        if (!dev || !dev->decode_fn || dev->verbose || b->timing[d].priority != lowest)
+        // only quiet decoders (account_event prints refused bitbuffers at -vv).  Those of later priority levels are not called
+        // for every package: what the filter proves refused goes along as a stub, the replay books it if it gets there (kPfStub)
+        if (!dev || !dev->decode_fn || dev->verbose)
             continue;
         eligible[d] = 1;
         keys[d] = ProbeKey::of(dev);
@@ -620,6 +621,7 @@ int r433_batch_probe_prefilter(r433_batch *b, r433_r_device *const *devices, uin
         if (known != g_known.end() && !known->second.empty()) {
             b->pf_index[d] = (int)(b->pf_tables.size() / kPfTable);
             b->pf_tables.insert(b->pf_tables.end(), known->second.begin(), known->second.end());
+            b->pf_tables[b->pf_tables.size() - kPfTable + kPfStub] = b->timing[d].priority != lowest ? 1 : 0; // (this engine's copy)
             filtered += 1;
         }
     }

@@ -166,6 +166,11 @@ constexpr uint32_t kPfTable = kPfRows * kPfBits;
 //   [16] code (kPfKeep: no rule)  [17] pattern bits (1..32)  [18..19] start  [20..23] the pattern, left-aligned in a u32
 //   [24..31] u64: bit n set = the rule holds for one-row bitbuffers of n bits (n < 64)
 constexpr uint32_t kPfRule = 16, kPfRuleMaxBits = 64;
+// [40] of the same row: the decoder sits on a LATER priority level (src/r_api.c:442-451: called only for packages the levels
+// before it decoded nothing of), so whether a refused bitbuffer counts in its statistics is the replay's to know: the slicer
+// then leaves a 16-byte STUB in the record's place -- an r433_evt_rec alone with num_rows = kPfStubRows and the refusal's code
+// in free_row -- which the replay books like the refusal it stands for, when and if it reaches that level for the package
+constexpr uint32_t kPfStub = 40, kPfStubRows = 0xffffu;
 
 struct SliceParams {
     uint8_t const *arena;

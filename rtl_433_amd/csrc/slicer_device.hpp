@@ -256,6 +256,16 @@ template <bool WRITE> struct BitSink {
                 if (!found)
                     verdict = pf[kPfRule];
             }
+            if (verdict != kPfKeep && pf[kPfStub] == 1u) { // a later priority level: the refusal goes along as a stub
+                put32(off, (uint32_t)sizeof(r433_evt_rec));
+                put32(off + 4, pkg);
+                put32(off + 8, (uint32_t)dev | ((uint32_t)ordinal << 16));
+                put32(off + 12, kPfStubRows | (min(verdict, 4u) << 16));
+                off += (uint32_t)sizeof(r433_evt_rec);
+                ordinal++;
+                clear();
+                return;
+            }
             if (verdict != kPfKeep) {
                 pf_d0 += verdict == 0u || verdict > 4u;
                 pf_d1 += verdict == 1u;

@@ -25,6 +25,9 @@ def records(blob):
         total, pkg = np.frombuffer(blob, "<u4", 2, at)
         dev, ordinal, num_rows, free_row = np.frombuffer(blob, "<u2", 4, at + 8)
         rows, p = [], at + 16
+        if int(num_rows) == 0xffff:  # a stub: a refusal of a later-level decoder, booked by the replay (kPfStub)
+            at += int(total)
+            continue
         for _ in range(int(num_rows)):
             bits, syncs, nbytes, _r = np.frombuffer(blob, "<u2", 4, p)
             rows.append((int(bits), int(syncs), bytes(blob[p + 8:p + 8 + int(nbytes)])))
