@@ -133,6 +133,11 @@ int __wrap_bitbuffer_find_repeated_row(bitbuffer_t *bits, unsigned min_repeats, 
         t_block.repeats += 1;
         return bits->bits_per_row[0] >= min_bits && 1u >= min_repeats ? 0 : -1;
     }
+    if (ASKED(bits) && t_block.rows_below && min_bits >= t_block.rows_below) {
+        t_block.repeats += 1; /* every row is supposed shorter than min_bits: none qualifies (src/bitbuffer.c:513-533) */
+        t_block.min_bits = min_bits;
+        return -1;
+    }
     int row;
     PROFILED(2, bits->num_rows, row = __real_bitbuffer_find_repeated_row(bits, min_repeats, min_bits));
     return row;
@@ -143,6 +148,11 @@ int __wrap_bitbuffer_find_repeated_prefix(bitbuffer_t *bits, unsigned min_repeat
     if (ASKED(bits) && bits->num_rows == 1) {
         t_block.repeats += 1;
         return bits->bits_per_row[0] >= min_bits && 1u >= min_repeats ? 0 : -1;
+    }
+    if (ASKED(bits) && t_block.rows_below && min_bits >= t_block.rows_below) {
+        t_block.repeats += 1; /* every row is supposed shorter than min_bits: none qualifies (src/bitbuffer.c:513-533) */
+        t_block.min_bits = min_bits;
+        return -1;
     }
     int row;
     PROFILED(3, bits->num_rows, row = __real_bitbuffer_find_repeated_prefix(bits, min_repeats, min_bits));

@@ -313,8 +313,10 @@ void r433_prefilter_forget(void);
  *   bitbuffer_search            `answer` for the first call of a question (a bit position, or < 0: "not found" = the row's
  *                               length), and they leave row / start / pattern_bits here; a second call sets `overflow`
  *   bitbuffer_find_repeated_*   on a ONE-row bitbuffer the row compares equal to itself whatever it holds: 0 if it is long
- *                               enough and one repeat suffices, else -1 (`repeats` counts); other row counts go to the real
- *                               function (and fault)
+ *                               enough and one repeat suffices, else -1 (`repeats` counts); on several rows -1 where the
+ *                               question supposes every row shorter than the call's min_bits (`rows_below`: the verdict is
+ *                               then kept for bitbuffers whose longest row is that short, which the slicer kernel knows),
+ *                               else the real function (which faults)
  * -- and the probe asks a head once per answer the real helper could have given (every position from `start` to length -
  * pattern_bits, and "not found").  Only where ALL of them make decode_fn return the same failure code, again without a look at
  * anything behind the head, that code becomes the verdict of the head: it holds for every payload.  One-row heads of up to
@@ -335,7 +337,11 @@ typedef struct r433_helper_probe {
     uint32_t row, start, pattern_bits; /* ... arguments of the first */
     uint32_t inverts, repeats;         /* ... bitbuffer_invert / bitbuffer_find_repeated_* calls answered without the payload */
     uint8_t pattern[8];    /* ... and the first bytes of its pattern (as many as pattern_bits needs, at most eight) */
-    uint32_t reserved[4];
+    uint32_t rows_below;   /* library -> wrappers: the question supposes that EVERY row of the subject has fewer bits than this
+                            * (0: nothing supposed); bitbuffer_find_repeated_* on several rows then answers -1 where its
+                            * min_bits is at least this -- no row can qualify, whatever the rows hold -- */
+    uint32_t min_bits;     /* ... and leaves its min_bits here (wrappers -> library) */
+    uint32_t reserved[2];
 } r433_helper_probe;
 typedef r433_helper_probe *(*r433_helper_probe_fn)(int session); /* -> the calling thread's block */
 void r433_prefilter_set_helper_probe(r433_helper_probe_fn host_block);

@@ -85,10 +85,10 @@ struct Handlers {
 struct Fence {
     uint8_t *region = nullptr;
     size_t page = 0;
-    r433_bitbuffer *bits = nullptr; // its first six bytes end the readable page
+    r433_bitbuffer *bits = nullptr; // its first six (or eight) bytes end the readable page
     bool ok = false;
 
-    Fence()
+    explicit Fence(unsigned readable_words = 3) // num_rows, free_row, bits_per_row[0 .. readable_words - 3]
     {
         long const ps = sysconf(_SC_PAGESIZE);
         page = ps > 0 ? (size_t)ps : 4096;
@@ -101,7 +101,7 @@ struct Fence {
         total = page + tail;
         if (mprotect(region + page, tail, PROT_NONE) != 0)
             return;
-        bits = (r433_bitbuffer *)(region + page - 6);
+        bits = (r433_bitbuffer *)(region + page - 2 * readable_words);
         ok = true;
     }
     ~Fence()
@@ -122,6 +122,23 @@ struct Fence {
         head[2] = (uint16_t)bits0;
         int ret = INT_MIN;
         if (sigsetjmp(t_jump, 0) == 0) { // (the handler runs with SA_NODEFER and an empty mask: no signal mask to put back)
+            t_armed = 1;
+            ret = dev->decode_fn(dev, bits);
+            t_armed = 0;
+        }
+        return ret;
+    }
+
+    // a two-row head, on a fence that leaves bits_per_row[1] readable
+    int ask2(r433_r_device *dev, unsigned bits0, unsigned bits1)
+    {
+        uint16_t *head = (uint16_t *)bits;
+        head[0] = 2;
+        head[1] = 2;
+        head[2] = (uint16_t)bits0;
+        head[3] = (uint16_t)bits1;
+        int ret = INT_MIN;
+        if (sigsetjmp(t_jump, 0) == 0) {
             t_armed = 1;
             ret = dev->decode_fn(dev, bits);
             t_armed = 0;
@@ -279,9 +296,11 @@ void probe_tiny(r433_r_device *dev, std::vector<uint8_t> &tab, bool &useful, boo
 
 bool probe_heads(Fence &fence, r433_r_device *dev, std::vector<uint8_t> &tab, bool &useful, bool &accepts);
 bool probe_helpers(Fence &fence, r433_r_device *dev, r433_helper_probe *blk, std::vector<uint8_t> &tab, bool &useful);
+bool probe_two_rows(Fence &fence2, r433_r_device *dev, r433_helper_probe *blk, std::vector<uint8_t> &tab, bool &useful);
+bool probe_short_rows(Fence &fence, r433_r_device *dev, r433_helper_probe *blk, std::vector<uint8_t> &tab, bool &useful);
 
 // Every question one decoder is asked.  True: `tab` holds its verdicts (something to filter, answers steady).
-bool probe_one(Fence &fence, r433_r_device *dev, r433_helper_probe *blk, std::vector<uint8_t> &tab)
+bool probe_one(Fence &fence, Fence &fence2, r433_r_device *dev, r433_helper_probe *blk, std::vector<uint8_t> &tab)
 {
     struct Quiet { // outputs off for the time of the questions
         r433_r_device *d;
@@ -305,8 +324,136 @@ bool probe_one(Fence &fence, r433_r_device *dev, r433_helper_probe *blk, std::ve
         return false;
     if (blk && !probe_helpers(fence, dev, blk, tab, useful))
         return false;
+    if (!probe_two_rows(fence2, dev, blk, tab, useful))
+        return false;
+    if (blk && !probe_short_rows(fence, dev, blk, tab, useful))
+        return false;
     probe_tiny(dev, tab, useful, accepts);
     return useful && !accepts;
+}
+
+// Bitbuffers of several rows that are ALL short (a slicer with a short gap limit makes a row per pulse out of a burst that is
+// not its decoder's: twenty rows of one to three bits): a decoder that opens with bitbuffer_find_repeated_row(min_repeats,
+// min_bits) finds no row that qualifies and refuses -- but the helper walks the row lengths, which lie behind the fence.  With
+// the host's wrappers the question SUPPOSES every row shorter than min_bits (r433_helper_probe.rows_below), the wrapper answers
+// -1 on that supposition alone, and a refusal that follows without a look at anything else holds for every bitbuffer of that
+// head whose longest row is that short: stored with kPfShort, the bound at kPfShortAt.  False: the answers moved.
+bool probe_short_rows(Fence &fence, r433_r_device *dev, r433_helper_probe *blk, std::vector<uint8_t> &tab, bool &useful)
+{
+    auto ask = [&](unsigned rows, unsigned n, unsigned below) -> int {
+        blk->answer = -1;
+        blk->subject = fence.bits;
+        blk->searches = blk->overflow = blk->row = blk->start = blk->pattern_bits = blk->inverts = blk->repeats = blk->min_bits = 0;
+        blk->rows_below = below;
+        blk->armed = 1;
+        int const ret = fence.ask(dev, rows, n);
+        blk->armed = 0;
+        blk->rows_below = 0;
+        return ret;
+    };
+    // the decoder's min_bits: what its helper asks for when every row is supposed to have at most one bit
+    unsigned bound = 0;
+    {
+        int const r = ask(3, 1, 2);
+        if (verdict_of(r) == kPfKeep || !blk->repeats || blk->searches || blk->min_bits < 2 || blk->min_bits > 0xffffu)
+            return true; // (not this kind of decoder)
+        bound = blk->min_bits;
+    }
+    std::vector<std::pair<unsigned, uint8_t>> got; // (table index, code)
+    for (unsigned rows = 2; rows < kPfHeadRows; ++rows) {
+        unsigned in_a_row = 0;
+        for (unsigned n = 0; n < bound && n < kPfBits && in_a_row < 2; ++n) {
+            if (tab[rows * kPfBits + n] != kPfKeep)
+                continue; // (the head alone settles it)
+            int const r = ask(rows, n, bound);
+            uint8_t const v = verdict_of(r);
+            bool const good = v != kPfKeep && blk->repeats && !blk->searches && blk->min_bits == bound;
+            in_a_row = good ? 0 : in_a_row + 1;
+            if (good)
+                got.push_back({rows * kPfBits + n, v});
+        }
+    }
+    for (auto const &g : got) // once more
+        if (verdict_of(ask(g.first / kPfBits, g.first % kPfBits, bound)) != g.second)
+            return false;
+    if (got.empty())
+        return true;
+    for (auto const &g : got)
+        tab[g.first] = (uint8_t)(kPfShort | g.second);
+    uint16_t const b16 = (uint16_t)bound;
+    memcpy(tab.data() + kPfShortAt, &b16, 2);
+    useful = true;
+    return true;
+}
+
+// Bitbuffers of exactly two rows, by both rows' lengths (kPfTwoAt): the fence leaves bits_per_row[1] readable as well, and a
+// head is (2, 2, bits0, bits1).  With the host's wrappers the helpers answer as in probe_helpers (a search is told "not
+// found" and every position it could have found; a repeated-row test on two rows goes to the real helper, which compares
+// lengths first and payloads only if they tie).  False: the answers moved.
+bool probe_two_rows(Fence &fence2, r433_r_device *dev, r433_helper_probe *blk, std::vector<uint8_t> &tab, bool &useful)
+{
+    auto ask = [&](unsigned n0, unsigned n1, int answer) -> int {
+        if (blk) {
+            blk->answer = answer;
+            blk->subject = fence2.bits;
+            blk->searches = blk->overflow = blk->row = blk->start = blk->pattern_bits = blk->inverts = blk->repeats = 0;
+            blk->armed = 1;
+        }
+        int const ret = fence2.ask2(dev, n0, n1);
+        if (blk)
+            blk->armed = 0;
+        return ret;
+    };
+    auto verdict = [&](unsigned n0, unsigned n1) -> uint8_t {
+        int const r0 = ask(n0, n1, -1);
+        uint8_t const v0 = verdict_of(r0);
+        if (v0 == kPfKeep || (blk && blk->overflow))
+            return (uint8_t)kPfKeep;
+        if (blk && blk->searches) {
+            unsigned const row = blk->row, start = blk->start, plen = blk->pattern_bits, n = row == 0 ? n0 : n1;
+            if (row > 1)
+                return (uint8_t)kPfKeep;
+            if (plen >= 1 && plen <= n)
+                for (unsigned pos = start; pos + plen <= n; ++pos)
+                    if (ask(n0, n1, (int)pos) != r0 || blk->overflow || !blk->searches || blk->row != row || blk->start != start || blk->pattern_bits != plen)
+                        return (uint8_t)kPfKeep;
+        }
+        return v0;
+    };
+    // a decoder that reaches for the payload whatever the two lengths say is not asked a thousand times
+    static unsigned const sample[8][2] = {{1, 0}, {0, 0}, {1, 1}, {2, 0}, {40, 0}, {9, 3}, {64, 1}, {127, 7}};
+    bool any = false;
+    for (auto const &q : sample)
+        any |= ask(q[0], q[1], -1) != INT_MIN;
+    if (!any)
+        return true;
+    uint8_t *const two = tab.data() + kPfTwoAt;
+    std::vector<uint8_t> got(kPfTwo0 * kPfTwo1, (uint8_t)kPfKeep);
+    // (faults are what costs: two second-row lengths in a row that make the decoder reach for the payload end a first-row
+    // length, twenty such first-row lengths in a row end the questions)
+    unsigned faults = 0, barren = 0;
+    for (unsigned n0 = 0; n0 < kPfTwo0 && faults < 300 && barren < 20; ++n0) {
+        if (tab[2 * kPfBits + n0] != kPfKeep)
+            continue; // (the head alone settles it)
+        unsigned in_a_row = 0, learned = 0;
+        for (unsigned n1 = 0; n1 < kPfTwo1 && in_a_row < 2; ++n1) {
+            uint8_t const v = verdict(n0, n1);
+            got[n0 * kPfTwo1 + n1] = v;
+            in_a_row = v == kPfKeep ? in_a_row + 1 : 0;
+            faults += v == kPfKeep;
+            learned += v != kPfKeep;
+        }
+        barren = learned ? 0 : barren + 1;
+    }
+    for (unsigned i = 0; i < kPfTwo0 * kPfTwo1; ++i) // once more (only refusals: no faults unless the decoder moved)
+        if (got[i] != kPfKeep && verdict_of(ask(i / kPfTwo1, i % kPfTwo1, -1)) != got[i])
+            return false;
+    for (unsigned i = 0; i < kPfTwo0 * kPfTwo1; ++i)
+        if (got[i] != kPfKeep) {
+            two[i] = got[i];
+            useful = true;
+        }
+    return true;
 }
 
 // The questions a host with wrapped bitbuffer helpers makes possible (include/r433_hip.h, r433_helper_probe): one-row heads
@@ -588,8 +735,8 @@ int r433_batch_probe_prefilter(r433_batch *b, r433_r_device *const *devices, uin
         std::atomic<int> no_pages{0};
         r433_helper_probe_fn const helper = g_helper;
         b->pool.run(nt, [&](unsigned) {
-            Fence fence;
-            if (!fence.ok) {
+            Fence fence, fence2(4);
+            if (!fence.ok || !fence2.ok) {
                 no_pages.store(1);
                 return;
             }
@@ -598,7 +745,7 @@ int r433_batch_probe_prefilter(r433_batch *b, r433_r_device *const *devices, uin
                 uint32_t const k = cursor.fetch_add(1, std::memory_order_relaxed);
                 if (k >= ask_list.size())
                     break;
-                answered[k] = probe_one(fence, devices[ask_list[k]], blk, answers[k]) ? 1 : 0;
+                answered[k] = probe_one(fence, fence2, devices[ask_list[k]], blk, answers[k]) ? 1 : 0;
             }
             if (helper)
                 helper(-1);

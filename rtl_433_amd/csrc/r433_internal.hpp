@@ -159,6 +159,10 @@ constexpr uint32_t kPfRows = 51, kPfBits = 1024, kPfKeep = 0xff;
 // a verdict with this bit holds for one-row bitbuffers without a sync count and nothing written past the row's bits only: it was
 // found by asking the decoder every content such a row can have (prefilter.cpp probe_tiny), not under the memory fence
 constexpr uint32_t kPfTiny = 0x40;
+// a verdict with this bit holds for bitbuffers whose LONGEST row has fewer bits than the decoder's bound ([44..45] of the table's
+// first row, kPfShortAt): the decoder's first act is bitbuffer_find_repeated_row / _prefix with that min_bits, and where no row
+// can qualify it refuses without a look at anything else (r433_helper_probe.rows_below)
+constexpr uint32_t kPfShort = 0x20, kPfShortAt = 44;
 constexpr uint32_t kPfTable = kPfRows * kPfBits;
 // The table's row for num_rows == 0 only ever uses its first byte (an empty bitbuffer has no row 0): bytes 16..31 of it hold the
 // decoder's SEARCH RULE (r433_helper_probe: the decoder's first act on a one-row bitbuffer is bitbuffer_search(row 0, start,
@@ -171,6 +175,12 @@ constexpr uint32_t kPfRule = 16, kPfRuleMaxBits = 64;
 // then leaves a 16-byte STUB in the record's place -- an r433_evt_rec alone with num_rows = kPfStubRows and the refusal's code
 // in free_row -- which the replay books like the refusal it stands for, when and if it reaches that level for the package
 constexpr uint32_t kPfStub = 40, kPfStubRows = 0xffffu;
+// Heads are asked for up to kPfHeadRows - 1 rows; the table's rows behind them are free.  The last one holds the TWO-ROW table:
+// verdicts by (bits_per_row[0] < kPfTwo0, bits_per_row[1] < kPfTwo1) for bitbuffers of exactly two rows, learned like the heads
+// but with the second row's length on the readable side of the fence (a PWM slicer's "one bit, then a sync pulse opens an empty
+// second row" is most of what two-row bitbuffers are)
+constexpr uint32_t kPfHeadRows = 25, kPfTwo0 = 128, kPfTwo1 = 8, kPfTwoAt = (kPfRows - 1) * kPfBits;
+static_assert(kPfTwo0 * kPfTwo1 <= kPfBits, "the two-row table fits one row of the table");
 
 struct SliceParams {
     uint8_t const *arena;

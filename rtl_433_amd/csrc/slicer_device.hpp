@@ -34,8 +34,7 @@ template <bool WRITE> struct BitSink {
                         // region, so every store is bounded by this.
     uint32_t off;       // bytes of finished events
     uint32_t pkg;
-    uint16_t dev;
-    uint16_t ordinal;
+    uint32_t dev_ord;   // device | ordinal << 16 (the third word of a record, as it is written)
     // bitbuffer under construction
     uint32_t num_rows, free_row;
     uint32_t row0_bits; // bits_per_row[0]
@@ -44,12 +43,14 @@ template <bool WRITE> struct BitSink {
     uint32_t extent;    // most bits the current row ever held
     uint32_t written;   // dwords of the current row already stored
     uint32_t acc;       // bits of the dword being filled, MSB first
+    uint32_t max_bits;  // the longest CLOSED row of the bitbuffer under construction (the pre-filter's short-rows verdicts)
     uint32_t w0;        // the first dword of the current row once it is full (the pre-filter's search rule looks at rows of < 64 bits)
     uint32_t row_hdr;   // offset of the current row's header (relative to out)
     uint32_t wr;        // write cursor (relative to out)
     // decoder pre-filter (r433_batch_probe_prefilter): the decoder's table, and what it refused so far
     uint8_t const *pf;  // kPfTable verdicts, or nullptr
-    uint32_t pf_d0, pf_d1, pf_d2, pf_d3, pf_d4; // (five scalars, not an array: a dynamically indexed array would live in scratch memory)
+    uint64_t pf_dropped; // ... per code 0..4 in fields of 12 bits (a package has at most 1200 pulses, so at most 1200 bitbuffers per
+                         // decoder; one value, not an array: a dynamically indexed array would live in scratch memory)
 
     __device__ __forceinline__ void put32(uint32_t at, uint32_t v)
     {
@@ -63,10 +64,9 @@ template <bool WRITE> struct BitSink {
         limit = limit_;
         off = 0;
         pkg = pkg_;
-        dev = (uint16_t)dev_;
-        ordinal = 0;
+        dev_ord = dev_ & 0xffffu;
         pf = nullptr;
-        pf_d0 = pf_d1 = pf_d2 = pf_d3 = pf_d4 = 0;
+        pf_dropped = 0;
         clear();
     }
 
@@ -74,7 +74,7 @@ template <bool WRITE> struct BitSink {
     __device__ __forceinline__ void clear()
     {
         num_rows = free_row = 0;
-        row0_bits = cur_bits = cur_syncs = 0;
+        row0_bits = cur_bits = cur_syncs = max_bits = 0;
         extent = written = acc = w0 = 0;
         wr = off + (uint32_t)sizeof(r433_evt_rec);
         row_hdr = wr;
@@ -116,6 +116,7 @@ template <bool WRITE> struct BitSink {
         uint32_t k = cur_bits >> 5;
         if (cur_bits & 31u)
             store_word(k, acc);
+        max_bits = max(max_bits, cur_bits);
         uint32_t nbytes = (extent + 7u) >> 3;
         put32(row_hdr, (cur_bits & 0xffffu) | (cur_syncs << 16));
         put32(row_hdr + 4, nbytes & 0xffffu);
@@ -237,10 +238,14 @@ template <bool WRITE> struct BitSink {
         // A bitbuffer its decoder provably refuses on num_rows / free_row / bits_per_row[0] alone never becomes a record:
         // the next one is built over it (same offset, next ordinal), the refusal is counted under the code the decoder
         // would have returned.  Every pass of the slicer takes the same decisions, so sizes and offsets agree.
-        if (pf && num_rows <= R433_BB_ROWS && free_row == num_rows && row0_bits < kPfBits) {
+        if (pf && num_rows < kPfHeadRows && free_row == num_rows && row0_bits < kPfBits) {
             uint32_t verdict = pf[num_rows * kPfBits + row0_bits];
             if (verdict != kPfKeep && (verdict & kPfTiny)) // asked content by content for plain one-row bitbuffers only
                 verdict = (num_rows == 1 && cur_syncs == 0 && extent == cur_bits) ? (verdict & ~kPfTiny) : kPfKeep;
+            if (verdict != kPfKeep && (verdict & kPfShort)) // holds where no row reaches the decoder's min_bits (kPfShortAt)
+                verdict = max(max_bits, cur_bits) < (uint32_t) * (uint16_t const *)(pf + kPfShortAt) ? (verdict & ~kPfShort) : kPfKeep;
+            if (verdict == kPfKeep && num_rows == 2 && row0_bits < kPfTwo0 && cur_bits < kPfTwo1) // both rows' lengths (kPfTwoAt)
+                verdict = pf[kPfTwoAt + row0_bits * kPfTwo1 + cur_bits];
             // The decoder's search rule (kPfRule): its first act on a one-row bitbuffer of this length is bitbuffer_search(row 0,
             // start, pattern) and "not found" makes it refuse without a look at anything else.  A row of fewer than 64 bits that
             // never shrank is still in w0 / acc: look for the pattern (src/bitbuffer.c:228-253 finds the first place from `start`
@@ -259,20 +264,16 @@ template <bool WRITE> struct BitSink {
             if (verdict != kPfKeep && pf[kPfStub] == 1u) { // a later priority level: the refusal goes along as a stub
                 put32(off, (uint32_t)sizeof(r433_evt_rec));
                 put32(off + 4, pkg);
-                put32(off + 8, (uint32_t)dev | ((uint32_t)ordinal << 16));
+                put32(off + 8, dev_ord);
                 put32(off + 12, kPfStubRows | (min(verdict, 4u) << 16));
                 off += (uint32_t)sizeof(r433_evt_rec);
-                ordinal++;
+                dev_ord += 0x10000u;
                 clear();
                 return;
             }
             if (verdict != kPfKeep) {
-                pf_d0 += verdict == 0u || verdict > 4u;
-                pf_d1 += verdict == 1u;
-                pf_d2 += verdict == 2u;
-                pf_d3 += verdict == 3u;
-                pf_d4 += verdict == 4u;
-                ordinal++;
+                pf_dropped += 1ull << (12u * (verdict <= 4u ? verdict : 0u));
+                dev_ord += 0x10000u;
                 clear();
                 return;
             }
@@ -281,10 +282,10 @@ template <bool WRITE> struct BitSink {
             close_row();
         put32(off, wr - off);
         put32(off + 4, pkg);
-        put32(off + 8, (uint32_t)dev | ((uint32_t)ordinal << 16));
+        put32(off + 8, dev_ord);
         put32(off + 12, (num_rows & 0xffffu) | (free_row << 16));
         off = wr;
-        ordinal++;
+        dev_ord += 0x10000u;
         clear();
     }
 };

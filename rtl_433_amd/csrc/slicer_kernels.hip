@@ -51,7 +51,14 @@ enum { M_COUNT = 0, M_WRITE = 1, M_STAGE = 2, M_COMPACT = 3 };
 constexpr uint32_t kSmallW = 52;                 // weight (pulses / 5) from which a package is large
 constexpr uint32_t kSmallPulses = kSmallW * 5;   // a small package has fewer pulses than this
 
-template <int MODE, int CAP = R433_PD_MAX_PULSES> __global__ __launch_bounds__(64) void k_slice(SliceParams p)
+// (the small-package form lives on six wavefronts to a SIMD -- 2 KB of LDS each --: held to the 80 registers that takes; the
+// sink's fields grew with the pre-filter's rules and one register over is a wavefront less)
+#ifdef R433_EMU
+#define R433_SLICE_WAVES(cap)
+#else
+#define R433_SLICE_WAVES(cap) __attribute__((amdgpu_waves_per_eu((cap) < R433_PD_MAX_PULSES ? 6 : 1, 8)))
+#endif
+template <int MODE, int CAP = R433_PD_MAX_PULSES> __global__ __launch_bounds__(64) R433_SLICE_WAVES(CAP) void k_slice(SliceParams p)
 {
     constexpr bool PLACE = MODE == M_WRITE || MODE == M_COMPACT; // records go to their final offsets
     constexpr bool STORE = MODE != M_COUNT;                       // the sink stores bytes
@@ -169,11 +176,11 @@ template <int MODE, int CAP = R433_PD_MAX_PULSES> __global__ __launch_bounds__(6
                 slice_dispatch<STORE>(pv, t, sink);
                 my_bytes = sink.off;
                 if (!PLACE) { // the sizing pass counts; the placing pass only repeats its decisions
-                    dropped0 += sink.pf_d0;
-                    dropped1 += sink.pf_d1;
-                    dropped2 += sink.pf_d2;
-                    dropped3 += sink.pf_d3;
-                    dropped4 += sink.pf_d4;
+                    dropped0 += (uint32_t)(sink.pf_dropped & 0xfffu);
+                    dropped1 += (uint32_t)(sink.pf_dropped >> 12) & 0xfffu;
+                    dropped2 += (uint32_t)(sink.pf_dropped >> 24) & 0xfffu;
+                    dropped3 += (uint32_t)(sink.pf_dropped >> 36) & 0xfffu;
+                    dropped4 += (uint32_t)(sink.pf_dropped >> 48) & 0xfffu;
                 }
             }
             if (!PLACE)

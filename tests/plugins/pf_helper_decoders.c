@@ -156,3 +156,19 @@ int pfh_dec_search_position(struct r_device *d, bitbuffer_t *b)
         return -4;
     return at + 50 > len ? -1 : payload_verdict(b, 0);
 }
+
+/* 9. a repeated-row test, and where it fails the decoder walks the row lengths itself: the wrapper's "no row qualifies" rests on
+ * a supposition about lengths the decoder then LOOKS at -- behind the fence -- so nothing may be concluded for several rows */
+int pfh_dec_repeated_then_lengths(struct r_device *d, bitbuffer_t *b)
+{
+    (void)d;
+    pfh_calls[9]++;
+    int const row = bitbuffer_find_repeated_row(b, 2, 30);
+    if (row < 0) {
+        for (int r = 0; r < b->num_rows; ++r)
+            if (b->bits_per_row[r] > 2)
+                return -1;
+        return -2;
+    }
+    return payload_verdict(b, row);
+}

@@ -177,7 +177,8 @@ def test_prefilter_real_decoders(backend):
 
 
 HFNS = ["pfh_dec_search_then_length", "pfh_dec_search_two_codes", "pfh_dec_invert_then_length", "pfh_dec_invert_then_payload",
-        "pfh_dec_foreign_search", "pfh_dec_two_searches", "pfh_dec_repeated_row", "pfh_dec_repeated_once", "pfh_dec_search_position"]
+        "pfh_dec_foreign_search", "pfh_dec_two_searches", "pfh_dec_repeated_row", "pfh_dec_repeated_once", "pfh_dec_search_position",
+        "pfh_dec_repeated_then_lengths"]
 WRAP = "-Wl,--wrap=bitbuffer_invert,--wrap=bitbuffer_search,--wrap=bitbuffer_find_repeated_row,--wrap=bitbuffer_find_repeated_prefix"
 
 
@@ -207,6 +208,7 @@ def _helper_devices():
     devs[6] = (6, 250.0, 500.0, 1200.0, 800.0, 0.0, 120.0, 0)    # OOK_PWM: one- and several-row bitbuffers
     devs[7] = (5, 250.0, 500.0, 4000.0, 0.0, 0.0, 100.0, 0)      # OOK_PPM
     devs[8] = (4, 100.0, 100.0, 900.0, 0.0, 0.0, 0.0, 0)         # OOK_PCM, short reset
+    devs[9] = (6, 250.0, 500.0, 1200.0, 800.0, 0.0, 120.0, 0)    # OOK_PWM, as 6
     return devs
 
 
@@ -251,6 +253,10 @@ def test_prefilter_helper_probe_plugins(backend, helper_plugins):
     # with the wrappers: the searches (0, 1, 8), the inversion in front of a length test (2), the repeated-row tests (6, 7)
     for d in (0, 1, 2, 6, 7, 8):
         assert int(b["dropped"][d].sum()) > int(f["dropped"][d].sum()), d
+    # 6: bitbuffers of several rows, none long enough for its repeated-row test, go by the short-rows verdicts (the slicer
+    # kernel knows the longest row); 9 makes the same test and then walks the row lengths itself: only what one-row heads give
+    many = lambda recs, d: sum(1 for r in recs if int.from_bytes(r[8:10], "little") == d and 2 <= int.from_bytes(r[12:14], "little") < 0xffff)
+    assert many(b["records"], 6) < many(f["records"], 6) and many(b["records"], 9) == many(f["records"], 9) > 0
     # ... 3 looks at the payload whatever the length; 4 and 5 gain nothing (a foreign bitbuffer; a second search)
     assert int(b["dropped"][3].sum()) == 0
     assert int(b["dropped"][4].sum()) == int(f["dropped"][4].sum()) and int(b["dropped"][5].sum()) == int(f["dropped"][5].sum())
