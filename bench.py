@@ -454,7 +454,7 @@ def dropin_legs(host_iq, expect_json, reps=5):
 
 # ---------------------------------------------------------------- the software pipeline (configs 2 and 4)
 
-EXCLUSIVE = 3    # --exclusive: 1 the engines take turns on the detection kernel, 2 on the slicer kernels as well, 3 on the whole GPU leg, 0 no turns
+EXCLUSIVE = 2    # --exclusive: 1 the engines take turns on the detection kernel, 2 on the slicer kernels as well, 3 on the whole GPU leg, 0 no turns
 DEBUG_FLAGS = 0  # --debug: R433_DEBUG_* for every engine (development, A/B timing)
 NAP_WAIT = 2097152  # R433_DEBUG_NAP_WAIT (include/r433_hip.h)
 H2D_NAP = False     # --h2d-wait nap: the GPU leg's thread sleeps through its input copy instead of spinning (measured: no gain, 22.0-22.15 against 21.85 ms per step: the replay threads take what it frees)
@@ -1123,8 +1123,9 @@ def main():
     ap.add_argument("--stream-samples", type=int, default=0, help="configs 3 / 5: samples of the stream (0 = the recipe's)")
     ap.add_argument("--threads", type=int, default=0, help="host dispatch threads per rank (0 = auto)")
     ap.add_argument("--engines", type=int, default=3, help="batch engines in the software pipeline (>= 2)")
-    ap.add_argument("--exclusive", type=int, default=3, choices=[0, 1, 2, 3], help="pipeline: engines take turns on the detection kernel (1), on detection + slicers (2), "
-                    "on the whole GPU leg incl. the record copies (3, the default since round 5: with the replay down to the length of a GPU leg, record copies beside another engine's kernels cost the host more than they hide: 58 against 53 GS/s), not at all (0)")
+    ap.add_argument("--exclusive", type=int, default=2, choices=[0, 1, 2, 3], help="pipeline: engines take turns on the detection kernel (1), on detection + slicers (2, the default: "
+                    "record copies run beside the next engine's kernels), on the whole GPU leg incl. the record copies (3: the profile run; within 5 %% of 2 either way, "
+                    "profiles/r05_*), not at all (0)")
     ap.add_argument("--debug", type=lambda x: int(x, 0), default=0, help="development: R433_DEBUG_* flags for the engines (A/B timing)")
     ap.add_argument("--from-host", action="store_true", help="config 2: the timed region starts from pinned host memory (every step's H2D copy inside it: what "
                     "`pcie_inclusive` reports otherwise)")
