@@ -54,8 +54,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")  # separate rocprofv3 --pmc pass (tools/pmc_run.sh)
-PMC_ISSUE = os.path.join(ROOT, "profiles", "r04_pmc_issue.json")      # ... and the instruction counters of the same build
+def _newest(name):  # the committed counter passes of the latest round that has them
+    for rnd in ("r05", "r04"):
+        p = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
+        if os.path.exists(p):
+            return p
+    return os.path.join(ROOT, "profiles", f"r05_{name}")
+
+
+PMC_TRAFFIC = _newest("pmc_traffic.json")  # separate rocprofv3 --pmc passes (tools/pmc_traffic.py)
+PMC_ISSUE = _newest("pmc_issue.json")      # ... and the instruction counters of the same build (tools/pmc_issue.py)
 
 
 def _issue_note():
@@ -712,6 +720,7 @@ def run_batched(args, ctxd):
     solo = [pipe.gpu_leg(0, **leg_args_resident(i))[1] for i in range(1 if BK.emu else 5)]  # the kernel alone on the device, HIP events on its stream
     solo_det_ms = float(np.mean([t["detect_ms"] for t in solo]))
     solo_tot_ms = float(np.mean([t["total_ms"] for t in solo]))
+    solo_parts = {k: round(float(np.mean([t[k] for t in solo])), 3) for k in solo[0] if k != "total_ms"}
     pipe.stagger = solo_tot_ms / 1e3 / (pipe.n_eng - 1)
     pipe.run(args.warmup * per_step, leg_args)
     records.pop("acc", None)
@@ -762,7 +771,7 @@ def run_batched(args, ctxd):
                        **({} if strong else {"captures_per_batch": n_batch, "batches_per_step_per_gpu": args.batches,
                                               "note": f"the {args.batches} launches of {n_batch} captures of a step are issued as ONE grid of {n_streams} workgroups"}),
                        "parallelism": f"captures sharded over {world} GPU(s), no data-path collective; one variable-length gather of records to rank 0"},
-            "roofline": {"bound": "hbm", "kernel": "k_wave<2> (IQ -> packages)", "achieved": round(achieved, 2),
+            "roofline": {"bound": "hbm", "kernel": "k_wave<2> (IQ -> packages): the detection pass -- for grids of 6144 captures and more a launch of producers (filters), one of consumers (detector) and a run-again launch, timed together", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": pmc_traffic("config2" if not strong else "config4", alg_bytes, det_s),
                          "issue": ISSUE_NOTE,
@@ -771,6 +780,9 @@ def run_batched(args, ctxd):
                                  "this run: it is the HBM byte count of the committed counter pass (profiles/, tools/pmc_run.sh) over this run's kernel "
                                  "time.  The kernel is bound by wavefront instruction issue, not by HBM: see `issue` (DESIGN.md 3.1)"},
             "breakdown_ms": {"k_wave_timed_region": round(live_det_ms, 3), "k_wave_alone": round(solo_det_ms, 3), "gpu_leg_alone_incl_d2h": round(solo_tot_ms, 3),
+                             "gpu_leg_alone_parts": {**solo_parts, "what": "detect = the detection pass (k_wave: producers, consumers, run-again), dir = package directory, "
+                                                                            "count = the slicers' sizing pass (k_slice into staging slots, the pre-filter's verdicts applied), scan = offsets, "
+                                                                            "write = placing pass + slice index, d2h = records to pinned host memory"},
                              "gpu_leg_overlapped": round(float(np.mean(tot_ms)), 3),
                              "host_dispatch": round(float(np.mean(disp_s)) * 1e3, 3), "host_replay_call": round(replay_ms, 3), "engines": pipe.n_eng},
             "kernel_only": {"value": round(n_streams * n_samples / (live_det_ms * 1e-3) / 1e6, 1), "unit": "Msamples/s"},

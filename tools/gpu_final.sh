@@ -1,31 +1,28 @@
 #!/bin/bash
-# The closing GPU visit of a round: everything profiles/ quotes, from one build.  tools/gpu_final.sh <tag>
-TAG=${1:-final}
-OUT=gpurun_out/$TAG
-mkdir -p $OUT
+# The closing GPU visit of a round: everything profiles/<round>_* quotes, from one build, every step under its own timeout.
+#   tools/gpu_final.sh <tag>        (round 5: ~15 GPU minutes)
+TAG=${1:-r05}; OUT=gpurun_out/${TAG}_final; mkdir -p $OUT profiles
 export TMPDIR=/tmp
-bash tools/gpu_round.sh $TAG 2>&1 | grep -v amdgpu.ids | tail -30
-echo "== kbench (kernel alone; producer / consumer pair vs one wavefront, by grid size)"
-{ for n in 1024 3072 8192; do for f in 32768 4096; do timeout 300 python tools/kbench.py --nodevs --reps 7 --streams $n --debug $f 2>&1 | tail -1; done; done
-  timeout 300 python tools/kbench.py --reps 5 2>&1 | tail -1
-  timeout 300 python tools/kbench.py --reps 4 --streams 8192 2>&1 | tail -1
-  timeout 300 python tools/kbench.py --nodevs --cs16 2>&1 | tail -1
-  timeout 300 python tools/kbench.py --nodevs --fsk-cu8 2>&1 | tail -1; } 2>&1 | grep -v amdgpu.ids | tee $OUT/kbench.txt
-echo "== PMC traffic"
-timeout 900 python tools/pmc_traffic.py 2>&1 | tail -4
-echo "== PMC SQ (instruction mix of one launch of the bench batch)"
-for pmc in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
-  bash tools/pmc_run.sh ${TAG}_sq_$(echo $pmc | cut -d' ' -f2) "$pmc" --nodevs --streams 8192 2>&1 | grep k_wave | cut -c1-130
-done | tee $OUT/pmc_sq.txt
-echo "== configs 3 / 4 / 5"
-for c in 3 4 5; do timeout 900 python bench.py --config $c > $OUT/bench_c$c.json 2> $OUT/bench_c$c.err; python -c "
+echo "== SQ counters of the detection pass (producers / consumers apart)"
+R433_PMC_TAG=${TAG}_pmc timeout 500 python tools/pmc_issue.py </dev/null 2>&1 | tail -60 > $OUT/pmc_issue.txt; tail -12 $OUT/pmc_issue.txt
+[ -s gpurun_out/${TAG}_pmc/issue.json ] && cp gpurun_out/${TAG}_pmc/issue.json profiles/${TAG}_pmc_issue.json
+echo "== HBM traffic of the detection pass (FETCH_SIZE / WRITE_SIZE passes)"
+R433_PMC_TAG=${TAG}_pmc timeout 400 python tools/pmc_traffic.py config4 </dev/null 2>&1 | tail -3 | cut -c1-600
+[ -s gpurun_out/${TAG}_pmc/traffic.json ] && cp gpurun_out/${TAG}_pmc/traffic.json profiles/${TAG}_pmc_traffic.json
+echo "== bench (the driver's form)"
+timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err </dev/null; tail -2 $OUT/bench.err
+timeout 20 python -c "
 import json,sys
-d=json.load(open('$OUT/bench_c$c.json')); print('config $c:', d['value'], d['unit'], d['ms_per_step'], d.get('roofline',{}).get('frac'), d.get('parity'))"; done
-echo "== CLI drop-in"
-timeout 600 tools/cli_bench.sh 1024 $OUT 2>&1 | tail -3
-echo "== the C pipeline host"
-timeout 300 bash tools/pipeline_host_bench.sh 8192 2>&1 | tail -9 | tee $OUT/pipeline_host.txt
-echo "== probes: PCIe link, a pass beside a copy, capture order inside a grid"
-{ timeout 120 python tools/pcie_probe.py; timeout 120 python tools/overlap_probe.py; timeout 120 python tools/order_probe.py 8192; } 2>&1 | grep -v amdgpu.ids | tee $OUT/probes.txt
-echo "== fuzz (GPU, 8000 cases)"
-timeout 1500 python tools/fuzz_emu.py --gpu 8000 90000 2>&1 | tail -1 | tee $OUT/fuzz.txt
+d=json.load(open('$OUT/bench.json')); print({k: d.get(k) for k in ('value','ms_per_step','breakdown_ms','parity','bitbuffers_to_host_per_step','d2h_bytes_per_step_per_gpu')}); print(d.get('roofline',{}).get('frac'), d.get('roofline',{}).get('traffic'), d.get('pcie_inclusive'), d.get('cpu_baseline')); print({k: (v.get('value'), v.get('roofline',{}).get('frac'), v.get('parity')) for k, v in (d.get('other_configs') or {}).items() if isinstance(v, dict)}); print(json.dumps(d.get('dropin'))[:900])" </dev/null
+echo "== rocprofv3 kernel trace of the resident pipeline"
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 12 --warmup 3 --quick --exclusive 3 > $GRAFT_REPO_ROOT/$OUT/prof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err </dev/null )
+DB=$(find $OUT/prof -name '*.db' | head -1)
+[ -n "$DB" ] && timeout 60 python tools/rocprof_summary.py $DB $OUT/kernel_stats.txt </dev/null | head -30
+find $OUT/prof -name '*.db' -size +20M -delete
+echo "== pytest -m gpu"
+timeout 800 python -m pytest tests -m gpu -q </dev/null 2>&1 | tail -6 | tee $OUT/pytest.txt
+echo "== kernel alone"
+{ timeout 100 python tools/kbench.py --nodevs --reps 7 --streams 8192 </dev/null 2>&1 | tail -1
+  timeout 100 python tools/kbench.py --nodevs --reps 7 --streams 8192 --debug 8388608 </dev/null 2>&1 | tail -1
+  timeout 100 python tools/slice_pf_bench.py </dev/null 2>&1 | tail -1; } | grep -v amdgpu.ids | tee $OUT/kbench.txt
+ls $OUT

@@ -12,7 +12,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "gpurun_out", os.environ.get("R433_PMC_TAG", "r04_pmc"))
+OUT = os.path.join(ROOT, "gpurun_out", os.environ.get("R433_PMC_TAG", "r05_pmc"))
 
 WORKLOADS = {
     # key: (command, kernel name pattern, algorithmic bytes per launch, what a launch is)
@@ -32,7 +32,7 @@ def one_pass(tag, counter, cmd):
     os.makedirs(d, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "r", "--"] + cmd, cwd="/tmp", env=env,
-                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, timeout=1200)
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, timeout=400)
     dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
     if not dbs:
         return None
@@ -63,7 +63,10 @@ def main():
             continue
         n_disp = len(got["FETCH_SIZE"])
         if key in ("config2", "config4"):
-            per = sum(1 for n, _, _ in got["FETCH_SIZE"] if "k_wave" in n)  # every k_wave dispatch is one launch of the workload
+            # every detection pass is one launch of the workload: since round 5 a large grid goes out as three k_wave launches
+            # (FORM 4 producers, FORM 5 consumers, FORM 2 run-again) -- the consumers' launches count the passes
+            cons = sum(1 for n, _, _ in got["FETCH_SIZE"] if "k_wave" in n and n.split(">")[0].rstrip().endswith(", 5"))
+            per = cons or sum(1 for n, _, _ in got["FETCH_SIZE"] if "k_wave" in n)
         else:
             per = 3  # bench.py --config 3 / 5 --steps 2 --warmup 1: three passes over the stream
         fetch_kb = sum(v for _, _, v in got["FETCH_SIZE"]) / per
