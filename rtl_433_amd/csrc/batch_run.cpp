@@ -608,7 +608,7 @@ int run_detect(RunCtx &r)
             uint64_t const store = (uint64_t)r.n_streams * tiles_cap * kTileRecBytes;
             if (tiles_cap && store <= kRolesStoreMax) {
                 size_t const n = r.n_streams;
-                if ((rc = b->d_tile_store.ensure(store)) || (rc = b->d_tile_desc.ensure(n * tiles_cap)) || (rc = b->d_tile_words.ensure(4 * n + 4)))
+                if ((rc = b->d_tile_store.ensure(store)) || (rc = b->d_tile_desc.ensure(n * tiles_cap)) || (rc = b->d_tile_words.ensure(6 * n + 4)))
                     return rc;
                 sp.flags |= RUN_SPLIT_ROLES;
                 sp.tile_store = b->d_tile_store.p;
@@ -619,6 +619,8 @@ int run_detect(RunCtx &r)
                 sp.retry_count = b->d_tile_words.p + 2 * n;
                 sp.retry_list = b->d_tile_words.p + 2 * n + 4;
                 sp.retry_why = b->d_tile_words.p + 3 * n + 4;
+                sp.cons_weight = sp.wg_slot ? b->d_tile_words.p + 4 * n + 4 : nullptr; // (no order asked for: none made)
+                sp.cons_order = b->d_tile_words.p + 5 * n + 4;
             }
         }
         if (r.split) {

@@ -131,6 +131,8 @@ struct StreamParams {
     uint32_t *tile_info;          // n_streams
     uint32_t *retry_count;        // device scalar, zeroed by launch_stream
     uint32_t *retry_list;         // n_streams
+    uint32_t *cons_weight;        // n_streams: the consumers' launch takes its captures by the work the producers left them (launch_stream)
+    uint32_t *cons_order;         // n_streams
     uint32_t *retry_why;          // n_streams
     uint32_t const *wg_count;     // (the run-again launch) workgroups at and beyond *wg_count leave at once
 };

@@ -2724,6 +2724,54 @@ __global__ __launch_bounds__(64) void k_gather_packages(uint8_t const *arena, ui
     }
 }
 
+// The consumers' launch (FORM 5) takes its captures heaviest first BY THEIR OWN WORK: what the producers left -- per capture the
+// chunks of its filtered tiles whose envelope rises above the level below which the detector only idles or counts (quiet_bound:
+// everything else the consumer skips by the chunk maxima).  The producers' order (a look at 16 samples of the raw capture,
+// k_capture_weight) says little about that, and a launch of 2.7 rounds of consumers lasts as long as its last round's slowest
+// capture.  Order only: every capture is still one workgroup.
+__global__ __launch_bounds__(64) void k_consumer_weight(StreamParams p, uint32_t sample_size, uint32_t *weight)
+{
+    uint32_t const s = blockIdx.x;
+    int const lane = (int)threadIdx.x;
+    uint32_t const my_n = (p.stream_bytes ? p.stream_bytes[s] : p.uniform_bytes) / sample_size;
+    uint32_t const n_tiles = min((my_n + (uint32_t)kTile - 1u) / (uint32_t)kTile, p.tiles_cap);
+    int thr = (int)(int16_t)((-1 + min(p.det.min_high, p.det.max_high)) / 2);
+    if (p.det.fixed_high != 0)
+        thr = (int)(int16_t)p.det.fixed_high;
+    int const level = thr > 0 ? thr - (int)(int16_t)(thr / 8) - 1 : -1;
+    int active = 0;
+    for (uint32_t t = 0; t < n_tiles; ++t) {
+        if (p.tile_desc[(uint64_t)s * p.tiles_cap + t] < 0)
+            continue; // (kQuietTile: no samples, a few dozen scalar instructions)
+        short const *const ext = (short const *)(p.tile_store + ((uint64_t)s * p.tiles_cap + t) * kTileRecBytes);
+        active += (int)ext[kTileRecMax / 2 + lane] > level ? 1 : 0;
+    }
+    active = wave_sum(active);
+    if (lane == 0)
+        weight[s] = min((uint32_t)active >> 3, 254u) + (n_tiles ? 1u : 0u);
+}
+
+// captures by falling weight (a counting sort over 256 weights, one workgroup)
+__global__ __launch_bounds__(256) void k_order_falling(uint32_t const *weight, uint32_t n, uint32_t *order)
+{
+    __shared__ uint32_t count[256], first[256];
+    count[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 256)
+        atomicAdd(&count[weight[i] & 255u], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int w = 255; w >= 0; --w) {
+            first[w] = run;
+            run += count[w];
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 256)
+        order[atomicAdd(&first[weight[i] & 255u], 1u)] = i;
+}
+
 } // namespace
 
 bool launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st)
@@ -2776,10 +2824,17 @@ bool launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st)
         else
             R433_LAUNCH_WAVE(4, 4, p);
         lds = 2u * 64u * (uint32_t)kPitchOut; // the consumers: one tile
+        StreamParams c = p;
+        if (p.cons_weight && p.cons_order) { // ... heaviest first by what the producers left them
+            hipLaunchKernelGGL(k_consumer_weight, dim3(p.n_streams), dim3(64), 0, st, p, sample_size, p.cons_weight);
+            hipLaunchKernelGGL(k_order_falling, dim3(1), dim3(256), 0, st, p.cons_weight, p.n_streams, p.cons_order);
+            c.wg_slot = p.cons_order;
+            c.n_wgs = p.n_streams;
+        }
         if (sample_size == 2)
-            R433_LAUNCH_WAVE(2, 5, p);
+            R433_LAUNCH_WAVE(2, 5, c);
         else
-            R433_LAUNCH_WAVE(4, 5, p);
+            R433_LAUNCH_WAVE(4, 5, c);
         // what a consumer could not carry across its unfiltered tiles runs again as a pair, every tile filtered (the frame
         // sums were added by the first launch); a grid of the chip's size, strided over the list by further launches only if
         // it ever were longer (it never is: one capture in tens of thousands)

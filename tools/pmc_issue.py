@@ -28,7 +28,8 @@ def one(tag, counters, debug):
     d = os.path.join(OUT, f"issue_{tag}")
     os.makedirs(d, exist_ok=True)
     cmd = [sys.executable, os.path.join(ROOT, "tools", "kbench.py"), "--nodevs", "--streams", str(N_CAP), "--reps", "2"] + (["--debug", str(debug)] if debug else [])
-    subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + counters + ["-d", d, "-o", "r", "--"] + cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
+    if not os.environ.get("R433_PMC_OFFLINE"):  # (offline: only read the databases of an earlier visit again)
+      subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + counters + ["-d", d, "-o", "r", "--"] + cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, timeout=400)
     dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
     if not dbs:
@@ -50,7 +51,7 @@ def one(tag, counters, debug):
         kd = [n for n in t if "kernel_dispatch" in n]
         sym = [n for n in t if "kernel_symbol" in n]
         if kd and sym:
-            for name, dur in c.execute(f"select s.kernel_name, avg(d.end - d.start) from {kd[0]} d join {sym[0]} s on d.kernel_id = s.id where s.kernel_name like '%k_wave%' group by s.kernel_name").fetchall():
+            for name, dur in c.execute(f"select s.display_name, avg(d.end - d.start) from {kd[0]} d join {sym[0]} s on d.kernel_id = s.id where s.display_name like '%k_wave%' group by s.display_name").fetchall():
                 out.setdefault(form_of(name), {})["_duration_ns"] = dur
     except Exception as e:
         out["_duration_error"] = str(e)
