@@ -559,7 +559,8 @@ int run_stitch(RunCtx &r, StreamParams const &sp)
 // envelope, filters, pulse detection: packages per slot in the arena (grown and repeated if it overflows)
 constexpr uint32_t kOrderFrom = 2048; // captures in a grid from which on their order is worth a look (1536 pairs fit the chip at once)
 // Captures in a grid from which on the two roles of a capture run as two launches (stream_kernels.hip FORM 4 / FORM 5; measured:
-// 4096 captures 2.02 ms as pairs / 2.39 ms as two launches, 8192 captures 3.71 / 3.44, profiles/r05_b_split_roles.txt): below,
+// 4096 captures 2.02 ms as pairs / 2.39 ms as two launches, 8192 captures 3.66 / 3.41 -- 3.05 with the consumers in their own
+// order --, profiles/r05_kbench.txt, r05_h_kbench_consumer_order.txt): below,
 // a launch lasts as long as its slowest capture and the pair's overlap of filters and detector is what shortens that; above,
 // the grid is several rounds deep and what counts is how many CONSUMERS the chip holds at once (three to a SIMD instead of
 // one and a half).  The tile records are 8.4 KB per tile of 2048 samples: at most kRolesStoreMax bytes of HBM per engine.

@@ -1,8 +1,6 @@
 export TMPDIR=/tmp
-TAG=${1:-r05_g}; OUT=gpurun_out/$TAG; mkdir -p $OUT
-J='import json,sys
-d=json.load(open(sys.argv[1])); print({k: d.get(k) for k in ("value","ms_per_step","breakdown_ms")}, d.get("pcie_inclusive",{}).get("value"), d["config"].get("gpu_waits"), d["config"].get("host_dispatch_threads"))'
-echo "== default"; timeout 200 python bench.py --quick --steps 30 --warmup 3 > $OUT/b0.json 2>/dev/null </dev/null; timeout 20 python -c "$J" $OUT/b0.json </dev/null
-echo "== nap wait"; R433_DEBUG_NAP_WAIT=1 timeout 200 python bench.py --quick --steps 30 --warmup 3 > $OUT/b_nap.json 2>/dev/null </dev/null; timeout 20 python -c "$J" $OUT/b_nap.json </dev/null
-for t in 16 20 32; do echo "== threads $t"; timeout 200 python bench.py --quick --steps 30 --warmup 3 --threads $t > $OUT/b_t$t.json 2>/dev/null </dev/null; timeout 20 python -c "$J" $OUT/b_t$t.json </dev/null; done
-echo "== nap wait, threads 20"; R433_DEBUG_NAP_WAIT=1 timeout 200 python bench.py --quick --steps 30 --warmup 3 --threads 20 > $OUT/b_nap20.json 2>/dev/null </dev/null; timeout 20 python -c "$J" $OUT/b_nap20.json </dev/null
+TAG=${1:-r05_i}; OUT=gpurun_out/$TAG; mkdir -p $OUT
+echo "== the bench's own batch (every third capture a protocol transmission): default / capture order / pairs"
+{ timeout 150 python tools/slice_pf_bench.py "" 8 0 </dev/null 2>&1 | tail -1
+  timeout 150 python tools/slice_pf_bench.py "" 8 64 </dev/null 2>&1 | tail -1
+  timeout 150 python tools/slice_pf_bench.py "" 8 8388608 </dev/null 2>&1 | tail -1; } | grep -v amdgpu.ids | tee $OUT/spb.txt

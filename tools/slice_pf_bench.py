@@ -7,7 +7,7 @@ import numpy as np, torch
 import bench
 from rtl_433_amd import _lib, plugins
 from rtl_433_amd.engine import BatchEngine, flow_cfg, load_device_table
-so = sys.argv[1] if len(sys.argv) > 1 else None
+so = (sys.argv[1] or None) if len(sys.argv) > 1 else None
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 debug = int(sys.argv[3], 0) if len(sys.argv) > 3 else 0
 cache = "/tmp/r433_spb_input.npy"
