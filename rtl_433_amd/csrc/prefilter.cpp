@@ -758,8 +758,37 @@ int r433_batch_probe_prefilter(r433_batch *b, r433_r_device *const *devices, uin
                 verdicts = answers[k];
         }
     }
-    if (getenv("R433_PROBE_TRACE"))
+    if (char const *trace = getenv("R433_PROBE_TRACE")) {
         fprintf(stderr, "r.probe: %zu decoders asked, %lu questions in runs, %lu faults\n", ask_list.size(), g_asks.load(), g_faults.load());
+        if (atoi(trace) >= 2) // development: what was learned per decoder beyond the head tables
+            for (uint32_t d = 0; d < n_devices; ++d) {
+                auto const known = eligible[d] ? g_known.find(keys[d]) : g_known.end();
+                if (known == g_known.end() || known->second.empty())
+                    continue;
+                uint8_t const *t = known->second.data();
+                unsigned heads = 0, one_row = 0, two = 0, shorts = 0;
+                for (unsigned i = 0; i < kPfHeadRows * kPfBits; ++i) {
+                    bool const v = t[i] != kPfKeep && !(i < kPfBits && i > 0);
+                    heads += v;
+                    one_row += v && i / kPfBits == 1;
+                    shorts += v && (t[i] & kPfShort);
+                }
+                for (unsigned i = 0; i < kPfTwo0 * kPfTwo1; ++i)
+                    two += t[kPfTwoAt + i] != kPfKeep;
+                uint64_t lens;
+                uint32_t pat;
+                uint16_t st, bound;
+                memcpy(&lens, t + kPfRule + 8, 8);
+                memcpy(&pat, t + kPfRule + 4, 4);
+                memcpy(&st, t + kPfRule + 2, 2);
+                memcpy(&bound, t + kPfShortAt, 2);
+                fprintf(stderr, "r.probe: [%3u] %-40.40s heads %5u (one row %4u, short rows %4u below %u bits) two rows %4u", d, devices[d]->name ? devices[d]->name : "?",
+                        heads, one_row, shorts, shorts ? bound : 0u, two);
+                if (t[kPfRule] != kPfKeep)
+                    fprintf(stderr, "  search rule: code %u, %u bits %08x from %u, lengths %016llx", t[kPfRule], t[kPfRule + 1], pat, st, (unsigned long long)lens);
+                fprintf(stderr, "\n");
+            }
+    }
     int filtered = 0;
     for (uint32_t d = 0; d < n_devices; ++d) {
         if (!eligible[d])
