@@ -57,6 +57,7 @@ constexpr int kFloorWindow = 1024;          // samples a later segment of a spli
 constexpr int kVirtual = 4 * kChunk;        // samples at the start of a filtered tile that follows unfiltered ones: bounds only
 constexpr int kHead = 512;                  // ... and how far into the next tile a tile looks before it goes unfiltered (one row)
 constexpr int kQuietTile = (int)0x80000000, kPostQuiet = 0x40000000;
+constexpr bool kLazySplit = true;           // lazy tiles inside the pieces of a split capture (3.1b / 3.1c)
 constexpr int kPitchOut = kChunk * 2;       // filtered samples: time-linear, read by sample index (the padded pitch buys
                                              // nothing there and 8 wavefronts' LDS must fit one CU: 8 x 20 KB = 160 KB)
 // FORM 4 -> FORM 5 (the two roles as two kernels): what a tile hands from the filters to the detector, per (capture, tile)
@@ -436,7 +437,11 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
     // capture runs again with every tile filtered: nothing is ever published from an assumption.
     // Off for split captures (their pieces are verified against each other by the host), the function seam, taps, the logic
     // dump, sample files that are not IQ, filters outside the FAST class, frames that are not whole tiles.
-    bool const lazy_cfg = !SEAM && FAST && FORM != 3 && !p.segs && !p.tap_env && !p.tap_am && !p.logic && F % (uint32_t)kTile == 0
+    // (Pieces of a split capture, round 5: the same inside a piece.  Its establishing tile and -- unless the piece ends the
+    // capture -- its last tile are always filtered: the first proves the carries and the floor the piece starts from, the last
+    // lets the floor be settled over real samples before the host's stitch compares it with what the next piece assumed.  A piece
+    // that cannot be carried starts over with every tile filtered like a whole capture does; kLazySplit = false: as in round 4.)
+    bool const lazy_cfg = !SEAM && FAST && (kLazySplit || (FORM != 3 && !p.segs)) && !p.tap_env && !p.tap_am && !p.logic && F % (uint32_t)kTile == 0
             && !(p.flags & (RUN_NO_LAZY | RUN_DBG_SKIP_FILTERS | RUN_AM_IS_INPUT | RUN_FM_IS_INPUT | RUN_ENV_RAW16));
     bool lazy = lazy_cfg;        // this attempt
     int attempts = 0, n_quiet = 0;
@@ -681,7 +686,8 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
                 int const *const mh = p.frame_min_high + (uint64_t)cap * p.frames_cap;
                 E = min(min(quiet_bound(mh[min(t0 ? (t0 - 1u) / F : 0u, fl)]), quiet_bound(mh[min(t0 / F, fl)])), quiet_bound(mh[min((t0 + (uint32_t)kTile) / F, fl)]));
             }
-            bool const quiet = uni((int)(n_t == kTile && tail_max <= E && !__ballot(lmax > E || hmax > E))) != 0;
+            bool const must_filter = warm || (p.segs && !(seg_flags & SEG_LAST) && tile + 1u >= tile_end); // (a piece's first and last tile)
+            bool const quiet = uni((int)(n_t == kTile && !must_filter && tail_max <= E && !__ballot(lmax > E || hmax > E))) != 0;
             if (post_q) // (the head rule of the tile before this one: these samples are below its level)
                 vbound = max(prev_bound, wave_max(lane < kVirtual / 8 ? row0 : 0));
             if (!quiet) {

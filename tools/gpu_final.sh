@@ -3,12 +3,14 @@
 #   tools/gpu_final.sh <tag>        (round 5: ~15 GPU minutes)
 TAG=${1:-r05}; OUT=gpurun_out/${TAG}_final; mkdir -p $OUT profiles
 export TMPDIR=/tmp
+if [ -z "$SKIP_PMC" ]; then
 echo "== SQ counters of the detection pass (producers / consumers apart)"
 R433_PMC_TAG=${TAG}_pmc timeout 500 python tools/pmc_issue.py </dev/null 2>&1 | tail -60 > $OUT/pmc_issue.txt; tail -12 $OUT/pmc_issue.txt
 [ -s gpurun_out/${TAG}_pmc/issue.json ] && cp gpurun_out/${TAG}_pmc/issue.json profiles/${TAG}_pmc_issue.json
 echo "== HBM traffic of the detection pass (FETCH_SIZE / WRITE_SIZE passes)"
 R433_PMC_TAG=${TAG}_pmc timeout 400 python tools/pmc_traffic.py config4 </dev/null 2>&1 | tail -3 | cut -c1-600
 [ -s gpurun_out/${TAG}_pmc/traffic.json ] && cp gpurun_out/${TAG}_pmc/traffic.json profiles/${TAG}_pmc_traffic.json
+fi
 echo "== bench (the driver's form)"
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err </dev/null; tail -2 $OUT/bench.err
 timeout 20 python -c "
