@@ -2746,11 +2746,18 @@ __global__ __launch_bounds__(64) void k_consumer_weight(StreamParams p, uint32_t
         thr = (int)(int16_t)p.det.fixed_high;
     int const level = thr > 0 ? thr - (int)(int16_t)(thr / 8) - 1 : -1;
     int active = 0;
-    for (uint32_t t = 0; t < n_tiles; ++t) {
+    for (uint32_t t = (uint32_t)lane; t < n_tiles; t += 64u) { // a lane per tile (one dependent load chain per 64 tiles, not per tile)
         if (p.tile_desc[(uint64_t)s * p.tiles_cap + t] < 0)
             continue; // (kQuietTile: no samples, a few dozen scalar instructions)
-        short const *const ext = (short const *)(p.tile_store + ((uint64_t)s * p.tiles_cap + t) * kTileRecBytes);
-        active += (int)ext[kTileRecMax / 2 + lane] > level ? 1 : 0;
+        uint4 const *const ext = (uint4 const *)(p.tile_store + ((uint64_t)s * p.tiles_cap + t) * kTileRecBytes + kTileRecMax);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { // the 64 chunk maxima of the tile, 8 shorts a load
+            uint4 const v = ext[k];
+            uint32_t const w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                active += ((int)(int16_t)(w[j] & 0xffffu) > level ? 1 : 0) + ((int)(int16_t)(w[j] >> 16) > level ? 1 : 0);
+        }
     }
     active = wave_sum(active);
     if (lane == 0)
