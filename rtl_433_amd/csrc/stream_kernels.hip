@@ -408,6 +408,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
     uint8_t *const g_tiles = (to_hbm || from_hbm) ? p.tile_store + (uint64_t)s * p.tiles_cap * kTileRecBytes : nullptr;
     int *const g_desc = (to_hbm || from_hbm) ? p.tile_desc + (uint64_t)s * p.tiles_cap : nullptr;
     int self_retry = 0; // FORM 4: the producer found that the capture cannot be carried across its unfiltered tiles
+    int p_active = 0;   // FORM 4: per lane (= chunk) the filtered tiles whose envelope rose above the quiet level there: the consumer's work
 
     // ---- detector: wave-uniform.  Every lane carries the same scalar state and takes the same
     // branches, in the fast paths and in the general step alike; lane 0 alone touches the arena and
@@ -1242,6 +1243,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
         }
         if (to_hbm) {
             short *const ext = (short *)(g_tiles + (uint64_t)tile * kTileRecBytes);
+            p_active += cmax > quiet_bound(p.det.min_high) ? 1 : 0;
             ext[kTileRecMax / 2 + lane] = (short)max(cmax, -32768);
             ext[kTileRecMin / 2 + lane] = (short)min(cmin, 32767);
             if (p_over && lane == 0)
@@ -2482,6 +2484,7 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
         for (;;) {
             init_producer();
             self_retry = 0;
+            p_active = 0;
             if (lane == 0)
                 p.tile_over[s] = 0;
             issue_loads(tile_first);
@@ -2495,8 +2498,13 @@ template <int SS, bool FAST, bool FM, bool SEAM = false, int FORM = 1> __global_
             lazy = false;
             attempts += 1;
         }
-        if (lane == 0)
+        // what the consumers' launch sorts its captures by (k_order_falling): the chunks the detector cannot skip
+        p_active = wave_sum(p_active);
+        if (lane == 0) {
             p.tile_info[s] = (uint32_t)attempts | ((uint32_t)retry_why << 8);
+            if (p.cons_weight)
+                p.cons_weight[s] = min((uint32_t)p_active >> 3, 254u) + (tile_end > tile_first ? 1u : 0u);
+        }
         return;
     }
     else if constexpr (from_hbm) {
@@ -2732,38 +2740,10 @@ __global__ __launch_bounds__(64) void k_gather_packages(uint8_t const *arena, ui
 
 // The consumers' launch (FORM 5) takes its captures heaviest first BY THEIR OWN WORK: what the producers left -- per capture the
 // chunks of its filtered tiles whose envelope rises above the level below which the detector only idles or counts (quiet_bound:
-// everything else the consumer skips by the chunk maxima).  The producers' order (a look at 16 samples of the raw capture,
-// k_capture_weight) says little about that, and a launch of 2.7 rounds of consumers lasts as long as its last round's slowest
-// capture.  Order only: every capture is still one workgroup.
-__global__ __launch_bounds__(64) void k_consumer_weight(StreamParams p, uint32_t sample_size, uint32_t *weight)
-{
-    uint32_t const s = blockIdx.x;
-    int const lane = (int)threadIdx.x;
-    uint32_t const my_n = (p.stream_bytes ? p.stream_bytes[s] : p.uniform_bytes) / sample_size;
-    uint32_t const n_tiles = min((my_n + (uint32_t)kTile - 1u) / (uint32_t)kTile, p.tiles_cap);
-    int thr = (int)(int16_t)((-1 + min(p.det.min_high, p.det.max_high)) / 2);
-    if (p.det.fixed_high != 0)
-        thr = (int)(int16_t)p.det.fixed_high;
-    int const level = thr > 0 ? thr - (int)(int16_t)(thr / 8) - 1 : -1;
-    int active = 0;
-    for (uint32_t t = (uint32_t)lane; t < n_tiles; t += 64u) { // a lane per tile (one dependent load chain per 64 tiles, not per tile)
-        if (p.tile_desc[(uint64_t)s * p.tiles_cap + t] < 0)
-            continue; // (kQuietTile: no samples, a few dozen scalar instructions)
-        uint4 const *const ext = (uint4 const *)(p.tile_store + ((uint64_t)s * p.tiles_cap + t) * kTileRecBytes + kTileRecMax);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { // the 64 chunk maxima of the tile, 8 shorts a load
-            uint4 const v = ext[k];
-            uint32_t const w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                active += ((int)(int16_t)(w[j] & 0xffffu) > level ? 1 : 0) + ((int)(int16_t)(w[j] >> 16) > level ? 1 : 0);
-        }
-    }
-    active = wave_sum(active);
-    if (lane == 0)
-        weight[s] = min((uint32_t)active >> 3, 254u) + (n_tiles ? 1u : 0u);
-}
-
+// everything else the consumer skips by the chunk maxima); every producer leaves that count as it goes (StreamParams::
+// cons_weight).  The producers' own order (a look at 16 samples of the raw capture, k_capture_weight) says little about it, and a
+// launch of 2.7 rounds of consumers lasts as long as its last round's slowest capture.  Order only: every capture is still one
+// workgroup.
 // captures by falling weight (a counting sort over 256 weights, one workgroup)
 __global__ __launch_bounds__(256) void k_order_falling(uint32_t const *weight, uint32_t n, uint32_t *order)
 {
@@ -2839,7 +2819,6 @@ bool launch_stream(StreamParams const &p, uint32_t sample_size, hipStream_t st)
         lds = 2u * 64u * (uint32_t)kPitchOut; // the consumers: one tile
         StreamParams c = p;
         if (p.cons_weight && p.cons_order) { // ... heaviest first by what the producers left them
-            hipLaunchKernelGGL(k_consumer_weight, dim3(p.n_streams), dim3(64), 0, st, p, sample_size, p.cons_weight);
             hipLaunchKernelGGL(k_order_falling, dim3(1), dim3(256), 0, st, p.cons_weight, p.n_streams, p.cons_order);
             c.wg_slot = p.cons_order;
             c.n_wgs = p.n_streams;

@@ -1,5 +1,5 @@
 """The detection pass as two launches (producers, consumers: stream_kernels.hip FORM 4 / FORM 5) with the consumers' launch taking
-its captures heaviest first by the work the producers left (k_consumer_weight / k_order_falling): the order of the workgroups
+its captures heaviest first by the work the producers left (StreamParams::cons_weight, counted by the producers, / k_order_falling): the order of the workgroups
 is all that changes -- package records are those of the one-launch form, byte for byte (reference src/pulse_detect.c:199-483
 is per capture; src/rtl_433.c:1845-1854 resets the flow between files)."""
 import zlib
