@@ -113,7 +113,11 @@ typedef struct hip_engine {
     int probed, tables; /* the decoder pre-filter of this engine: asked for, decoders with a table */
     int lane;           /* which of the two passes in flight it serves (a pass on the GPU while the one before is replayed) */
     unsigned long used; /* for the least recently used */
+    int busy;           /* passes (in flight or owed a replay) that hold this engine: never the one to make room */
 } hip_engine;
+
+/* H.engines is looked at by the file loop's thread and by the thread of a pass in flight */
+static pthread_mutex_t g_eng_mu = PTHREAD_MUTEX_INITIALIZER;
 
 static struct {
     r433_batch *eng; /* the engine of the pass at hand (one of engines[]) */
@@ -168,6 +172,7 @@ typedef struct pending_pass {
     int active;
     pthread_t thread;
     r433_batch *eng;
+    hip_engine *mine; /* made by pass_start already (the pre-filter's questions were due): held */
     r_cfg_t *cfg;
     r433_flow_cfg fc;
     int lane;
@@ -762,22 +767,53 @@ static void engine_config(r_cfg_t *cfg, hip_capture const *c, r433_flow_cfg *fc)
 
 /* the engine of a flow configuration and a lane: found or made.  Touches H.engines only (the thread of a pass in flight calls it
    for its own lane while the file loop's thread replays the pass before: H.cur / H.eng are the caller's to set) */
+static hip_engine *engine_get_locked(r_cfg_t *cfg, r433_flow_cfg const *fc, int lane, int hold);
+
+/* hold: the caller is a pass that keeps the engine beyond this call (engine_release when its replay is done) */
+static hip_engine *engine_get_held(r_cfg_t *cfg, r433_flow_cfg const *fc, int lane, int hold)
+{
+    warm_join(); /* (the first GPU call of the process is made below) */
+    pthread_mutex_lock(&g_eng_mu);
+    hip_engine *const e = engine_get_locked(cfg, fc, lane, hold);
+    pthread_mutex_unlock(&g_eng_mu);
+    return e;
+}
+
 static hip_engine *engine_get(r_cfg_t *cfg, r433_flow_cfg const *fc, int lane)
 {
+    return engine_get_held(cfg, fc, lane, 0);
+}
+
+static void engine_release(r433_batch const *eng)
+{
+    pthread_mutex_lock(&g_eng_mu);
+    for (int k = 0; k < HIP_ENGINES; ++k)
+        if (H.engines[k].eng == eng && eng && H.engines[k].busy > 0)
+            H.engines[k].busy -= 1;
+    pthread_mutex_unlock(&g_eng_mu);
+}
+
+static hip_engine *engine_get_locked(r_cfg_t *cfg, r433_flow_cfg const *fc, int lane, int hold)
+{
     struct dm_state *demod = cfg->demod;
-    warm_join(); /* (the first GPU call of the process is made below) */
     void *first            = demod->r_devs.len ? demod->r_devs.elems[0] : NULL;
     hip_engine *slot       = NULL;
     for (int k = 0; k < HIP_ENGINES; ++k) {
         hip_engine *e = &H.engines[k];
         if (e->eng && memcmp(fc, &e->cfg, sizeof(*fc)) == 0 && e->devs == demod->r_devs.len && e->first_dev == first && e->lane == lane) {
             e->used = ++H.eng_clock;
+            e->busy += hold;
             return e;
         }
-        /* where a new engine would go: the first empty place, else the one that rested longest */
+        /* where a new engine would go: the first empty place, else the one that rested longest -- never one that a pass in
+           flight, a pass owed its replay or the file loop's own run (H.cur) still works with: at most three of the four */
+        if (e->eng && (e->busy || e == H.cur))
+            continue;
         if (!slot || (slot->eng && (!e->eng || e->used < slot->used)))
             slot = e;
     }
+    if (!slot)
+        hip_fatal("no engine slot free");
     r433_batch_destroy(slot->eng);
     memset(slot, 0, sizeof(*slot));
     /* another set of decoders than the engines so far were made for (decoders registered or freed in between): what the
@@ -840,6 +876,7 @@ static hip_engine *engine_get(r_cfg_t *cfg, r433_flow_cfg const *fc, int lane)
     slot->first_dev = first;
     slot->used      = ++H.eng_clock;
     slot->lane      = lane;
+    slot->busy      = hold;
     return slot;
 }
 
@@ -862,7 +899,18 @@ static int replay_is_chatty(struct dm_state *demod)
     return 0;
 }
 
-static void engine_prefilter_of(r_cfg_t *cfg, hip_engine *cur)
+/* from how many bytes of samples on the decoders are asked (RTL433_HIP_PREFILTER_FROM: tests bring the moment into a short list) */
+static size_t prefilter_from(void)
+{
+    char const *e = getenv("RTL433_HIP_PREFILTER_FROM");
+    return e ? (size_t)strtoull(e, NULL, 0) : (size_t)1 << 33;
+}
+
+/* may_probe = 0: the caller runs beside a replay (the thread of a pass in flight).  The questions call every decoder's
+   decode_fn with the decoder's output_fn / log_fn swapped for swallowers and a process-wide SIGSEGV / SIGBUS handler in place
+   -- the very objects the replay of the pass before is calling at that moment: they are only ever asked by the file loop's
+   thread, between the join of one pass and the start of the next (drain_queue), where no decoder is running. */
+static void engine_prefilter_of(r_cfg_t *cfg, hip_engine *cur, int may_probe)
 {
     struct dm_state *demod = cfg->demod;
     char const *env        = getenv("RTL433_HIP_PREFILTER");
@@ -871,16 +919,20 @@ static void engine_prefilter_of(r_cfg_t *cfg, hip_engine *cur)
        with signals as the bench's, a few ms per GiB of mostly idle captures.  Measured with the CLI on the MI355X box
        (tools/gpu_r4_cli.sh): 8192 captures of 128 KiB (1 GiB) 0.46-0.78 s without the questions, 0.59-0.90 s with them asked
        half-way.  So: from 8 GiB of samples on, or when told to (RTL433_HIP_PREFILTER=1; =0: never). */
-    int const worth        = (env && env[0] == '1') || H.staged_total >= ((size_t)1 << 33);
+    int const worth        = (env && env[0] == '1') || H.staged_total >= prefilter_from();
     int const want         = !(env && env[0] == '0') && worth && !H.sync_active && replay_threads() > 1 && !replay_is_chatty(demod) && demod->r_devs.len;
-    if (want && !cur->probed) {
+    if (want && !cur->probed && may_probe) {
         cur->probed = 1;
+        double const t_ask = trace_now();
         /* this program's decoders reach bitbuffer_invert / _search / _find_repeated_* through dropin/helper_wrap.c (ld --wrap) */
         r433_prefilter_set_helper_probe(r433_host_helper_probe);
         int const t = r433_batch_probe_prefilter(cur->eng, (r433_r_device *const *)demod->r_devs.elems, (uint32_t)demod->r_devs.len);
         if (t < 0)
             hip_fatal("r433_batch_probe_prefilter");
         cur->tables = t;
+        if (trace_on())
+            fprintf(stderr, "hip flow: pre-filter questions asked on the file loop's thread in %.1f ms after %zu bytes of samples, pass in flight: %d, %d decoders with a table\n",
+                    trace_now() - t_ask, H.staged_total, P.active, t);
     }
     if (cur->tables > 0 && r433_batch_set_prefilter(cur->eng, want) < 0)
         hip_fatal("r433_batch_set_prefilter");
@@ -888,7 +940,16 @@ static void engine_prefilter_of(r_cfg_t *cfg, hip_engine *cur)
 
 static void engine_prefilter(r_cfg_t *cfg)
 {
-    engine_prefilter_of(cfg, H.cur);
+    engine_prefilter_of(cfg, H.cur, 1);
+}
+
+/* would engine_prefilter_of ask its questions for an engine that has not been asked for yet? (same test, no side effect) */
+static int prefilter_questions_due(r_cfg_t *cfg)
+{
+    struct dm_state *demod = cfg->demod;
+    char const *env        = getenv("RTL433_HIP_PREFILTER");
+    int const worth        = (env && env[0] == '1') || H.staged_total >= prefilter_from();
+    return !(env && env[0] == '0') && worth && !H.sync_active && replay_threads() > 1 && !replay_is_chatty(demod) && demod->r_devs.len;
 }
 
 /* -E quit / -E hop: src/rtl_433.c:1136-1143 acts on the events of each push, so a push cannot be left for later.  The capture as
@@ -1259,10 +1320,10 @@ static void *pass_thread(void *arg)
     /* Everything of the pass that talks to the GPU happens here, the wait for the device's opening included (the first pass of
        a process): the file loop's thread is back at its files meanwhile, and at the next drain it replays the pass before
        this one through H.eng / H.cur -- which this thread therefore leaves alone: its engine is in `mine` and P.eng. */
-    hip_engine *const mine = engine_get(P.cfg, &P.fc, P.lane);
+    hip_engine *const mine = P.mine ? P.mine : engine_get_held(P.cfg, &P.fc, P.lane, 1);
     r433_batch_enable_logic_dump(mine->eng, 0);
     r433_batch_set_taps(mine->eng, NULL, NULL, NULL, 0);
-    engine_prefilter_of(P.cfg, mine);
+    engine_prefilter_of(P.cfg, mine, 0); /* (switches on what pass_start had asked; asks nothing itself: a replay may be running) */
     P.eng = mine->eng;
     stage_pin(P.stage);
     P.n_pkgs = r433_batch_run_host(P.eng, P.ptrs, P.bytes, (uint32_t)P.n);
@@ -1300,6 +1361,16 @@ static void pass_start(r_cfg_t *cfg, size_t n)
     P.cfg   = cfg;
     P.lane  = H.lane; /* (the engine of this lane: made or found by the pass's own thread) */
     P.eng   = NULL;
+    P.mine  = NULL;
+    /* The decoder pre-filter's questions, when they are due for this lane's engine, are asked HERE: the pass before has been
+       joined, its replay has not begun, no decoder is running anywhere.  (On the pass's thread they ran beside that replay,
+       through the same r_device objects.)  Costs the file loop the engine's making in that one pass. */
+    if (prefilter_questions_due(cfg)) {
+        hip_engine *const e = engine_get_held(cfg, &P.fc, P.lane, 1);
+        if (!e->probed)
+            engine_prefilter_of(cfg, e, 1);
+        P.mine = e;
+    }
     P.ptrs  = malloc(n * sizeof(*P.ptrs));
     P.bytes = malloc(n * sizeof(*P.bytes));
     if (!P.ptrs || !P.bytes)
@@ -1351,6 +1422,7 @@ static int pass_replay(r_cfg_t *cfg, pending_pass *d)
     H.eng                = d->eng;
     int const events     = replay_group(cfg, d->caps, d->n, d->n_pkgs);
     H.eng                = keep_eng;
+    engine_release(d->eng);
     for (size_t i = 0; i < d->n; ++i)
         capture_free(&d->caps[i]);
     free(d->caps);

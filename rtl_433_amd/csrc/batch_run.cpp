@@ -607,10 +607,16 @@ int run_detect(RunCtx &r)
         if (!r.split && !(b->debug_flags & R433_DEBUG_NO_SPLIT_ROLES) && (r.n_streams >= kRolesFrom || (b->debug_flags & R433_DEBUG_SPLIT_ROLES))) {
             uint32_t const tiles_cap = (uint32_t)((r.stride_bytes / r.ss + kTileSamples - 1) / kTileSamples);
             uint64_t const store = (uint64_t)r.n_streams * tiles_cap * kTileRecBytes;
-            if (tiles_cap && store <= kRolesStoreMax) {
-                size_t const n = r.n_streams;
-                if ((rc = b->d_tile_store.ensure(store)) || (rc = b->d_tile_desc.ensure(n * tiles_cap)) || (rc = b->d_tile_words.ensure(6 * n + 4)))
-                    return rc;
+            size_t const n = r.n_streams;
+            // (the two-launch form is an optimisation: where its store -- twice the cu8 input -- does not fit beside the other
+            // engines of the device, the pass goes out as pairs, which need none)
+            bool have_store = tiles_cap && store <= kRolesStoreMax;
+            if (have_store && (b->d_tile_store.ensure(store) || b->d_tile_desc.ensure(n * tiles_cap) || b->d_tile_words.ensure(6 * n + 4))) {
+                (void)hipGetLastError();
+                b->d_tile_store.release();
+                have_store = false;
+            }
+            if (have_store) {
                 sp.flags |= RUN_SPLIT_ROLES;
                 sp.tile_store = b->d_tile_store.p;
                 sp.tile_desc = b->d_tile_desc.p;

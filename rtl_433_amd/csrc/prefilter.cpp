@@ -497,6 +497,9 @@ bool probe_helpers(Fence &fence, r433_r_device *dev, r433_helper_probe *blk, std
     auto verdict = [&](unsigned n) -> uint8_t {
         int const r0 = ask(n, -1);
         reached = r0 == INT_MIN;
+        // bitbuffer_invert before the search (tpms_eezrv.c:82-91): the decoder searches the INVERTED row, the device would search
+        // the row as the slicer left it -- no search rule then; the head-alone verdicts below hold whatever the row contains
+        bool const inverted = blk->inverts != 0;
         uint8_t const v0 = verdict_of(r0);
         if (v0 == kPfKeep || blk->overflow)
             return (uint8_t)kPfKeep;
@@ -511,7 +514,7 @@ bool probe_helpers(Fence &fence, r433_r_device *dev, r433_helper_probe *blk, std
                     if (blk->overflow || !blk->searches || blk->start != start || blk->pattern_bits != plen)
                         return (uint8_t)kPfKeep;
                     if (r != r0) {
-                        if (n < kPfRuleMaxBits && plen <= 32 && start < 65536u)
+                        if (!inverted && !blk->inverts && n < kPfRuleMaxBits && plen <= 32 && start < 65536u)
                             cands.push_back({n, Cand{start, plen, plen == 32 ? pat : pat & ~(0xffffffffu >> plen), v0}});
                         return (uint8_t)kPfKeep;
                     }

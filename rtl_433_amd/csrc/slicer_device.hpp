@@ -265,7 +265,7 @@ template <bool WRITE> struct BitSink {
                 put32(off, (uint32_t)sizeof(r433_evt_rec));
                 put32(off + 4, pkg);
                 put32(off + 8, dev_ord);
-                put32(off + 12, kPfStubRows | (min(verdict, 4u) << 16));
+                put32(off + 12, kPfStubRows | ((verdict <= 4u ? verdict : 0u) << 16)); // (the same mapping as the drop below: codes are 0..4)
                 off += (uint32_t)sizeof(r433_evt_rec);
                 dev_ord += 0x10000u;
                 clear();

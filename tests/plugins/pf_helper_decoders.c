@@ -172,3 +172,24 @@ int pfh_dec_repeated_then_lengths(struct r_device *d, bitbuffer_t *b)
     }
     return payload_verdict(b, row);
 }
+
+/* 10. like tpms_eezrv.c:82-91: the row is inverted IN PLACE first, then searched; "not found" and "found, too short" are
+ * different codes.  The search the decoder runs is over the inverted row: a search rule formed from its pattern and run
+ * over the row as the slicer left it would look for the wrong bits -- no rule may be formed here (only the head-alone
+ * verdicts, which hold whatever the row contains). */
+static uint8_t const kEdgePreamble[1] = {0x0c}; /* 000011: not in the test's short rows as sliced (they hold 111100), in most of them once inverted */
+int pfh_dec_invert_then_search(struct r_device *d, bitbuffer_t *b)
+{
+    (void)d;
+    pfh_calls[10]++;
+    if (b->num_rows != 1)
+        return -2;
+    bitbuffer_invert(b);
+    int const len = b->bits_per_row[0];
+    int const at = (int)bitbuffer_search(b, 0, 1, kEdgePreamble, 6);
+    if (at >= len)
+        return -2;
+    if (len - at < 20)
+        return -1;
+    return payload_verdict(b, 0);
+}

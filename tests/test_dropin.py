@@ -55,12 +55,12 @@ def _ensure_built(binary):
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "dropin"), "emu" if binary == EMU else "hip"], stdout=subprocess.DEVNULL)
 
 
-def run_cli(binary, args, cwd, env=None):
+def run_cli(binary, args, cwd, env=None, with_stderr=False):
     e = dict(os.environ)
     e.update(env or {})
     p = subprocess.run([binary] + args, cwd=cwd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
-    return p.stdout.decode()
+    return (p.stdout.decode(), p.stderr.decode(errors="replace")) if with_stderr else p.stdout.decode()
 
 
 def write_ook_files(d, seeds):
@@ -117,6 +117,17 @@ def check_two_passes_in_flight(binary, tmp_path):
     args = file_args(names) + FLEX + ["-F", "json", "-M", "level", "-M", "protocol", "-M", "bits", "-K", "FILE"]
     assert run_cli(binary, args, tmp_path, {"RTL433_HIP_BATCH": "3", "RTL433_HIP_OVERLAP": "0"}) == ref
     assert run_cli(binary, args, tmp_path, {"RTL433_HIP_BATCH": "5", "RTL433_HIP_OVERLAP": "1", "RTL433_HIP_THREADS": "1"}) == ref
+    # The decoder pre-filter's questions come due in the THIRD pass (after 0.8 MB of samples), while the second pass is owed its
+    # replay: they are asked on the file loop's thread between the join and the next pass's start -- on the pass's own thread
+    # they called every decode_fn (output_fn / log_fn swapped for swallowers) beside the replay that runs the same decoders.
+    # (-M stats: the per-decoder statistics the filter must keep are in the comparison)
+    args_stats = args + ["-M", "stats:2:0"]
+    ref_stats = run_cli(REF, args_stats, tmp_path)
+    late = {"RTL433_HIP_BATCH": "3", "RTL433_HIP_OVERLAP": "1", "RTL433_HIP_PREFILTER_FROM": "800000", "RTL433_HIP_THREADS": "4", "RTL433_HIP_TRACE": "1"}
+    got = run_cli(binary, args_stats, tmp_path, late, with_stderr=True)
+    assert got[0] == ref_stats
+    asked = [ln for ln in got[1].splitlines() if "pre-filter questions" in ln]
+    assert len(asked) >= 1 and all("file loop's thread" in ln for ln in asked), got[1][-3000:]
 
 
 def check_config3(binary, tmp_path):

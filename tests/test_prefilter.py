@@ -178,7 +178,7 @@ def test_prefilter_real_decoders(backend):
 
 HFNS = ["pfh_dec_search_then_length", "pfh_dec_search_two_codes", "pfh_dec_invert_then_length", "pfh_dec_invert_then_payload",
         "pfh_dec_foreign_search", "pfh_dec_two_searches", "pfh_dec_repeated_row", "pfh_dec_repeated_once", "pfh_dec_search_position",
-        "pfh_dec_repeated_then_lengths"]
+        "pfh_dec_repeated_then_lengths", "pfh_dec_invert_then_search"]
 WRAP = "-Wl,--wrap=bitbuffer_invert,--wrap=bitbuffer_search,--wrap=bitbuffer_find_repeated_row,--wrap=bitbuffer_find_repeated_prefix"
 
 
@@ -209,6 +209,7 @@ def _helper_devices():
     devs[7] = (5, 250.0, 500.0, 4000.0, 0.0, 0.0, 100.0, 0)      # OOK_PPM
     devs[8] = (4, 100.0, 100.0, 900.0, 0.0, 0.0, 0.0, 0)         # OOK_PCM, short reset
     devs[9] = (6, 250.0, 500.0, 1200.0, 800.0, 0.0, 120.0, 0)    # OOK_PWM, as 6
+    devs[10] = (4, 100.0, 100.0, 900.0, 0.0, 0.0, 0.0, 0)        # OOK_PCM, short reset, as 1: the same rows, inverted before the search
     return devs
 
 
@@ -262,6 +263,10 @@ def test_prefilter_helper_probe_plugins(backend, helper_plugins):
     assert int(b["dropped"][4].sum()) == int(f["dropped"][4].sum()) and int(b["dropped"][5].sum()) == int(f["dropped"][5].sum())
     # 1: only rows too short for the preamble go ("not found" and "found, too short" are different codes): all under ABORT_EARLY
     assert int(b["dropped"][1][1]) == 0 and int(b["dropped"][1][2]) > 0
+    # 10: the same decoder behind a bitbuffer_invert.  Its search runs over the inverted row, so the device must not run it over
+    # the row as sliced (no search rule): what goes is what the length alone decides, never more than decoder 1 loses -- and the
+    # statistics above are equal, which they are not when the raw row is searched for the decoder's pattern
+    assert 0 < int(b["dropped"][10].sum()) <= int(b["dropped"][1].sum())
     assert b["nev"] < f["nev"] < a["nev"]
 
 

@@ -20,6 +20,7 @@ ap.add_argument("--lib", default=None, help="a development variant of the librar
 ap.add_argument("--sigma-only", action="store_true", help="only the captures with noise (sigma > 0): no closed-form silence")
 ap.add_argument("--fsk-cu8", action="store_true", help="250 kS/s cu8 FSK bursts at 433.92 MHz: the classic FSK detector")
 ap.add_argument("--analyze", action="store_true", help="also time the pulse analyzer (-A) over the packages of the run")
+ap.add_argument("--bench-batch", action="store_true", help="the captures of bench.py's configs[1] batch (every third one a protocol transmission): 1024 distinct, tiled")
 ap.add_argument("--cs16", action="store_true", help="config 3 style: 1024 kS/s cs16 FSK Manchester bursts, minmax detector")
 a = ap.parse_args()
 if a.cs16:
@@ -30,6 +31,11 @@ elif a.fsk_cu8:
     host = np.stack([synth.fsk_stream_cu8(s, a.samples, n_bursts=4, nbits=512, gap=3000) for s in range(min(a.streams, 64))])
     host = np.tile(host, ((a.streams + len(host) - 1) // len(host), 1))[: a.streams]
     cfg = flow_cfg(2, 250000, fpdm=0)
+elif a.bench_batch:
+    import bench
+    host = bench.ook_batches(a.seed0, min(a.streams, 1024), procs=8)
+    host = np.tile(host, ((a.streams + len(host) - 1) // len(host), 1))[: a.streams]
+    cfg = flow_cfg(2, 250000)
 else:
     if a.sigma_only:  # the bench recipe draws sigma from {0, 1, 2}: keep the two thirds a real receiver could produce
         rows, seed = [], 0
