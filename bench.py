@@ -57,11 +57,11 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 def _newest(name):  # the committed counter passes of the latest round that has them
-    for rnd in ("r05", "r04"):
+    for rnd in ("r06", "r05", "r04"):
         p = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
         if os.path.exists(p):
             return p
-    return os.path.join(ROOT, "profiles", f"r05_{name}")
+    return os.path.join(ROOT, "profiles", f"r06_{name}")
 
 
 PMC_TRAFFIC = _newest("pmc_traffic.json")  # separate rocprofv3 --pmc passes (tools/pmc_traffic.py)
@@ -77,6 +77,33 @@ def _issue_note():
 
 
 ISSUE_NOTE = _issue_note()
+PMC_SLICE = _newest("pmc_slice.json")      # ... and of the decoder fan-out (R433_PMC_WHAT=slice tools/pmc_issue.py)
+
+
+def slicers_note(live_ms):
+    """k_slice beside the detection pass: its time in THIS run (sizing + placing of one pass, the kernel alone on the device) and what
+    the committed counter pass of this build says about it"""
+    out = {"ms": live_ms, "ms_what": "sizing pass + placing pass of one pass over the step's packages x all decoders, HIP events, the engine alone on the device"}
+    try:
+        s = json.load(open(PMC_SLICE))["derived"]["summary"]
+        out.update({k: s[k] for k in ("wave_instr_per_pulse", "simd_ipc", "waves_per_simd", "packages", "pulses")})
+        out["counts_from"] = os.path.basename(PMC_SLICE) + " (a counter pass of this build, not of this run; without the pre-filter)"
+    except Exception as e:
+        out["counts_from"] = f"no counter pass: {e}"
+    return out
+SIMDS, SHADER_CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, nominal clock (MI355X_MICROARCH.md)
+
+
+def issue_floor_ms(valu_scale=1.0):
+    """The roofline that binds the detection pass: its VALU wave-instructions (committed SQ counter pass of this build, both
+    roles) at 2 clocks per wave64 VALU instruction over 1024 SIMDs -- the time the pass would take if every SIMD issued a
+    VALU instruction whenever it could.  -> (ms, where the counts come from) or (None, why not)"""
+    try:
+        d = ISSUE_NOTE["derived"]
+        valu = sum(d[r]["wave_instructions"]["valu"] for r in ("producers", "consumers", "run_again_or_pairs") if r in d)
+        return valu * valu_scale * 2.0 / (SIMDS * SHADER_CLOCK_HZ) * 1e3, os.path.basename(PMC_ISSUE)
+    except Exception as e:
+        return None, f"no counter pass: {e}"
 
 
 class Backend:
@@ -291,15 +318,30 @@ def cpu_baseline_real_decoders(host_iq, reps=1, what="the inputs of the LAST ste
 
 def other_configs_summary(args):
     """configs[2] and configs[4] (one long cs16 FSK stream; one 2 MS/s mixed stream with -Y autolevel) at BASELINE's full
-    sizes in the same process: their detection time, roofline fraction and the checksum of every bitbuffer of the whole
-    stream against the unmodified reference (half a minute of the run is making the two streams)."""
+    sizes in the same process, the reference's real decoders behind them: their detection time, roofline fraction, the JSON
+    lines of the decoders against the unmodified reference's over the whole stream, the checksum of every bitbuffer, and for
+    configs[4] the latency-per-burst histogram; then configs[3] (the list of 65536 captures) on this one GPU."""
     out = {}
     for cfg_no, n_samples in ((3, 64 << 20), (5, 256 << 20)):
         a = argparse.Namespace(**vars(args))
         a.config, a.stream_samples, a.steps, a.warmup, a.quick, a.no_cpu_baseline = cfg_no, n_samples, 3, 1, True, True
         r = run_stream(a, dict(rank=0, world=1, local_rank=0, dist=None), parity_prefix=True)
-        out[f"config{cfg_no}"] = {k: r[k] for k in ("value", "unit", "ms_per_step", "roofline", "breakdown_ms", "packages_per_step", "parity") if k in r}
+        out[f"config{cfg_no}"] = {k: r[k] for k in ("value", "unit", "ms_per_step", "roofline", "breakdown_ms", "packages_per_step", "bitbuffers_per_step",
+                                                       "decoded_messages_per_step", "decoders_behind_the_path", "parity", "parity_detail", "cpu_baseline",
+                                                       "latency_per_burst_ms") if k in r}
         out[f"config{cfg_no}"]["workload"] = r["config"]["workload"]
+    # configs[3] at N = 1: the one list of 65536 captures in launches of 8192 (the multi-GPU workload on one GPU; the driver's
+    # scaling run is `--config 4 --gpus N`)
+    try:
+        a = argparse.Namespace(**vars(args))
+        a.config, a.list_len, a.launch, a.list_distinct, a.steps, a.warmup, a.quick, a.no_cpu_baseline = 4, 65536, 8192, 16384, 2, 1, False, False
+        r = run_batched(a, dict(rank=0, world=1, local_rank=0, dist=None))
+        out["config4"] = {k: r[k] for k in ("value", "unit", "ms_per_step", "roofline", "breakdown_ms", "packages_per_step", "decoded_messages_per_step",
+                                             "bitbuffers_to_host_per_step", "decoders_behind_the_path", "parity", "parity_detail", "cpu_baseline") if k in r}
+        out["config4"]["roofline"] = {k: v for k, v in out["config4"].get("roofline", {}).items() if k != "issue"}
+        out["config4"]["workload"] = r["config"]["workload"]
+    except Exception as e:
+        out["config4"] = dict(error=str(e))
     return out
 
 
@@ -583,14 +625,14 @@ def replay_threads(world):
     return max(1, min(64, (cpu_quota() * 3 // 2) // max(1, world)))
 
 
-def real_decoder_plugins():
+def real_decoder_plugins(flex=None):
     """The reference's decoders as plugins (dropin/_build/libr433plugins.so: built by `make -C dropin plugins` without the
     reference's DSP units, linked to librtl433seam.so).  No stand-in: the timed path never loads anything under oracle/."""
     from rtl_433_amd import plugins
     if not plugins.available():
         raise SystemExit(f"bench.py: {plugins.LIB_PATH} is missing (`make -C dropin plugins` where the reference tree is; the file travels "
                          "to the GPU box with the snapshot) -- the decoders behind the path are part of the job, there is no substitute")
-    p = plugins.Plugins()
+    p = plugins.Plugins(flex=flex)
     p.source = "dropin/_build/libr433plugins.so"
     return p
 
@@ -650,12 +692,27 @@ def run_batched(args, ctxd):
         # this rank's shard of the one list, resident in HBM (8.6 GB in all, 1.07 GB per GPU at N = 8)
         d_all = torch.empty((n_mine, 2 * n_samples), dtype=torch.uint8, device=dev)
         host_first = None
+        host_launch0 = []  # the captures of this rank's first launch on the host: their decoded JSON is compared with the reference's
+        distinct = args.list_distinct or total  # (--list-distinct D: capture i of the list is seed i mod D -- the default run's short form)
+        made = {}
         for c0 in range(0, n_mine, 4096):
             c1 = min(n_mine, c0 + 4096)
-            part = ook_batches(first + c0, c1 - c0, procs)
+            s0 = (first + c0) % distinct
+            if (first + c0) // distinct == (first + c1 - 1) // distinct:  # (4096 divides every D used: a piece never wraps)
+                part = made.get(s0)
+                if part is None:
+                    part = ook_batches(s0, c1 - c0, procs)
+                    if distinct < total:
+                        made[s0] = part
+            else:
+                part = np.stack([_synth_one((first + c) % distinct) for c in range(c0, c1)])
             if c0 == 0:
                 host_first = part[: min(256, c1)].copy()
+            if c0 < launch:
+                host_launch0.append(part[: min(c1, launch) - c0])
             d_all[c0:c1].copy_(torch.from_numpy(part))
+        made.clear()
+        host_launch0 = np.concatenate(host_launch0) if host_launch0 else None
         batches = [d_all[l * launch: min(n_mine, (l + 1) * launch)] for l in range(n_launches)]
         per_step = n_launches
         n_streams = launch
@@ -681,6 +738,8 @@ def run_batched(args, ctxd):
         if strong:
             st[3] ^= fnv64(e.packages()[0])
         st[4].append(text)
+        if strong and k % per_step == 0:
+            records["launch0_text"] = text  # (of the last pass over the list: the same captures every pass)
         pk_b, _, ev_b, ev_n = e.sizes()
         st[5] += ev_n          # bitbuffers that crossed to the host (the pre-filter keeps the provably refused ones on the device)
         st[6] += pk_b + ev_b   # bytes of records copied back
@@ -753,7 +812,8 @@ def run_batched(args, ctxd):
         det_s = live_det_ms / 1e3
         alg_bytes = 2 * n_streams * n_samples  # 2 B per cu8 IQ sample, read once x the captures of one launch
         achieved = alg_bytes / det_s / 1e9
-        workload = (f"configs[3]: one list of {args.list_len} independent cu8 captures x {n_samples} samples (seeds 0..{args.list_len - 1}) "
+        workload = (f"configs[3]: one list of {args.list_len} independent cu8 captures x {n_samples} samples (seeds 0..{args.list_len - 1}"
+                    + (f" mod {args.list_distinct}: {args.list_distinct} distinct captures, the short form of the default run; `--config 4` makes all {args.list_len} distinct" if args.list_distinct and args.list_distinct < args.list_len else "") + ") "
                     f"sharded contiguously over {world} GPU(s), launches of {n_streams} captures, all {len(devs)} default decoders, "
                     "records gathered on rank 0") if strong else \
                    (f"configs[1]: batches of {n_batch} synthetic 250 kS/s cu8 OOK bursts x {n_samples} samples (every third capture a "
@@ -767,7 +827,14 @@ def run_batched(args, ctxd):
             "data": ("synthetic (resident in HBM; one fixed list)" if strong else
                      "synthetic (in pinned host memory when the timed region starts: --from-host, every step's H2D copy is timed; three distinct inputs rotate)" if args.from_host else
                      "synthetic (resident in HBM when the timed region starts; three distinct inputs rotate; `pcie_inclusive` is the same pipeline fed from pinned host memory)"),
-            "config": {"workload": workload, "streams_per_launch": n_streams, "samples_per_stream": n_samples,
+            "config": {"workload": workload,
+                       "value_definition": ("whole-job IQ samples / wall time of the timed region, inputs RESIDENT IN HBM when the region starts, decoded events "
+                                            "(JSON lines of the reference's real decoders) on the host and gathered on rank 0 when it ends.  Fixed since round 5 "
+                                            "(the task's definition) and not to move again; `value_r04_definition` is the SAME pipeline of the SAME run fed from "
+                                            "pinned host memory, every step's H2D copy inside the timed region: what `value` meant in rounds 1-4 (BENCH_r01..r04), "
+                                            "for like-for-like reads across rounds (= `pcie_inclusive.value`)") if not strong else
+                                           "whole-job IQ samples / wall time of the timed region over the one list, inputs resident in HBM, records gathered on rank 0",
+                       "streams_per_launch": n_streams, "samples_per_stream": n_samples,
                        "sample_rate": 250000, "decoders": len(devs), "host_dispatch_threads": threads, "host_cpus": {"logical": os.cpu_count(), "cfs_quota": cpu_quota()},
                        "launches_per_step_per_gpu": per_step if strong else args.batches,
                        **({} if strong else {"captures_per_batch": n_batch, "batches_per_step_per_gpu": args.batches,
@@ -776,7 +843,13 @@ def run_batched(args, ctxd):
             "roofline": {"bound": "hbm", "kernel": "k_wave<2> (IQ -> packages): the detection pass -- for grids of 6144 captures and more a launch of producers (filters), one of consumers (detector) and a run-again launch, timed together", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": pmc_traffic("config2" if not strong else "config4", alg_bytes, det_s),
+                         "issue_frac": (round(issue_floor_ms()[0] / live_det_ms, 4) if issue_floor_ms()[0] else None),
+                         "issue_floor": {"ms": (round(issue_floor_ms()[0], 3) if issue_floor_ms()[0] else None), "counts_from": issue_floor_ms()[1],
+                                         "formula": "VALU wave-instructions of one pass (producers + consumers + run-again) x 2 clocks per wave64 VALU "
+                                                    "instruction / (1024 SIMDs x 2.4 GHz); issue_frac = that floor / the pass's measured time in THIS run "
+                                                    "(k_wave_timed_region): the fraction of the roofline that binds this kernel, beside `frac` (HBM), which does not"},
                          "issue": ISSUE_NOTE,
+                         "slicers": slicers_note(round(solo_parts.get("count_ms", 0.0) + solo_parts.get("write_ms", 0.0), 3)),
                          "note": "achieved = 2 B/sample x samples of one launch / the kernel's mean launch duration over the timed region (HIP events on "
                                  "the launching stream; the engines of the pipeline take turns on the kernels of a pass).  `traffic` is NOT measured in "
                                  "this run: it is the HBM byte count of the committed counter pass (profiles/, tools/pmc_run.sh) over this run's kernel "
@@ -806,6 +879,8 @@ def run_batched(args, ctxd):
         pipe.run(2, other)
         el, (det_res, _, _, _) = timed(dist, torch, lambda: pipe.run(k_res, other))
         if rank == 0:
+            if not args.from_host:
+                result["value_r04_definition"] = round(world * n_streams * n_samples * k_res / el / 1e6, 2)
             result["hbm_resident" if args.from_host else "pcie_inclusive"] = {
                 "value": round(world * n_streams * n_samples * k_res / el / 1e6, 2), "unit": "Msamples/s", "steps": k_res,
                 "ms_per_step": round(el / k_res * 1e3, 3), "k_wave_ms": round(float(np.mean(det_res)), 3),
@@ -900,6 +975,16 @@ def run_batched(args, ctxd):
                 ref.close()
                 result["cpu_baseline"] = dict(value=round(host_first.shape[0] * n_samples / dt / 1e6, 2), unit="Msamples/s", cores=1, kind="reference",
                                               sample=f"the first {host_first.shape[0]} captures of the list, checksum decode_fn, one pass, single thread")
+                if host_launch0 is not None and records.get("launch0_text") is not None:
+                    # the decoded events of the whole first launch: the JSON lines of the reference's real decoders behind the GPU path against the
+                    # unmodified reference over the same captures (one core: this is also the CPU baseline with real decoders)
+                    import hashlib
+                    real, cpu_text = cpu_baseline_real_decoders(host_launch0, what="the first launch of the list")
+                    mine = records["launch0_text"]
+                    result["cpu_baseline"] = real
+                    result["parity"] += ("; decoded-json-sha256-match" if cpu_text == mine else "; DECODED JSON MISMATCH") + f" (the {host_launch0.shape[0]} captures of the first launch)"
+                    result["parity_detail"] = {"first_launch": {"captures": int(host_launch0.shape[0]), "gpu_sha256": hashlib.sha256(mine).hexdigest(),
+                                                                "cpu_sha256": hashlib.sha256(cpu_text).hexdigest(), "json_lines": mine.count(b"\n")}}
         except Exception as e:
             result["parity"] = f"check failed: {e}"
     pipe_for_extra.close()
@@ -1029,29 +1114,43 @@ def run_stream(args, ctxd, parity_prefix=False):
     d = torch.from_numpy(host.view(np.uint8)).cuda().reshape(1, -1)
     ctx = _lib.DigestCtx(0, 0)
     rdev_arr, rdev_objs = make_rdevices(devs, digest_plugin_addr(), C.addressof(ctx), names, protocols)
+    # The decoders behind the path are the reference's REAL ones (the plugin library: its default set + this config's flex
+    # decoder), replayed in reference order on the host's threads with the device-side pre-filter on -- as in the headline.
+    # What they say (JSON lines of the reference's own printer) is what is compared with the unmodified reference over the
+    # whole stream; every bitbuffer of the stream is checked by a checksum decode_fn on both sides in an untimed pass after it.
+    plug = real_decoder_plugins(flex=ref_kw.get("flex"))
+    assert len(plug.devices) == len(devs), "the plugin library registers another decoder set than the device table"
     eng = BatchEngine(cfg, devs, profiling=True)
     if DEBUG_FLAGS:
         eng.set_debug(DEBUG_FLAGS)
+    eng.set_stateless(plug.stateless())
+    eng.probe_prefilter(plug.devices, helper=plug.helper_probe())
+    hooks = plug.hooks()
     lat = []
+    said = {}
 
-    def one_pass(record_latency=False):
+    def one_pass(record_latency=False, checksum=False):
         ctx.sum = 0
         ctx.events = 0
         t0 = time.perf_counter()
         npk = eng.run(d)
         t_gpu = time.perf_counter() - t0
-        if record_latency:
+        if checksum:  # every bitbuffer through a checksum decode_fn (the pre-filter is off for this pass: the checksum wants every record)
+            eng.dispatch(rdev_arr, n_threads=threads)
+        elif record_latency:
             # the whole stream is on the host at t0; a burst's events leave when its package has been through the decoders
             stamps = []
 
             @_lib.PACKAGE_FN
             def on_pkg(user, stream, typ, pd):
                 stamps.append(time.perf_counter() - t0)
-            eng.dispatch(rdev_arr, pkg_cb=on_pkg, n_threads=1)
+            eng.dispatch(plug.devices, pkg_cb=on_pkg, n_threads=1)
             stamps.append(time.perf_counter() - t0)
             lat.extend(stamps[1:])  # package k is done when package k+1 begins
+            plug.take()
         else:
-            eng.dispatch(rdev_arr, n_threads=threads)
+            eng.dispatch_ordered(plug.devices, hooks, threads)
+            said["text"], said["messages"] = plug.take()
         return npk, t_gpu
 
     for _ in range(max(1, args.warmup)):
@@ -1065,6 +1164,10 @@ def run_stream(args, ctxd, parity_prefix=False):
             tms.append(eng.timing())
         return out
     elapsed, (npk, _) = timed(dist, torch, region)
+    gpu_text, gpu_messages = said.get("text", b""), said.get("messages", 0)
+    eng.set_prefilter(0)
+    one_pass(checksum=True)
+    eng.set_prefilter(1)
     gpu_digest, gpu_events = int(ctx.sum), int(ctx.events)
     det_ms = float(np.mean([t["detect_ms"] for t in tms]))
     result = None
@@ -1083,9 +1186,11 @@ def run_stream(args, ctxd, parity_prefix=False):
                          "traffic": pmc_traffic("config3" if args.config == 3 else "config5", alg_bytes, det_ms / 1e3),
                          "note": f"achieved = {ss} B/sample x samples / detection time of one pass (HIP events, mean of the timed steps)"},
             "breakdown_ms": {k: round(float(np.mean([t[k] for t in tms])), 3) for k in tms[0]},
-            "packages_per_step": int(npk), "events_per_step": gpu_events,
+            "packages_per_step": int(npk), "bitbuffers_per_step": gpu_events, "decoded_messages_per_step": int(gpu_messages),
+            "decoders_behind_the_path": f"the reference's real decode_fn ({plug.source}{' + flex ' + ref_kw['flex'][0] if ref_kw.get('flex') else ''}), "
+                                        f"ordered replay on {threads} threads, device-side pre-filter on",
         }
-        if args.config == 5 and not args.quick:
+        if args.config == 5 and (parity_prefix or not args.quick):
             one_pass(record_latency=True)
             a = np.array(lat) * 1e3
             edges = [0, 5, 10, 20, 50, 100, 200, 500, 1000, 2000, 5000, 1e9]
@@ -1097,25 +1202,46 @@ def run_stream(args, ctxd, parity_prefix=False):
                                                       "every decoder; single-threaded replay in package order"}
         if (parity_prefix or (not args.no_cpu_baseline and not args.quick)) and po.have_ref():
             try:
+                import hashlib
+                sample = min(n_samples, 1 << 28)
+                part = host[: sample * (2 if ss == 2 else 2)].view(np.uint8)[: sample * ss]
+                # the unmodified reference with its real decoders over the stream: what they say, as JSON lines
+                ref = po.Ref(call_real=True, record=False, **ref_kw)
+                if ref_levels:
+                    ref.set_levels(**ref_levels)
+                ref.set_digest_mode(0)
+                ref.text_mode(True)
+                ref.take_text()
+                t0 = time.perf_counter()
+                ref.run(part, ss, rate, freq, fpdm=2, stream_index=0)
+                dt = time.perf_counter() - t0
+                cpu_text = ref.take_text()
+                ref.close()
+                result["cpu_baseline"] = dict(value=round(sample / dt / 1e6, 2), unit="Msamples/s", cores=1, kind="reference",
+                                              sample=f"the first {sample} samples of the stream, the reference's real decoders, one pass, single thread")
+                # ... and with a checksum decode_fn: every bitbuffer of the stream
                 ref = po.Ref(record=False, **ref_kw)
                 if ref_levels:
                     ref.set_levels(**ref_levels)
                 ref.set_digest_mode(2)
-                sample = min(n_samples, 1 << 28)
-                t0 = time.perf_counter()
-                ref.run(host[: sample * (2 if ss == 2 else 2)].view(np.uint8)[: sample * ss], ss, rate, freq, fpdm=2, stream_index=0)
-                dt = time.perf_counter() - t0
+                ref.run(part, ss, rate, freq, fpdm=2, stream_index=0)
                 dg, nev = ref.digest2(), ref.digest()[1]
                 ref.close()
-                result["cpu_baseline"] = dict(value=round(sample / dt / 1e6, 2), unit="Msamples/s", cores=1, kind="reference",
-                                              sample=f"the first {sample} samples of the stream, checksum decode_fn, one pass, single thread")
                 if sample == n_samples:
-                    result["parity"] = "digest-match" if (dg == gpu_digest and nev == gpu_events) else f"MISMATCH cpu {dg}/{nev} gpu {gpu_digest}/{gpu_events}"
+                    json_ok = cpu_text == gpu_text
+                    dig_ok = dg == gpu_digest and nev == gpu_events
+                    result["parity"] = (("decoded-json-sha256-match" if json_ok else "DECODED JSON MISMATCH") + "; bitbuffers: "
+                                        + ("digest-match" if dig_ok else f"MISMATCH cpu {dg}/{nev} gpu {gpu_digest}/{gpu_events}"))
+                    result["parity_detail"] = {"gpu_sha256": hashlib.sha256(gpu_text).hexdigest(), "cpu_sha256": hashlib.sha256(cpu_text).hexdigest(),
+                                               "json_lines": gpu_text.count(b"\n"), "bitbuffers": int(nev),
+                                               "what": "JSON lines of the reference's real decoders behind the GPU path against the unmodified reference over the "
+                                                       "whole stream; every bitbuffer of the stream by a checksum decode_fn on both sides"}
                 else:
                     result["parity"] = "not compared (cpu sample is a prefix of the stream)"
             except Exception as e:
                 result["parity"] = f"cpu baseline failed: {e}"
     eng.close()
+    plug.close()
     return result
 
 
@@ -1134,6 +1260,8 @@ def main():
     ap.add_argument("--batches", type=int, default=8, help="config 2: batches a step submits together per GPU")
     ap.add_argument("--list-len", type=int, default=65536, help="config 4: captures in the one list")
     ap.add_argument("--launch", type=int, default=8192, help="config 4: captures per launch")
+    ap.add_argument("--list-distinct", type=int, default=0, help="config 4: capture i of the list is seed i mod D (0: every capture distinct); the default run's "
+                    "other_configs uses 16384 (making 65536 captures on the host takes over a minute)")
     ap.add_argument("--stream-samples", type=int, default=0, help="configs 3 / 5: samples of the stream (0 = the recipe's)")
     ap.add_argument("--threads", type=int, default=0, help="host dispatch threads per rank (0 = auto)")
     ap.add_argument("--engines", type=int, default=3, help="batch engines in the software pipeline (>= 2)")

@@ -22,6 +22,7 @@
 #include "r_device.h"
 #include "r_private.h"
 #include "rtl_433.h"
+#include "rtl_433_devices.h" /* flex_decoder */
 
 typedef struct r433p {
     r_cfg_t *cfg;
@@ -110,8 +111,9 @@ static void drop_log(r_device *decoder, int level, data_t *data)
     data_free(data);
 }
 
-/* all default-enabled protocols, in registration order */
-void *r433p_create(void)
+/* all default-enabled protocols, in registration order, then one flex decoder per line of flex_specs (`-X` of the CLI,
+   src/rtl_433.c:847-851; NULL or "": none) */
+void *r433p_create_with(char const *flex_specs)
 {
     r433p *h = calloc(1, sizeof(*h));
     if (!h)
@@ -119,6 +121,18 @@ void *r433p_create(void)
     r_logger_set_log_handler(quiet_log, NULL);
     h->cfg = r_create_cfg();
     register_all_protocols(h->cfg, 0);
+    if (flex_specs && *flex_specs) {
+        char *dup = strdup(flex_specs);
+        if (!dup)
+            abort();
+        for (char *s = strtok(dup, "\n"); s; s = strtok(NULL, "\n")) {
+            char *spec = strdup(s); /* (the flex parser keeps pointers into its argument) */
+            if (!spec)
+                abort();
+            register_protocol(h->cfg, &flex_decoder, spec);
+        }
+        free(dup);
+    }
     for (void **it = h->cfg->demod->r_devs.elems; it && *it; ++it) {
         r_device *d   = *it;
         d->output_fn  = take_message;
@@ -126,6 +140,11 @@ void *r433p_create(void)
         d->output_ctx = h;
     }
     return h;
+}
+
+void *r433p_create(void)
+{
+    return r433p_create_with(NULL);
 }
 
 int r433p_devices(void *hv, r_device **out, int cap)

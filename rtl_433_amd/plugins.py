@@ -16,18 +16,20 @@ def available():
 
 
 class Plugins:
-    def __init__(self):
+    def __init__(self, flex=None):
+        """flex: `-X` specs (list of str) registered behind the default decoders, as the CLI does (src/rtl_433.c:847-851)"""
         if not available():
             raise RuntimeError(f"{LIB_PATH} is missing: `make -C dropin plugins` (needs the reference tree once)")
         L = C.CDLL(os.path.abspath(LIB_PATH))
-        L.r433p_create.restype = C.c_void_p
+        L.r433p_create_with.restype = C.c_void_p
+        L.r433p_create_with.argtypes = [C.c_char_p]
         L.r433p_devices.restype = C.c_int
         L.r433p_devices.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.r433p_take.restype = C.c_size_t
         L.r433p_take.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_ulong)]
         L.r433p_destroy.argtypes = [C.c_void_p]
         self.L = L
-        self.h = L.r433p_create()
+        self.h = L.r433p_create_with("\n".join(flex).encode() if flex else None)
         n = L.r433p_devices(self.h, None, 0)
         self.devices = (C.c_void_p * n)()
         assert L.r433p_devices(self.h, self.devices, n) == n

@@ -72,7 +72,13 @@ for r in range(a.reps):
 best = min(ts, key=lambda t: t["detect_ms"])
 import zlib
 print("detect_ms per rep:", [round(t["detect_ms"], 3) for t in ts], "packages crc %08x" % zlib.crc32(eng.packages()[0]), eng.split_stats())
-print(f"flags={a.debug} streams={a.streams} samples={a.samples} pkgs={n} " +
+def _pulses(blob):  # sum of num_pulses over the package records (include/r433_records.h)
+    b, at, tot = bytes(blob), 0, 0
+    while at + 64 <= len(b):
+        tot += int.from_bytes(b[at + 12:at + 16], "little")
+        at += int.from_bytes(b[at:at + 4], "little")
+    return tot
+print(f"flags={a.debug} streams={a.streams} samples={a.samples} pkgs={n} pulses={_pulses(eng.packages()[0])} " +
       " ".join(f"{k}={v:.3f}" for k, v in best.items()) + (f" split={eng.split_stats()}" if a.split else ""))
 
 if a.analyze:

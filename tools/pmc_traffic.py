@@ -20,8 +20,8 @@ WORKLOADS = {
                 "k_wave<2,true,true>, 1024 captures x 65536 cu8 samples (tools/kbench.py, all decoders), one launch"),
     "config3": ([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "3", "--quick", "--steps", "2", "--warmup", "1"], ("k_wave<4", "k_tile_max", "k_frame_sums"), 4 * (64 << 20),
                 "every kernel that reads the stream in one pass of bench.py --config 3 (one 64 Mi-sample cs16 stream): the cut-planning estimate k_tile_max and k_wave<4,...> over the verified segments, all launches"),
-    "config4": ([sys.executable, os.path.join(ROOT, "tools", "kbench.py"), "--reps", "2", "--nodevs", "--streams", "8192"], ("k_wave<2", "k_capture_weight"), 2 * 8192 * 65536,
-                "k_wave<2,true,true> and the look at the captures that orders its grid (k_capture_weight), one launch of 8192 captures x 65536 cu8 samples (what bench.py --config 4 launches eight times per step, and the default bench once per step)"),
+    "config4": ([sys.executable, os.path.join(ROOT, "tools", "kbench.py"), "--reps", "2", "--nodevs", "--streams", "8192", "--bench-batch"], ("k_wave<2", "k_capture_weight"), 2 * 8192 * 65536,
+                "the detection pass (k_wave<2,true,true,..>: producers, consumers, run-again) and the look at the captures that orders its grid (k_capture_weight), one pass over 8192 captures x 65536 cu8 samples of bench.py's own batch (what bench.py --config 4 launches eight times per step, and the default bench once per step)"),
     "config5": ([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "5", "--quick", "--steps", "2", "--warmup", "1"], ("k_wave<2", "k_tile_max", "k_frame_sums"), 2 * (256 << 20),
                 "every kernel that reads the stream in one pass of bench.py --config 5 (one 256 Mi-sample 2 MS/s cu8 stream, -Y autolevel): k_frame_sums (the levels of every frame have to be known before detection), k_tile_max, k_wave<2,...> over the segments"),
 }
@@ -68,7 +68,7 @@ def main():
             cons = sum(1 for n, _, _ in got["FETCH_SIZE"] if "k_wave" in n and n.split(">")[0].rstrip().endswith(", 5"))
             per = cons or sum(1 for n, _, _ in got["FETCH_SIZE"] if "k_wave" in n)
         else:
-            per = 3  # bench.py --config 3 / 5 --steps 2 --warmup 1: three passes over the stream
+            per = 4  # bench.py --config 3 / 5 --steps 2 --warmup 1: three passes over the stream + the untimed checksum pass behind them (round 6)
         fetch_kb = sum(v for _, _, v in got["FETCH_SIZE"]) / per
         write_kb = sum(v for _, _, v in got["WRITE_SIZE"]) / per
         res[key] = dict(kernel=what, dispatches_seen=n_disp, launches_or_passes=per,
