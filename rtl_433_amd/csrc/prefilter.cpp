@@ -713,6 +713,12 @@ int r433_batch_probe_prefilter(r433_batch *b, r433_r_device *const *devices, uin
         // for every package: what the filter proves refused goes along as a stub, the replay books it if it gets there (kPfStub)
         if (!dev || !dev->decode_fn || dev->verbose)
             continue;
+        // A decoder the host says keeps state between calls (r433_batch_set_stateless, made before the probe: statics like
+        // src/devices/secplus_v1.c:142-143, a create_fn's context) is not asked: what it answers may depend on what it was asked
+        // before -- a refusal on the head alone is then no function of the head --, and the questions themselves would leave
+        // made-up half-messages in its state for the replay to pair real ones with.  Its records all cross.
+        if (!b->stateless.empty() && d < b->stateless.size() && !b->stateless[d])
+            continue;
         eligible[d] = 1;
         keys[d] = ProbeKey::of(dev);
         if (g_known.find(keys[d]) == g_known.end()) {

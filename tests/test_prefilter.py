@@ -118,6 +118,45 @@ def test_prefilter_plugins(backend, plugins):
     assert a["calls"][4] == b["calls"][4]
 
 
+def test_prefilter_leaves_stateful_decoders_alone(plugins):
+    """A decoder the host declares as keeping state between calls (r433_batch_set_stateless with a 0 for it; the reference has
+    four with file-scope statics, src/devices/secplus_v1.c:142-143, and every create_fn's context) is never asked -- the
+    questions would leave made-up half-messages in its state, and its refusals need not be functions of the head -- and none
+    of its records is dropped; the others are filtered as ever."""
+    if not build_emu.available():
+        pytest.skip("wave emulator needs x86-64")
+    devs, fns = _devices()
+    iqs = [synth.ook_stream(3000 + k, 40000)[0] for k in range(6)]
+    calls = (C.c_ulong * 8).in_dll(plugins, "pf_calls")
+    got = {}
+    for mode in ("all stateless", "decoders 0 and 5 keep state"):
+        eng = _engine(devs, "emu")
+        eng.L.r433_prefilter_forget()
+        arr, objs = make_rdevices(devs)
+        for o, f in zip(objs, fns):
+            o.decode_fn = C.cast(getattr(plugins, FNS[f]), C.c_void_p).value
+        flags = (C.c_uint8 * len(devs))(*([1] * len(devs)))
+        if mode != "all stateless":
+            flags[0] = flags[5] = 0
+        eng.set_stateless(flags)
+        for k in range(8):
+            calls[k] = 0
+        tables = eng.probe_prefilter(arr)
+        asked = list(calls)
+        eng.run_host(iqs)
+        eng.dispatch_ordered(arr, None, 2)
+        got[mode] = dict(tables=tables, asked=asked, dropped=eng.prefilter_counts(), stats=_stats(objs))
+        eng.L.r433_prefilter_forget()
+        eng.close()
+    a, b = got["all stateless"], got["decoders 0 and 5 keep state"]
+    assert a["stats"] == b["stats"]
+    assert b["tables"] == a["tables"] - 2  # (decoder 6, a later priority level, shares decoder 0's decode_fn but is its own object)
+    assert a["asked"][5] > 0 and b["asked"][5] == 0  # pf_dec_zero is decoder 5's alone: never called by the probe
+    assert a["dropped"][0].sum() > 0 and a["dropped"][5].sum() > 0
+    assert b["dropped"][0].sum() == 0 and b["dropped"][5].sum() == 0
+    assert (b["dropped"][[1, 3]] == a["dropped"][[1, 3]]).all()
+
+
 def test_prefilter_ordered_replay_and_switch(backend, plugins):
     """The ordered multi-threaded replay accounts the dropped records too; set_prefilter(0) brings every record back; an
     event_done hook or a package_filter refuses to run over a filtered pass."""
