@@ -261,6 +261,7 @@ int main(int argc, char **argv)
         }
         if (n_eng > (unsigned)n_gpus)
             r433_batch_set_exclusive_detect(g->eng, 2); /* the engines of one GPU take turns on the kernels of a pass */
+        r433_batch_set_staging_slot(g->eng, 2048); /* a process that lives as long as its file list: a quarter of the device memory to allocate and to leave behind (include/r433_hip.h) */
         if (stateless && r433_batch_set_stateless(g->eng, stateless, (uint32_t)n_dev) != 0) {
             fprintf(stderr, "r433_batch_set_stateless: %s\n", r433_last_error());
             return 1;

@@ -154,6 +154,13 @@ int r433_batch_set_split(r433_batch *b, uint32_t segment_samples);
  * kernel that takes compute units from the kernel beside it; outside the profiler copies run on the SDMA engines and level 2
  * is the faster setting).  Off by default: a lone engine has nobody to wait for. */
 int r433_batch_set_exclusive_detect(r433_batch *b, int on);
+/* Bytes of the staging slot the slicers build a (package, device)'s records in before they are placed (512 .. 8192 in steps of 512;
+ * 0 = the default: 8192, which holds every record there can be -- 50 rows x 132 bytes).  A record that outgrows its slot is
+ * sliced a second time by the placing pass: same results, a little more kernel time per pass (+0.8 ms per 8192 packages at
+ * 2 KB) -- and a quarter of the device memory: 335 decoders x 2100 packages are 5.6 GB of slots at 8 KB.  For hosts that live as
+ * long as one file list: a process that leaves 14 GB of device memory behind slows the NEXT process's start while the driver
+ * frees them (the drop-in CLI back to back: 330-1030 ms per run at 8 KB, 250-400 ms at 2 KB: profiles/r06_g_cli_series.txt). */
+int r433_batch_set_staging_slot(r433_batch *b, uint32_t bytes);
 /* of the last run: wavefront slots planned (segments incl. parity variants), pieces run again after a dropped cut */
 int r433_batch_split_stats(r433_batch *b, uint32_t *segments, uint32_t *pieces_rerun);
 /* How the last detection pass was launched: 45 = the producers of the grid (filters; filtered tiles to HBM) and its consumers

@@ -118,7 +118,7 @@ EXPORTS = [
     "r433_version", "r433_last_error", "r433_device_count", "r433_flow_cfg_default", "r433_level_db",
     "r433_batch_create", "r433_batch_create_on", "r433_batch_device", "r433_batch_destroy", "r433_batch_run", "r433_batch_packages", "r433_batch_events",
     "r433_batch_frame_sums", "r433_batch_device_events", "r433_batch_set_taps", "r433_batch_set_split",
-    "r433_batch_split_stats", "r433_batch_detect_form", "r433_warmup", "r433_host_register", "r433_host_unregister", "r433_batch_set_profiling", "r433_batch_set_debug", "r433_batch_set_exclusive_detect", "r433_batch_enable_logic_dump", "r433_batch_logic_dump",
+    "r433_batch_split_stats", "r433_batch_detect_form", "r433_warmup", "r433_host_register", "r433_host_unregister", "r433_batch_set_profiling", "r433_batch_set_debug", "r433_batch_set_exclusive_detect", "r433_batch_set_staging_slot", "r433_batch_enable_logic_dump", "r433_batch_logic_dump",
     "r433_batch_get_timing", "r433_batch_debug_state", "r433_batch_dispatch", "r433_batch_dispatch_mt", "r433_dispatch_current",
     "r433_plugin_digest_decode", "r433_envelope_detect", "r433_magnitude_est_cu8",
     "r433_magnitude_est_cs16", "r433_convert_cs8_cu8", "r433_convert_cf32_cs16", "r433_dump_convert",
@@ -189,6 +189,8 @@ def bind(L):
     L.r433_batch_logic_dump.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
     L.r433_batch_set_exclusive_detect.restype = C.c_int
     L.r433_batch_set_exclusive_detect.argtypes = [vp, C.c_int]
+    L.r433_batch_set_staging_slot.restype = C.c_int
+    L.r433_batch_set_staging_slot.argtypes = [vp, C.c_uint32]
     L.r433_batch_set_debug.restype = C.c_int
     L.r433_batch_set_debug.argtypes = [vp, C.c_uint32]
     L.r433_batch_detect_form.restype = C.c_int

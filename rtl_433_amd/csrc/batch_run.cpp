@@ -223,7 +223,13 @@ int run_plan_split(RunCtx &r, uint32_t split_samples)
         uint32_t const *tm = b->h_tile_max.p + (size_t)c * tiles_cap;
         uint64_t quiet_below = abs_quiet; // on tile sums
         if (n >= 2 * kTileS) {
-            std::vector<uint32_t> med(tm, tm + n / kTileS);
+            // (only a workgroup's estimated cost depends on it: for long captures the median of every 16th tile -- the full
+            // selection over 131072 tiles was a third of a millisecond between k_tile_max and k_wave, device idle)
+            uint32_t const nt = n / kTileS, step = nt >= 4096 ? 16u : 1u;
+            std::vector<uint32_t> med;
+            med.reserve(nt / step + 1);
+            for (uint32_t t = 0; t < nt; t += step)
+                med.push_back(tm[t]);
             std::nth_element(med.begin(), med.begin() + med.size() / 2, med.end());
             quiet_below = std::max<uint64_t>(abs_quiet, (uint64_t)med[med.size() / 2] * 3 / 2);
         }
@@ -236,12 +242,23 @@ int run_plan_split(RunCtx &r, uint32_t split_samples)
         std::vector<uint32_t> block_min((n_whole + 63) / 64 + 1, 0xffffffffu);
         for (uint32_t t = 0; t < n_whole; ++t)
             block_min[t / 64] = std::min(block_min[t / 64], tm[t]);
-        auto quiet_at = [&](uint32_t t) {
+        auto quiet_tile = [&](uint32_t t) {
             uint32_t const bk = t / 64;
             uint32_t lo = std::min(block_min[bk], block_min[bk + 1]);
             if (bk > 0)
                 lo = std::min(lo, block_min[bk - 1]);
             return tm[t] < std::max<uint64_t>(abs_quiet, (uint64_t)lo * 3 / 2);
+        };
+        // every tile judged once, and the loud ones counted up to each tile: "the quiet_tiles tiles before P are all quiet" is
+        // one subtraction (a candidate used to walk its 12.5 ms again: 0.8 M tile tests per pass over a 256 Mi-sample stream,
+        // a millisecond of host time with the device idle -- profiles/r06_stream_phases.txt)
+        std::vector<uint32_t> loud_before(n_whole + 2, 0);
+        for (uint32_t t = 0; t < n_whole; ++t)
+            loud_before[t + 1] = loud_before[t] + (quiet_tile(t) ? 0u : 1u);
+        loud_before[n_whole + 1] = loud_before[n_whole] + 1u; // (a tile that is not whole is never quiet)
+        auto quiet_at = [&](uint32_t t) { return t < n_whole && loud_before[t + 1] == loud_before[t]; };
+        auto quiet_run = [&](uint32_t first, uint32_t count) { // tiles first .. first + count - 1, all whole and quiet
+            return first + count <= n_whole && loud_before[first + count] == loud_before[first];
         };
         std::vector<uint32_t> cuts;
         uint32_t pos = seg_len;
@@ -252,9 +269,7 @@ int run_plan_split(RunCtx &r, uint32_t split_samples)
             // (anything longer than the space between two lines shows in the next tile's first line): such cuts first.
             uint32_t cut = 0, second_best = 0;
             for (uint32_t P = pos; P < std::min(n, pos + seg_len) && P + kTileS <= n; P += kTileS) {
-                bool quiet = P / kTileS >= quiet_tiles;
-                for (uint32_t q = 1; quiet && q <= quiet_tiles; ++q)
-                    quiet = quiet_at(P / kTileS - q);
+                bool const quiet = P / kTileS >= quiet_tiles && quiet_run(P / kTileS - quiet_tiles, quiet_tiles);
                 if (blind || (quiet && quiet_at(P / kTileS))) {
                     cut = P;
                     break;
@@ -774,7 +789,7 @@ int run_slice_and_mirror(RunCtx &r)
         uint32_t const stretch = (b->debug_flags & (R433_DEBUG_TWO_PASS_SLICER | R433_DEBUG_ONE_STRETCH)) ? r.total_pkgs
                 : (b->debug_flags & R433_DEBUG_SMALL_STRETCH)                                            ? std::min<uint32_t>(3u, r.total_pkgs)
                                                                                                          : std::min(r.total_pkgs, fit);
-        uint32_t stage_cap = 8192;
+        uint32_t stage_cap = b->stage_slot ? b->stage_slot : 8192u;
         if (char const *e = getenv("R433_STAGE_CAP")) // development: A/B timing of smaller slots (records over the slot are sliced again by the placing pass)
             stage_cap = std::max(512, std::min(8192, atoi(e))) & ~511u;
         while (stage_cap >= 512 && (size_t)stretch * n_devs * stage_cap > kStageMax)

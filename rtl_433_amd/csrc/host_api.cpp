@@ -404,6 +404,16 @@ int r433_batch_logic_dump(r433_batch *b, uint8_t const **host, uint64_t *stride)
     return 0;
 }
 
+int r433_batch_set_staging_slot(r433_batch *b, uint32_t bytes)
+{
+    if (!b)
+        return fail(R433_EINVAL, "null batch");
+    if (bytes && (bytes < 512u || bytes > 8192u))
+        return fail(R433_EINVAL, "staging slots are 512 .. 8192 bytes (0: the default, 8192)");
+    b->stage_slot = bytes & ~511u;
+    return 0;
+}
+
 int r433_batch_set_exclusive_detect(r433_batch *b, int on)
 {
     if (!b)

@@ -224,6 +224,7 @@ struct r433_batch {
     // split captures (r433_batch_set_split)
     uint32_t split_samples = R433_SPLIT_AUTO;
     uint32_t debug_flags = 0; // r433_batch_set_debug
+    uint32_t stage_slot = 0; // r433_batch_set_staging_slot: bytes per (package, device) staging slot of the slicers (0: 8 KB, every record fits)
     int exclusive_detect = 0; // r433_batch_set_exclusive_detect: 1 the detection kernel, 2 the slicer kernels as well, 3 the record copies too
     bool logic_on = false;         // r433_batch_enable_logic_dump
     DevBuf<uint8_t> d_logic;

@@ -173,6 +173,10 @@ class BatchEngine:
         (r433_batch_set_exclusive_detect)."""
         _lib.check(self.L.r433_batch_set_exclusive_detect(self.h, int(on)), "r433_batch_set_exclusive_detect", self.L)
 
+    def set_staging_slot(self, nbytes):
+        """bytes per (package, device) staging slot of the slicers, 512 .. 8192 (0: the default 8192); records over it are sliced again by the placing pass"""
+        _lib.check(self.L.r433_batch_set_staging_slot(self.h, int(nbytes)), "r433_batch_set_staging_slot", self.L)
+
     def set_debug(self, flags):
         """Development switches (R433_DEBUG_* of include/r433_hip.h): 1 blind cuts, 2 two-pass slicer, 1024 phase timing."""
         _lib.check(self.L.r433_batch_set_debug(self.h, int(flags)), "r433_batch_set_debug", self.L)

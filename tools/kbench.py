@@ -21,6 +21,7 @@ ap.add_argument("--sigma-only", action="store_true", help="only the captures wit
 ap.add_argument("--fsk-cu8", action="store_true", help="250 kS/s cu8 FSK bursts at 433.92 MHz: the classic FSK detector")
 ap.add_argument("--analyze", action="store_true", help="also time the pulse analyzer (-A) over the packages of the run")
 ap.add_argument("--bench-batch", action="store_true", help="the captures of bench.py's configs[1] batch (every third one a protocol transmission): 1024 distinct, tiled")
+ap.add_argument("--make-batch-only", action="store_true", help="with --bench-batch: make the cached batch and leave (before a profiler run)")
 ap.add_argument("--cs16", action="store_true", help="config 3 style: 1024 kS/s cs16 FSK Manchester bursts, minmax detector")
 a = ap.parse_args()
 if a.cs16:
@@ -32,8 +33,17 @@ elif a.fsk_cu8:
     host = np.tile(host, ((a.streams + len(host) - 1) // len(host), 1))[: a.streams]
     cfg = flow_cfg(2, 250000, fpdm=0)
 elif a.bench_batch:
-    import bench
-    host = bench.ook_batches(a.seed0, min(a.streams, 1024), procs=8)
+    # (kept in /tmp between the runs of a visit: under rocprofv3 the worker processes that make it take minutes)
+    cache = f"/tmp/r433_bench_batch_{a.seed0}_{min(a.streams, 1024)}.npy"
+    if os.path.exists(cache):
+        host = np.load(cache)
+    else:
+        import bench
+        host = bench.ook_batches(a.seed0, min(a.streams, 1024), procs=8)
+        np.save(cache + ".tmp.npy", host)
+        os.replace(cache + ".tmp.npy", cache)
+    if a.make_batch_only:
+        sys.exit(0)
     host = np.tile(host, ((a.streams + len(host) - 1) // len(host), 1))[: a.streams]
     cfg = flow_cfg(2, 250000)
 else:

@@ -75,6 +75,9 @@ def one(tag, counters, debug):
 
 
 def main():
+    if BENCH_BATCH and not os.environ.get("R433_PMC_OFFLINE"):  # the batch is made once, outside the profiler (tools/kbench.py caches it in /tmp)
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kbench.py"), "--bench-batch", "--make-batch-only", "--streams", str(N_CAP)],
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, timeout=300)
     forms = {}
     for i, counters in enumerate(PASSES):
         for form, got in one(f"{WHAT}_pass{i}", counters, int(os.environ.get("R433_PMC_DEBUG", "0"), 0)).items():
