@@ -460,22 +460,36 @@ def dropin_legs(host_iq, expect_json, reps=5):
             host_iq[k].tofile(os.path.join(d, names[-1]))
         args = [a for f in names for a in ("-r", f)] + ["-F", "json", "-M", "level", "-K", "FILE"]
 
-        def run(binary, argv):
+        def run(binary, argv, settle=0.0):
+            # settle: seconds to wait first.  When a process that held gigabytes of device and pinned memory is gone, the driver
+            # goes on freeing them for about a second, and a process that opens the GPU meanwhile waits for it (its hipInit takes
+            # 200-300 ms instead of 80, its first allocations likewise): profiles/r06_g_cli_series.txt.  A run is timed by
+            # itself; what back-to-back runs cost is reported beside it.
+            if settle:
+                time.sleep(settle)
             t0 = time.perf_counter()
             p = subprocess.run([binary] + argv, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             return (time.perf_counter() - t0) * 1e3, p
         out = {"files": n, "samples_per_file": n_samples, "where": d.rsplit("/", 1)[0]}
         walls, shas = [], set()
         for _ in range(reps):
-            ms, p = run(cli, args)
+            ms, p = run(cli, args, settle=1.5)
             if p.returncode != 0:
                 return dict(error="rtl_433_hip: " + p.stderr.decode(errors="replace")[-300:])
             walls.append(round(ms, 1))
             shas.add(hashlib.sha256(p.stdout).hexdigest())
+        b2b = []
+        for _ in range(4):
+            ms, p = run(cli, args)
+            b2b.append(round(ms, 1))
+            shas.add(hashlib.sha256(p.stdout).hexdigest())
         cli_out = {"wall_ms": walls, "median_ms": float(np.median(walls)), "max_over_min": round(max(walls) / min(walls), 2),
                    "value": round(n * n_samples / (float(np.median(walls)) * 1e-3) / 1e6, 1), "unit": "Msamples/s",
+                   "wall_ms_back_to_back": b2b[1:],
                    "json_lines": p.stdout.count(b"\n"), "same_output_every_run": len(shas) == 1,
-                   "note": "wall time of the whole process (start, GPU opening, file reads, passes, replay, JSON), median of the runs"}
+                   "note": "wall time of the whole process (start, GPU opening, file reads, passes, replay, JSON), every run by itself: 1.5 s after the "
+                           "process before it has gone (the driver frees that one's device and pinned memory for about a second, and a process that opens "
+                           "the GPU meanwhile waits: `wall_ms_back_to_back` are runs started at once behind another -- the 2x spread of round 5's line)"}
         if os.path.exists(stock):
             ms, p = run(stock, args)
             cli_out["stock_binary_ms"] = round(ms, 1)
@@ -484,7 +498,7 @@ def dropin_legs(host_iq, expect_json, reps=5):
         if os.path.exists(ph):
             walls, own, ok = [], [], True
             for _ in range(3):
-                ms, p = run(ph, ["-e", "3", "-b", "1024", "-p"] + names)
+                ms, p = run(ph, ["-e", "3", "-b", "1024", "-p"] + names, settle=1.5)
                 if p.returncode != 0:
                     out["pipeline_host_hip"] = dict(error=p.stderr.decode(errors="replace")[-300:])
                     break

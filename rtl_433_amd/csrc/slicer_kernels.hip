@@ -63,6 +63,11 @@ template <int MODE, int CAP = R433_PD_MAX_PULSES> __global__ __launch_bounds__(6
     constexpr bool PLACE = MODE == M_WRITE || MODE == M_COMPACT; // records go to their final offsets
     constexpr bool STORE = MODE != M_COUNT;                       // the sink stores bytes
     constexpr bool SMALL = CAP < R433_PD_MAX_PULSES;              // the launch of the small packages (sizing passes only)
+    // The placing pass (M_COMPACT with a token CAP): a copy per record, and only a slot that its records outgrew is sliced again
+    // -- rare enough to read the pulses straight from the package record in HBM.  Without the 9.6 KB of LDS six wavefronts fit a
+    // SIMD instead of four, and the pass is a chain of dependent loads per item (SIMD IPC 0.04 with 2.9 wavefronts resident,
+    // profiles/r06_pmc_slice.json): more of them in flight is what it wants.
+    constexpr bool FROM_HBM = MODE == M_COMPACT && CAP < 64;
     __shared__ int2 pairs[CAP];
 
     uint32_t const n_pkgs = min(min(*p.n_pkgs, p.max_pkgs), p.pkg_end);
@@ -122,7 +127,7 @@ template <int MODE, int CAP = R433_PD_MAX_PULSES> __global__ __launch_bounds__(6
         }
         uint8_t const *rec = p.arena + (uint64_t)p.dir_stream[pkg] * p.arena_stride + p.dir_off[pkg];
         uint32_t const type = ((uint32_t const *)rec)[2];
-        uint32_t const num = min(((uint32_t const *)rec)[3], (uint32_t)CAP); // (a small launch only draws packages that fit)
+        uint32_t const num = min(((uint32_t const *)rec)[3], (uint32_t)(FROM_HBM ? R433_PD_MAX_PULSES : CAP)); // (a small launch only draws packages that fit)
         int2 const *src = (int2 const *)(rec + sizeof(r433_pkg_rec));
         // The device row is read again for every package ON PURPOSE (the index is made opaque): with the row known to be the
         // same for all packages the compiler unswitches the loop on its modulation -- ten copies of the loop, twice the
@@ -137,11 +142,13 @@ template <int MODE, int CAP = R433_PD_MAX_PULSES> __global__ __launch_bounds__(6
             my_size = p.sizes[(uint64_t)pkg * p.n_devs + t.orig];
         // a compaction visit only needs the pulses if some record of the item has to be sliced again
         bool const need_pulses = MODE != M_COMPACT || __ballot(my_size > p.stage_cap) != 0;
-        __syncthreads(); // previous item done with LDS
-        if (need_pulses)
-            for (uint32_t i = lane; i < num; i += 64)
-                pairs[i] = src[i];
-        __syncthreads();
+        if (!FROM_HBM) {
+            __syncthreads(); // previous item done with LDS
+            if (need_pulses)
+                for (uint32_t i = lane; i < num; i += 64)
+                    pairs[i] = src[i];
+            __syncthreads();
+        }
 
         uint32_t my_bytes = 0;
         uint32_t copy_bytes = 0, copy_base = 0;
@@ -170,7 +177,7 @@ template <int MODE, int CAP = R433_PD_MAX_PULSES> __global__ __launch_bounds__(6
                 limit = p.stage_cap;
             }
             if (slice && fits) {
-                PulseView pv{pairs, num};
+                PulseView pv{FROM_HBM ? src : pairs, num};
                 sink.begin(out, limit, pkg, (uint32_t)t.orig);
                 sink.pf = pf_tab;
                 slice_dispatch<STORE>(pv, t, sink);
@@ -665,8 +672,10 @@ void launch_slice_write(SliceParams const &p, uint32_t grid_pkgs, hipStream_t st
 {
     hipLaunchKernelGGL(k_dev_prefix, dim3(grid_pkgs < 1 ? 1 : grid_pkgs < 16384 ? grid_pkgs : 16384), dim3(64), 0, st, p.sizes, p.dev_off,
             p.n_pkgs, p.max_pkgs, p.n_devs, p.pkg_begin, p.pkg_end);
-    if (p.stage)
+    if (p.stage && getenv("R433_PLACE_FROM_LDS")) // development: A/B timing of the form that stages the pulses of every re-sliced item in LDS
         hipLaunchKernelGGL(k_slice<M_COMPACT>, dim3(slice_grid(grid_pkgs, p.n_rows)), dim3(64), 0, st, p);
+    else if (p.stage)
+        hipLaunchKernelGGL((k_slice<M_COMPACT, 16>), dim3(slice_grid(grid_pkgs, p.n_rows)), dim3(64), 0, st, p);
     else
         hipLaunchKernelGGL(k_slice<M_WRITE>, dim3(slice_grid(grid_pkgs, p.n_rows)), dim3(64), 0, st, p);
 }
