@@ -428,16 +428,23 @@ template <bool W> __device__ __forceinline__ void slice_ppm(PulseView const &p, 
         o_lo = z_hi - 1;
         o_hi = t.s_gap ? t.s_gap : t.s_reset;
     }
+    // (One add_bit and one add_row per symbol, whatever the symbol is: the lanes of a wavefront are 64 decoders with different
+    // timings, most symbols are a one to some of them and a zero to others, and a wavefront executes every inlined copy that any
+    // lane takes -- with a copy per branch of the reference's if-chain, the bit writer ran twice and the row writer three times
+    // per symbol.)
     for (uint32_t n = 0; n < p.num; ++n) {
         int g = p.gap(n);
-        if (g > z_lo && g < z_hi)
-            s.add_bit(0);
-        else if (g > o_lo && g < o_hi)
-            s.add_bit(1);
-        else if (g > y_lo && g < y_hi)
-            s.add_sync();
-        else if (g < t.s_reset)
+        int const bit = (g > z_lo && g < z_hi) ? 0 : (g > o_lo && g < o_hi) ? 1 : -1;
+        bool const sync = bit < 0 && g > y_lo && g < y_hi;
+        bool const row = bit < 0 && !sync && g < t.s_reset;
+        if (bit >= 0)
+            s.add_bit(bit);
+        if (sync)
+            s.touch();
+        if (row || (sync && s.cur_bits)) // add_sync (src/bitbuffer.c:122-133): a row first if the current one holds bits
             s.add_row();
+        if (sync)
+            s.cur_syncs++;
         if ((n == p.num - 1 || g >= t.s_reset) && (s.row0_bits > 0 || s.num_rows > 1))
             s.fire();
     }
@@ -490,16 +497,18 @@ template <bool W> __device__ __forceinline__ void slice_pwm(PulseView const &p, 
     }
     for (uint32_t n = 0; n < p.num; ++n) {
         int w = p.pulse(n), g = p.gap(n);
-        if (w > o_lo && w < o_hi)
-            s.add_bit(1);
-        else if (w > z_lo && w < z_hi)
-            s.add_bit(0);
-        else if (w > y_lo && w < y_hi)
-            s.add_sync();
-        else if (w <= o_lo) {
-        }
-        else
+        // (one add_bit and one add_row for the symbol: see slice_ppm)
+        int const bit = (w > o_lo && w < o_hi) ? 1 : (w > z_lo && w < z_hi) ? 0 : -1;
+        bool const sync = bit < 0 && w > y_lo && w < y_hi;
+        bool const row = bit < 0 && !sync && w > o_lo;
+        if (bit >= 0)
+            s.add_bit(bit);
+        if (sync)
+            s.touch();
+        if (row || (sync && s.cur_bits))
             s.add_row();
+        if (sync)
+            s.cur_syncs++;
         if ((n == p.num - 1 || g > t.s_reset) && s.num_rows > 0)
             s.fire();
         else if (t.s_gap > 0 && g > t.s_gap && s.num_rows > 0 && s.last_row_bits() > 0)
