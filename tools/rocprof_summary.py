@@ -57,6 +57,37 @@ def main(db, out=None):
                 lines.append(f"{r[0]:<28} {r[1]:>6} {r[2]:>18.1f} {r[3]:>20.1f}")
     except sqlite3.Error:
         pass
+    # The detection pass of a large grid is three launches (k_wave<..., 4> producers, <..., 5> consumers, <..., 2> run-again):
+    # what bench.py times as `k_wave_timed_region` and prices as `roofline.achieved` is their sum, pass by pass.
+    try:
+        rows = list(c.execute("select name, start, end from kernels where name like '%k_wave%' order by start"))
+
+        def form(n):
+            return n[n.index("k_wave<"):].split(">")[0].split(",")[-1].strip()
+        passes, cur = [], None
+        for n, s, e in rows:
+            f = form(n)
+            if f == "4":
+                cur = {"4": e - s, "t0": s}
+            elif cur is not None and f in ("5", "2"):
+                cur[f] = cur.get(f, 0) + (e - s)
+                cur["t1"] = e
+                if f == "2":
+                    passes.append(cur)
+                    cur = None
+        if passes:
+            lines.append("")
+            lines.append(f"detection pass = producers + consumers + run-again, {len(passes)} passes:")
+            for k, nm in (("4", "producers  k_wave<..,4>"), ("5", "consumers  k_wave<..,5>"), ("2", "run-again  k_wave<..,2>")):
+                v = [p.get(k, 0) / 1e3 for p in passes]
+                lines.append(f"  {nm}: mean {sum(v) / len(v):9.2f} us (min {min(v):.2f}, max {max(v):.2f})")
+            tot = [(p.get("4", 0) + p.get("5", 0) + p.get("2", 0)) / 1e3 for p in passes]
+            span = [(p["t1"] - p["t0"]) / 1e3 for p in passes]
+            best = sorted(tot)[: max(1, len(tot) // 2)]
+            lines.append(f"  sum of the three: mean {sum(tot) / len(tot):.2f} us, the faster half of the passes (nothing beside them) {sum(best) / len(best):.2f} us; "
+                         f"first start to last end: mean {sum(span) / len(span):.2f} us")
+    except (sqlite3.Error, ValueError, KeyError) as e:
+        lines.append(f"(no per-pass sum: {e})")
     text = "\n".join(lines) + "\n"
     if out:
         open(out, "w").write(text)
