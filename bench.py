@@ -885,7 +885,7 @@ def run_batched(args, ctxd):
     pipe_for_extra = pipe
 
     # ---- secondary measurements of the same run (rank 0, N = 1, the default workload only) ----
-    if not strong and not BK.emu:
+    if not strong and not BK.emu and not (args.quick and args.resident):  # (--quick --resident: the profile run -- under rocprofv3 the H2D copies are blit kernels beside k_wave)
         # the same pipeline fed the other way (every rank runs it: the ranks share the host): from pinned host memory with the
         # H2D copy inside every step when `value` is the resident rate, resident when --from-host made the copy part of `value`
         k_res = max(3, min(args.steps, 20))

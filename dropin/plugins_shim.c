@@ -173,13 +173,18 @@ int r433p_stateless(void *hv, unsigned char *flags, int cap)
     for (void **it = h->cfg->demod->r_devs.elems; it && *it; ++it, ++n) {
         r_device const *d = *it;
         int keeps         = d->decode_ctx != NULL || d->create_fn != NULL;
+        int statics       = 0;
         for (size_t k = 0; k < sizeof(stateful) / sizeof(stateful[0]); ++k)
             if (d->name && strcmp(d->name, stateful[k]) == 0) {
-                keeps = 1;
+                statics = 1;
                 matched |= 1u << k;
             }
+        /* 1 stateless; 0 keeps state in file-scope statics (never asked by the pre-filter); 2 (R433_KEEPS_CONTEXT) all of its
+         * state sits in the context its create_fn allocated (decoder_create, src/decoder_util.c:19-45: blueline, vivint, flex --
+         * none of them has a file-scope variable; arad_ms_meter has both and is in the list above): one replay thread, and asked
+         * by the pre-filter with decode_ctx out of reach */
         if (flags && n < cap)
-            flags[n] = keeps ? 0 : 1;
+            flags[n] = statics ? 0 : keeps ? (d->decode_ctx ? 2 : 0) : 1;
     }
     /* fail closed: a name of the list that matches no registered decoder means the list is stale (a decoder was renamed) --
      * answering then would declare the renamed decoder stateless and let its statics race on the replay threads */

@@ -872,9 +872,12 @@ static hip_engine *engine_get_locked(r_cfg_t *cfg, r433_flow_cfg const *fc, int 
         for (size_t i = 0; i < n; ++i) {
             r_device const *d = demod->r_devs.elems[i];
             int keeps         = d->decode_ctx != NULL || d->create_fn != NULL || !d->decode_fn;
+            int statics       = !d->decode_fn;
             for (size_t k = 0; k < sizeof(stateful) / sizeof(stateful[0]); ++k)
-                keeps |= d->name && strcmp(d->name, stateful[k]) == 0;
-            flags[i] = keeps ? 0 : 1;
+                statics |= d->name && strcmp(d->name, stateful[k]) == 0;
+            /* 2 = R433_KEEPS_CONTEXT: its state is the context of its create_fn (blueline, vivint, flex decoders): one replay
+               thread, asked by the pre-filter with that context out of reach (include/r433_hip.h) */
+            flags[i] = statics ? 0 : keeps ? (d->decode_ctx ? 2 : 0) : 1;
         }
         if (r433_batch_set_stateless(slot->eng, flags, (uint32_t)n) < 0)
             hip_fatal("r433_batch_set_stateless");

@@ -280,7 +280,16 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
  * of a large batch (a TPMS decoder that searches every row of every bitbuffer: 0.6 M calls, 27 ms per 8192 captures), and
  * of the reference's 335 default decoders only four keep state (secplus_v1, secplus_v2, ikea_sparsnas, arad_ms_meter:
  * file-scope statics under src/devices).  Which decoders qualify is the HOST's knowledge about its plugins: the library
- * cannot see it and the default is 0 for every decoder.  NULL: back to the default.  The flags stay with the engine. */
+ * cannot see it and the default is 0 for every decoder.  NULL: back to the default.  The flags stay with the engine.
+ * The flags also tell the pre-filter whom it may ask (round 6; make the statement BEFORE r433_batch_probe_prefilter):
+ *   1  stateless: asked as it is;
+ *   0  keeps state the library cannot see (file-scope statics): never asked and never filtered -- a refusal of such a decoder
+ *      need not be a function of the bitbuffer's head, and the questions would leave made-up messages in its state;
+ *   2  (R433_KEEPS_CONTEXT) keeps state, all of it behind r_device.decode_ctx (a create_fn's context: src/decoder_util.c:19-45):
+ *      stays on one replay thread like 0, and is asked with decode_ctx pointing at an unreadable page -- a refusal that comes
+ *      back without a fault has neither read nor written the decoder's state, so it is a function of the head it was shown
+ *      (the same argument as for the payload behind the fence), and the real context is not touched by any question. */
+#define R433_KEEPS_CONTEXT 2
 int r433_batch_set_stateless(r433_batch *b, uint8_t const *stateless, uint32_t n_devices);
 /* per package of the last dispatch: the events its decoders reported (p_events) */
 int r433_batch_decoded(r433_batch *b, int const **per_package, uint32_t *count);

@@ -638,7 +638,7 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
         uint32_t const kStretch = (b->debug_flags & R433_DEBUG_SMALL_STRETCH) ? 5u : by_slice ? 1536u : 6144u; // (a slice holds ~4 records)
         for (uint32_t d : devs_of_level) {
             uint32_t const first = dev_count[d], last = dev_count[d + 1];
-            bool const split = d < b->stateless.size() && b->stateless[d] && last - first > kStretch + kStretch / 2;
+            bool const split = d < b->stateless.size() && b->stateless[d] == 1 && last - first > kStretch + kStretch / 2;
             if (!split) {
                 items.push_back({d, first, last});
                 continue;

@@ -248,7 +248,18 @@ void apply_prefilter_counts(r433_batch *b, r433_r_device *const *devices, uint32
 // syncs_before_row[0] == 0, no byte ever written past the row's bits (BitSink::fire).
 constexpr unsigned kTinyBits = 14;
 
-void probe_tiny(r433_r_device *dev, std::vector<uint8_t> &tab, bool &useful, bool &accepts)
+// An unreadable page for r_device.decode_ctx to point at while a decoder that keeps its state behind that pointer is asked
+// (R433_KEEPS_CONTEXT): one per process, never unmapped.
+void *dead_context()
+{
+    static void *const page = [] {
+        void *p = mmap(nullptr, 4096, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        return p == MAP_FAILED ? nullptr : p;
+    }();
+    return page;
+}
+
+void probe_tiny(r433_r_device *dev, std::vector<uint8_t> &tab, bool &useful, bool &accepts, bool guarded)
 {
     r433_bitbuffer *bits = (r433_bitbuffer *)calloc(1, sizeof(r433_bitbuffer));
     if (!bits)
@@ -271,7 +282,19 @@ void probe_tiny(r433_r_device *dev, std::vector<uint8_t> &tab, bool &useful, boo
                 uint32_t const msb = n ? v << (16 - n) : 0u; // MSB first, like bitbuffer_add_bit
                 bits->bb[0][0] = (uint8_t)(msb >> 8);
                 bits->bb[0][1] = (uint8_t)msb;
-                int const ret = dev->decode_fn(dev, bits);
+                int ret = INT_MIN;
+                if (!guarded) {
+                    ret = dev->decode_fn(dev, bits);
+                }
+                else if (sigsetjmp(t_jump, 0) == 0) { // (its context is fenced: a content that makes it reach for its state faults)
+                    t_armed = 1;
+                    ret = dev->decode_fn(dev, bits);
+                    t_armed = 0;
+                }
+                if (ret == INT_MIN) { // reached for its state: nothing is known about this length
+                    same = false;
+                    break;
+                }
                 // a decoder that added or extracted rows before it refused (bitbuffer_add_row, an in-place expansion) must not
                 // leave them for the next question: every row its num_rows / free_row reach is cleared, as the replay's
                 // call_one does between two real bitbuffers (dispatch.cpp); the head and row 0 are rewritten above anyway
@@ -300,23 +323,29 @@ bool probe_two_rows(Fence &fence2, r433_r_device *dev, r433_helper_probe *blk, s
 bool probe_short_rows(Fence &fence, r433_r_device *dev, r433_helper_probe *blk, std::vector<uint8_t> &tab, bool &useful);
 
 // Every question one decoder is asked.  True: `tab` holds its verdicts (something to filter, answers steady).
-bool probe_one(Fence &fence, Fence &fence2, r433_r_device *dev, r433_helper_probe *blk, std::vector<uint8_t> &tab)
+bool probe_one(Fence &fence, Fence &fence2, r433_r_device *dev, r433_helper_probe *blk, std::vector<uint8_t> &tab, bool fence_context)
 {
+    if (fence_context && !dead_context())
+        return false;
     struct Quiet { // outputs off for the time of the questions
         r433_r_device *d;
         decltype(d->output_fn) out;
         decltype(d->log_fn) log;
-        explicit Quiet(r433_r_device *dev) : d(dev), out(dev->output_fn), log(dev->log_fn)
+        void *ctx;
+        Quiet(r433_r_device *dev, bool fence_ctx) : d(dev), out(dev->output_fn), log(dev->log_fn), ctx(dev->decode_ctx)
         {
             d->output_fn = swallow_output;
             d->log_fn = swallow_log;
+            if (fence_ctx) // the decoder's state is out of reach: what it answers without a fault it answers without it
+                d->decode_ctx = dead_context();
         }
         ~Quiet()
         {
             d->output_fn = out;
             d->log_fn = log;
+            d->decode_ctx = ctx;
         }
-    } quiet(dev);
+    } quiet(dev, fence_context);
     bool useful = false, accepts = false;
     tab.assign(kPfTable, (uint8_t)kPfKeep); // a head nobody asked about goes to the host: always safe
     bool const steady = probe_heads(fence, dev, tab, useful, accepts);
@@ -328,7 +357,7 @@ bool probe_one(Fence &fence, Fence &fence2, r433_r_device *dev, r433_helper_prob
         return false;
     if (blk && !probe_short_rows(fence, dev, blk, tab, useful))
         return false;
-    probe_tiny(dev, tab, useful, accepts);
+    probe_tiny(dev, tab, useful, accepts, fence_context);
     return useful && !accepts;
 }
 
@@ -717,8 +746,11 @@ int r433_batch_probe_prefilter(r433_batch *b, r433_r_device *const *devices, uin
         // src/devices/secplus_v1.c:142-143, a create_fn's context) is not asked: what it answers may depend on what it was asked
         // before -- a refusal on the head alone is then no function of the head --, and the questions themselves would leave
         // made-up half-messages in its state for the replay to pair real ones with.  Its records all cross.
+        // (2 = all of its state sits behind decode_ctx: asked with that pointer on an unreadable page, probe_one)
         if (!b->stateless.empty() && d < b->stateless.size() && !b->stateless[d])
             continue;
+        if (!b->stateless.empty() && d < b->stateless.size() && b->stateless[d] == R433_KEEPS_CONTEXT && !dev->decode_ctx)
+            continue; // (says its state is behind a context and has none: not to be believed)
         eligible[d] = 1;
         keys[d] = ProbeKey::of(dev);
         if (g_known.find(keys[d]) == g_known.end()) {
@@ -754,7 +786,9 @@ int r433_batch_probe_prefilter(r433_batch *b, r433_r_device *const *devices, uin
                 uint32_t const k = cursor.fetch_add(1, std::memory_order_relaxed);
                 if (k >= ask_list.size())
                     break;
-                answered[k] = probe_one(fence, fence2, devices[ask_list[k]], blk, answers[k]) ? 1 : 0;
+                uint32_t const d = ask_list[k];
+                bool const fence_context = d < b->stateless.size() && b->stateless[d] == R433_KEEPS_CONTEXT;
+                answered[k] = probe_one(fence, fence2, devices[d], blk, answers[k], fence_context) ? 1 : 0;
             }
             if (helper)
                 helper(-1);

@@ -139,3 +139,24 @@ int pf_dec_random(struct r_device *d, bitbuffer_t *b)
     }
     return payload_verdict(b, 0);
 }
+
+/* A decoder with a context (a create_fn's, src/decoder_util.c:19-45; the test hands its address in pf_ctx_offset, the offset of
+ * r_device.decode_ctx): its state is a counter in that context.  Multi-row bitbuffers and long rows it refuses without a look at
+ * its state; SHORT rows it counts in its state before it refuses them.  Asked with the context out of reach
+ * (R433_KEEPS_CONTEXT) it gets verdicts for the first two and none for the short rows -- and no question moves the counter. */
+unsigned pf_ctx_offset;
+int pf_dec_context(struct r_device *d, bitbuffer_t *b)
+{
+    pf_calls[6]++;
+    if (b->num_rows != 1)
+        return -2;
+    if (b->bits_per_row[0] > 150)
+        return -1;
+    unsigned *state = *(unsigned **)((char *)d + pf_ctx_offset);
+    if (b->bits_per_row[0] < 64) {
+        state[0] += 1; /* (the look at its state comes first) */
+        return -1;
+    }
+    state[1] += 1;
+    return payload_verdict(b, 0);
+}

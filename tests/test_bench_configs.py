@@ -1,7 +1,8 @@
 """BASELINE.json configs[2] and configs[4] at FULL size through bench.py on the GPU: one 64 Mi-sample 1024 kS/s cs16 FSK stream
 (min/max detector, Manchester decoders) and one 256 Mi-sample 2 MS/s cu8 stream (-Y autolevel, -Y filter, every decoder),
-each spread over the chip by verified cuts -- every bitbuffer of the whole stream against the unmodified reference
-(oracle/_ref) by checksum, the same line bench.py prints for `--config 3` / `--config 5`."""
+each spread over the chip by verified cuts, the reference's real decoders (+ the config's flex decoder) behind the path -- their
+JSON lines over the whole stream against the unmodified reference's (oracle/_ref) by SHA-256 and every bitbuffer by checksum, the
+same line bench.py prints for `--config 3` / `--config 5`."""
 import json
 import os
 import subprocess
@@ -23,5 +24,7 @@ def test_full_size_stream_vs_reference(config, samples):
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
     line = json.loads(p.stdout.decode().strip().splitlines()[-1])
     assert line["config"]["samples"] == samples
-    assert line["parity"] == "digest-match", line["parity"]
-    assert line["packages_per_step"] > 100 and line["events_per_step"] > 1000
+    # the reference's real decoders behind the path: their JSON lines over the whole stream by SHA-256, every bitbuffer by checksum
+    assert line["parity"] == "decoded-json-sha256-match; bitbuffers: digest-match", line["parity"]
+    assert line["parity_detail"]["gpu_sha256"] == line["parity_detail"]["cpu_sha256"]
+    assert line["packages_per_step"] > 100 and line["bitbuffers_per_step"] > 1000 and line["decoded_messages_per_step"] > 0

@@ -157,6 +157,46 @@ def test_prefilter_leaves_stateful_decoders_alone(plugins):
     assert (b["dropped"][[1, 3]] == a["dropped"][[1, 3]]).all()
 
 
+def test_prefilter_asks_a_context_decoder_with_its_context_out_of_reach(plugins):
+    """R433_KEEPS_CONTEXT (flag 2 of r433_batch_set_stateless): a decoder whose state is all behind r_device.decode_ctx is asked
+    with that pointer on an unreadable page -- a refusal that comes back without a fault has neither read nor written the state.
+    The test decoder refuses many-row bitbuffers and long rows without its state (filtered), counts short rows in its state
+    before it refuses them (never filtered: the question faults), and its counter is what the unfiltered run leaves."""
+    if not build_emu.available():
+        pytest.skip("wave emulator needs x86-64")
+    devs = np.zeros(2, dtype=po.DEV_DTYPE)
+    devs[0] = (4, 100.0, 100.0, 900.0, 0.0, 0.0, 0.0, 0)        # OOK_PCM, short reset: many short one-row bitbuffers
+    devs[1] = (4, 100.0, 100.0, 3000.0, 0.0, 0.0, 0.0, 0)       # OOK_PCM: long rows
+    iqs = [synth.ook_stream(7000 + k, 50000)[0] for k in range(12)]
+    C.c_uint.in_dll(plugins, "pf_ctx_offset").value = _lib.RDevice.decode_ctx.offset
+    calls = (C.c_ulong * 8).in_dll(plugins, "pf_calls")
+    got = {}
+    for mode in ("plain", "context fenced"):
+        eng = _engine(devs, "emu")
+        eng.L.r433_prefilter_forget()
+        arr, objs = make_rdevices(devs)
+        state = [(C.c_uint * 2)(0, 0) for _ in objs]
+        for o, st in zip(objs, state):
+            o.decode_fn = C.cast(plugins.pf_dec_context, C.c_void_p).value
+            o.decode_ctx = C.addressof(st)
+        eng.set_stateless((C.c_uint8 * 2)(2, 2))
+        tables = eng.probe_prefilter(arr) if mode != "plain" else 0
+        assert all(st[0] == 0 and st[1] == 0 for st in state), "a question reached the decoder's state"
+        assert all(o.decode_ctx == C.addressof(st) for o, st in zip(objs, state))  # (the pointer is back)
+        calls[6] = 0
+        eng.run_host(iqs)
+        eng.dispatch_ordered(arr, None, 2)
+        got[mode] = dict(tables=tables, calls=int(calls[6]), state=[(st[0], st[1]) for st in state], stats=_stats(objs),
+                         dropped=eng.prefilter_counts() if mode != "plain" else None)
+        eng.L.r433_prefilter_forget()
+        eng.close()
+    a, b = got["plain"], got["context fenced"]
+    assert b["tables"] == 2 and a["stats"] == b["stats"]
+    assert a["state"] == b["state"] and sum(s[0] for s in a["state"]) > 10  # every short row still reached the decoder, in both runs
+    dropped = int(b["dropped"].sum())
+    assert dropped > 20 and a["calls"] - b["calls"] == dropped  # the long rows and the many-row bitbuffers stayed on the device
+
+
 def test_prefilter_ordered_replay_and_switch(backend, plugins):
     """The ordered multi-threaded replay accounts the dropped records too; set_prefilter(0) brings every record back; an
     event_done hook or a package_filter refuses to run over a filtered pass."""

@@ -21,7 +21,7 @@ timeout 20 python -c "
 import json,sys
 d=json.load(open('$OUT/bench.json')); print({k: d.get(k) for k in ('value','ms_per_step','breakdown_ms','parity','bitbuffers_to_host_per_step','d2h_bytes_per_step_per_gpu')}); print(d.get('roofline',{}).get('frac'), d.get('roofline',{}).get('traffic'), d.get('pcie_inclusive'), d.get('cpu_baseline')); print({k: (v.get('value'), v.get('roofline',{}).get('frac'), v.get('parity')) for k, v in (d.get('other_configs') or {}).items() if isinstance(v, dict)}); print(json.dumps(d.get('dropin'))[:900])" </dev/null
 echo "== rocprofv3 kernel trace of the resident pipeline"
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 12 --warmup 3 --quick --exclusive 3 > $GRAFT_REPO_ROOT/$OUT/prof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err </dev/null )
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 12 --warmup 3 --quick --resident --exclusive 3 > $GRAFT_REPO_ROOT/$OUT/prof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err </dev/null )
 DB=$(find $OUT/prof -name '*.db' | head -1)
 [ -n "$DB" ] && timeout 60 python tools/rocprof_summary.py $DB $OUT/kernel_stats.txt </dev/null | head -30
 find $OUT/prof -name '*.db' -size +20M -delete
