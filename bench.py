@@ -460,7 +460,7 @@ def dropin_legs(host_iq, expect_json, reps=5):
             host_iq[k].tofile(os.path.join(d, names[-1]))
         args = [a for f in names for a in ("-r", f)] + ["-F", "json", "-M", "level", "-K", "FILE"]
 
-        def run(binary, argv, settle=0.0):
+        def run(binary, argv, settle=0.0, env=None):
             # settle: seconds to wait first.  When a process that held gigabytes of device and pinned memory is gone, the driver
             # goes on freeing them for about a second, and a process that opens the GPU meanwhile waits for it (its hipInit takes
             # 200-300 ms instead of 80, its first allocations likewise): profiles/r06_g_cli_series.txt.  A run is timed by
@@ -468,7 +468,7 @@ def dropin_legs(host_iq, expect_json, reps=5):
             if settle:
                 time.sleep(settle)
             t0 = time.perf_counter()
-            p = subprocess.run([binary] + argv, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            p = subprocess.run([binary] + argv, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
             return (time.perf_counter() - t0) * 1e3, p
         out = {"files": n, "samples_per_file": n_samples, "where": d.rsplit("/", 1)[0]}
         walls, shas = [], set()
@@ -490,13 +490,17 @@ def dropin_legs(host_iq, expect_json, reps=5):
                    "note": "wall time of the whole process (start, GPU opening, file reads, passes, replay, JSON), every run by itself: 1.5 s after the "
                            "process before it has gone (the driver frees that one's device and pinned memory for about a second, and a process that opens "
                            "the GPU meanwhile waits: `wall_ms_back_to_back` are runs started at once behind another -- the 2x spread of round 5's line)"}
+        # one more run with the drop-in's own stage clock on stderr (RTL433_HIP_TRACE=1): where the wall time of a run goes
+        ms, p = run(cli, args, settle=1.5, env=dict(os.environ, RTL433_HIP_TRACE="1"))
+        cli_out["traced_run"] = {"wall_ms": round(ms, 1), "stages": [l.replace("hip flow: ", "")[:110] for l in p.stderr.decode(errors="replace").splitlines()
+                                                                    if "hip flow:" in l][:24]}
         if os.path.exists(stock):
             ms, p = run(stock, args)
             cli_out["stock_binary_ms"] = round(ms, 1)
             cli_out["json_sha256_equals_stock_binary"] = bool(p.returncode == 0 and shas == {hashlib.sha256(p.stdout).hexdigest()})
         out["rtl_433_hip"] = cli_out
         if os.path.exists(ph):
-            walls, own, ok = [], [], True
+            walls, own, ok, ph_texts = [], [], True, set()
             for _ in range(3):
                 ms, p = run(ph, ["-e", "3", "-b", "1024", "-p"] + names, settle=1.5)
                 if p.returncode != 0:
@@ -507,12 +511,14 @@ def dropin_legs(host_iq, expect_json, reps=5):
                 at = tail.rfind("passes over")
                 own.append(float(tail[at:].split(": ", 1)[1].split(" ms", 1)[0]) if at >= 0 else None)
                 ok = ok and (expect_json is None or p.stdout == expect_json)
+                ph_texts.add(p.stdout)
             else:
                 out["pipeline_host_hip"] = {"wall_ms": walls, "median_ms": float(np.median(walls)), "passes_ms_by_its_own_clock": own,
                                             "value": round(n * n_samples / (float(np.median(walls)) * 1e-3) / 1e6, 1), "unit": "Msamples/s",
                                             "json_equals_timed_region": (bool(ok) if expect_json is not None else None),
                                             "note": "a C host over include/r433_hip.h + libr433plugins.so, three engines, passes of 1024 files, "
                                                     "pre-filter on; wall time of the whole process"}
+                out["_ph_texts"] = ph_texts  # (popped by the caller: compared with the timed region's JSON once that exists)
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -697,6 +703,7 @@ def run_batched(args, ctxd):
     assert len(plug.devices) == len(devs), "the plugin library registers another decoder set than the device table"
     stateless = plug.stateless()  # what the plugin library says about its own decoders (r433p_stateless -> r433_batch_set_stateless)
 
+    dropin_first = None
     if strong:
         total = args.list_len
         bounds = shard.partition(total, world)
@@ -735,9 +742,20 @@ def run_batched(args, ctxd):
         n_streams = n_batch * args.batches     # captures a step submits together (one grid)
         n_rot = 3
         host_batches = [ook_batches((rank * n_rot + b) * n_streams, n_streams, procs if n_streams >= 2048 else 1) for b in range(n_rot)]
+        per_step = 1
+        if rank == 0 and world == 1 and not BK.emu and not args.quick and not args.no_cpu_baseline:
+            # The drop-in CLI and the C pipeline host over the files of the LAST step of the timed region (what a user of
+            # `rtl_433 -r` gets): processes of their own, timed before this one has touched the GPU -- no device memory, no
+            # pinned memory, no replay threads beside them.  Their JSON is compared with the timed region's once that has run.
+            # (It makes no difference to their wall time -- 570-600 ms at the start as at the end of the run, this box; the
+            # 285 ms of profiles/r06_g_cli_series.txt are tools/cli_trace.sh's lighter captures, synth.ook_stream without the
+            # protocol transmissions: a third of the replay -- but a quiet machine is the cleaner measurement.)
+            try:
+                dropin_first = dropin_legs(host_batches[(args.steps * per_step - 1) % len(host_batches)], None)
+            except Exception as e:
+                dropin_first = dict(error=str(e))
         pinned = [BK.pinned(h) for h in host_batches]
         batches = [BK.resident(h) for h in host_batches]  # the same inputs resident in HBM (`hbm_resident`)
-        per_step = 1
 
     records = {}
 
@@ -954,7 +972,7 @@ def run_batched(args, ctxd):
                 result["real_decoders"] = real_decoders_leg(host_batches[0][:n_batch], batches[0][:n_batch], devs, threads, local_rank)
             except Exception as e:
                 result["real_decoders"] = dict(error=str(e))
-            want_dropin = True  # (run at the very end, when this process has given its engines and its device memory back)
+            want_dropin = True  # (the legs ran first -- dropin_first --; their JSON is compared at the end)
             try:  # the other single-stream workloads of BASELINE.json under the same roof (short passes, inputs resident)
                 result["other_configs"] = other_configs_summary(args)
             except Exception as e:
@@ -1000,20 +1018,14 @@ def run_batched(args, ctxd):
         except Exception as e:
             result["parity"] = f"check failed: {e}"
     pipe_for_extra.close()
-    if want_dropin:
-        # the drop-in CLI and the C pipeline host over the files of the last step (what a user of `rtl_433 -r` gets): processes of
-        # their own, timed when this one holds nothing on the GPU any more (beside a process with 100 GB of device memory and
-        # 3 GiB of pinned memory their GPU opening took twice as long)
-        try:
-            last = host_batches[(args.steps * per_step - 1) % len(host_batches)]
-            last_text = records.get("last_text")
-            del pinned, batches, d_bufs
-            import gc
-            gc.collect()
-            torch.cuda.empty_cache()
-            result["dropin"] = dropin_legs(last, last_text)
-        except Exception as e:
-            result["dropin"] = dict(error=str(e))
+    if want_dropin and dropin_first is not None:
+        # (the legs themselves ran first, before this process opened the GPU: dropin_first)
+        ph_texts = dropin_first.pop("_ph_texts", None)
+        last_text = records.get("last_text")
+        if ph_texts is not None and isinstance(dropin_first.get("pipeline_host_hip"), dict) and last_text is not None:
+            dropin_first["pipeline_host_hip"]["json_equals_timed_region"] = bool(ph_texts == {last_text})
+        dropin_first["when"] = "before this process opened the GPU (a process of its own beside an idle device, as a user runs it)"
+        result["dropin"] = dropin_first
     return result
 
 

@@ -11,3 +11,8 @@ for c in 3 5 4; do
 import json
 d=json.load(open('$OUT/bench_config$c.json')); print({k: d.get(k) for k in ('value','ms_per_step','parity')}, d.get('roofline',{}).get('frac'), d.get('breakdown_ms',{}).get('detect_ms'), d.get('latency_per_burst_ms',{}).get('p50'))" </dev/null
 done
+echo "== bench (the driver's form) again, drop-in legs at the end"
+timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err </dev/null; tail -1 $OUT/bench.err | cut -c1-200
+timeout 20 python -c "
+import json
+d=json.load(open('$OUT/bench.json')); print({k: d.get(k) for k in ('value','ms_per_step','parity')}, d['roofline']['frac'], d['roofline']['issue_frac']); dd=d['dropin']; print(dd['rtl_433_hip']['wall_ms'], dd['rtl_433_hip']['median_ms'], dd['rtl_433_hip']['max_over_min'], dd['rtl_433_hip']['wall_ms_back_to_back'], dd['pipeline_host_hip']['wall_ms'])" </dev/null
