@@ -640,6 +640,14 @@ def cpu_quota():
     return n
 
 
+def cgroup_cpu_stat():
+    """usage_usec / nr_throttled / throttled_usec of this container's cgroup (v2), {} where there is none"""
+    try:
+        return {k: int(v) for k, v in (l.split()[:2] for l in open("/sys/fs/cgroup/cpu.stat")) if k in ("usage_usec", "nr_throttled", "throttled_usec")}
+    except Exception:
+        return {}
+
+
 def replay_threads(world):
     """host threads of the ordered replay per rank: one and a half per CPU the quota grants (they wait on memory), at most 64"""
     return max(1, min(64, (cpu_quota() * 3 // 2) // max(1, world)))
@@ -824,7 +832,9 @@ def run_batched(args, ctxd):
         return out
 
     pipe.replay_s.clear()
+    cpu0, cg0 = os.times(), cgroup_cpu_stat()
     elapsed, (det_ms, tot_ms, disp_s, n_pkgs) = timed(dist, torch, timed_region)
+    cpu1, cg1 = os.times(), cgroup_cpu_stat()
     replay_ms = float(np.mean(pipe.replay_s)) * 1e3 if pipe.replay_s else 0.0
 
     result = None
@@ -886,6 +896,15 @@ def run_batched(args, ctxd):
                                  "the launching stream; the engines of the pipeline take turns on the kernels of a pass).  `traffic` is NOT measured in "
                                  "this run: it is the HBM byte count of the committed counter pass (profiles/, tools/pmc_run.sh) over this run's kernel "
                                  "time.  The kernel is bound by wavefront instruction issue, not by HBM: see `issue` (DESIGN.md 3.1)"},
+            "host_cpu": {"cpus_granted": cpu_quota(), "replay_threads": threads,
+                         "cpu_ms_per_step_this_rank": round(((cpu1.user + cpu1.system) - (cpu0.user + cpu0.system)) * 1e3 / args.steps, 1),
+                         "cgroup_cpu_ms_per_step": round((cg1["usage_usec"] - cg0["usage_usec"]) / 1e3 / args.steps, 1) if "usage_usec" in cg0 and "usage_usec" in cg1 else None,
+                         "throttled_periods": (cg1["nr_throttled"] - cg0["nr_throttled"]) if "nr_throttled" in cg0 and "nr_throttled" in cg1 else None,
+                         "throttled_ms_per_step": round((cg1["throttled_usec"] - cg0["throttled_usec"]) / 1e3 / args.steps, 2) if "throttled_usec" in cg0 and "throttled_usec" in cg1 else None,
+                         "note": "CPU time of this process (replay threads into the decoders, the GPU legs' threads -- their waits spin --, Python) over the timed "
+                                 "region, per step; cgroup = everything in the container (all ranks at N > 1); throttled = time the container's threads "
+                                 "were held back by its CFS quota.  cpu_ms_per_step / cpus_granted is the floor the host sets under ms_per_step: what decides "
+                                 "the N > 1 curve on a host whose ranks share one quota (DESIGN 4)"},
             "breakdown_ms": {"k_wave_timed_region": round(live_det_ms, 3), "k_wave_alone": round(solo_det_ms, 3), "gpu_leg_alone_incl_d2h": round(solo_tot_ms, 3),
                              "gpu_leg_alone_parts": {**solo_parts, "what": "detect = the detection pass (k_wave: producers, consumers, run-again), dir = package directory, "
                                                                             "count = the slicers' sizing pass (k_slice into staging slots, the pre-filter's verdicts applied), scan = offsets, "
