@@ -54,6 +54,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# Eight hardware queues instead of the runtime's four (read once, at the process's first HIP call -- before torch is imported):
+# three engines have six streams of their own, and streams that share a hardware queue run in submission order -- the sizing pass of
+# one engine sat for 17 ms behind the 1 GiB input copy of another (rtl_433_amd/csrc/host_api.cpp, profiles/r06_hw_queues.txt)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 def _newest(name):  # the committed counter passes of the latest round that has them
@@ -560,13 +564,22 @@ class Pipeline:
         self.hooks = hooks      # r433_dispatch_hooks of the ordered replay (the plugins' output_render: JSON lines made on the replay threads)
         self.stagger = 0.0
         self.replay_s = []  # the library's replay call alone, per host leg
+        self.leg_tm = {}
+        self.h2d_trace = [] if os.environ.get("R433_BENCH_H2D_TRACE") else None  # development: when every step's input copy ran (h2d_timeline)
 
     def gpu_leg(self, k, src, lens=None, h2d_from=None, d_buf=None):
         BK.set_device(self.local_rank)
         e, st = self.engines[k % self.n_eng], self.streams[k % self.n_eng]
         if h2d_from is not None:  # host -> HBM over PCIe on the engine's own stream, overlapping the other engines' kernels
             with BK.on(st):
-                d_buf.copy_(h2d_from, non_blocking=True)
+                if self.h2d_trace is not None and st is not None:
+                    ev0, ev1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+                    ev0.record(st)
+                    d_buf.copy_(h2d_from, non_blocking=True)
+                    ev1.record(st)
+                    self.h2d_trace.append((k, time.perf_counter(), ev0, ev1))
+                else:
+                    d_buf.copy_(h2d_from, non_blocking=True)
                 if H2D_NAP and st is not None:
                     # The copy takes 18.7 ms and the library's first wait of the pass would SPIN through all of it
                     # (hipEventSynchronize spins on this stack, tools/spin_probe.py): two legs in flight = two of the 16 CPUs
@@ -604,6 +617,8 @@ class Pipeline:
             nxt += 1
         for k in range(n):
             n_pkgs, tm = futs.popleft().result()
+            if self.h2d_trace is not None:
+                self.leg_tm[k] = (time.perf_counter(), dict(tm))
             if nxt < n:
                 futs.append(self.pool.submit(self.gpu_leg, nxt, **leg_args(nxt)))
                 nxt += 1
@@ -613,6 +628,21 @@ class Pipeline:
             det.append(tm["detect_ms"])
             tot.append(tm["total_ms"])
         return det, tot, host, n_pkgs
+
+    def h2d_timeline(self, last=16):
+        """development (R433_BENCH_H2D_TRACE=1): start / end of the last input copies on the device's clock, and the link's idle time between them"""
+        tr = self.h2d_trace[-last:]
+        if len(tr) < 2:
+            return
+        self.torch.cuda.synchronize()
+        base = tr[0][2]
+        rows = [(k, t_host - tr[0][1], base.elapsed_time(e0), base.elapsed_time(e1)) for k, t_host, e0, e1 in tr]
+        busy_to = rows[0][3]
+        for k, th, a, b in rows:
+            got = self.leg_tm.get(k)
+            parts = "" if got is None else f" | leg taken at {(got[0] - tr[0][1]) * 1e3:8.2f} ms: " + " ".join(f"{n[:-3]} {v:.2f}" for n, v in got[1].items())
+            sys.stderr.write(f"h2d step {k:3d}: issued at {th * 1e3:8.2f} ms (host clock), on the device {a:8.2f} .. {b:8.2f} ms ({b - a:6.2f}), link idle before it {max(0.0, a - busy_to):6.2f} ms{parts}\n")
+            busy_to = max(busy_to, b)
 
     def close(self):
         for e in self.engines:
@@ -835,6 +865,8 @@ def run_batched(args, ctxd):
     cpu0, cg0 = os.times(), cgroup_cpu_stat()
     elapsed, (det_ms, tot_ms, disp_s, n_pkgs) = timed(dist, torch, timed_region)
     cpu1, cg1 = os.times(), cgroup_cpu_stat()
+    if pipe.h2d_trace:
+        pipe.h2d_timeline()
     replay_ms = float(np.mean(pipe.replay_s)) * 1e3 if pipe.replay_s else 0.0
 
     result = None
@@ -878,6 +910,7 @@ def run_batched(args, ctxd):
                                            "whole-job IQ samples / wall time of the timed region over the one list, inputs resident in HBM, records gathered on rank 0",
                        "streams_per_launch": n_streams, "samples_per_stream": n_samples,
                        "sample_rate": 250000, "decoders": len(devs), "host_dispatch_threads": threads, "host_cpus": {"logical": os.cpu_count(), "cfs_quota": cpu_quota()},
+                       "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "launches_per_step_per_gpu": per_step if strong else args.batches,
                        **({} if strong else {"captures_per_batch": n_batch, "batches_per_step_per_gpu": args.batches,
                                               "note": f"the {args.batches} launches of {n_batch} captures of a step are issued as ONE grid of {n_streams} workgroups"}),

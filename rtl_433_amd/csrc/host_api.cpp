@@ -147,6 +147,18 @@ float r433_level_db(uint32_t sum, uint32_t n, int is_magnitude)
 
 r433_batch *r433_batch_create_on(int device, r433_flow_cfg const *cfg, r433_dev_timing const *devs, uint32_t n_devs);
 
+// Streams and hardware queues.  The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by
+// default), and two streams that share one run in submission order: a pipeline of three engines has six streams of its own (a main
+// and a fork stream each, slicer_kernels.hip) beside the host's, and the sizing pass of one engine sat for 17 ms behind the
+// 1 GiB input copy of another (every third step of bench.py's host-fed pipeline: 22.3 -> 20.4 ms per step with eight queues,
+// profiles/r06_hw_queues.txt).  The runtime reads the variable when it initialises, i.e. at the process's first HIP call: a
+// library that is loaded before that asks for eight, unless the user has said otherwise.  (A host that has already made HIP
+// calls -- a Python process that imported torch and touched the device -- sets the variable itself: bench.py does.)
+__attribute__((constructor)) static void ask_for_hardware_queues()
+{
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
+
 namespace {
 __global__ void k_warm(int *p)
 {
