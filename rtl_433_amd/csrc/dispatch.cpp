@@ -557,6 +557,8 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
     // bytes) of its non-empty slices, made on the device) nothing is searched here: dev_count counts slices and an item walks
     // the records of its slices.  Without it (runs that made none) the host indexes every record itself.
     bool const by_slice = b->slices_valid && n_devices == b->timing.size();
+    static uint32_t const pf_dist = [] { char const *e = getenv("R433_REPLAY_PF_DIST"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 24u; }(); // (development: A/B -- 6 / 12 / 24 / 40 slices ahead: 75 / 78 / 80.4 / 70 GS/s, profiles/r06_replay_prefetch.txt)
+    static bool const pf_lines_all = [] { char const *e = getenv("R433_REPLAY_PREFETCH"); return !e || atoi(e) != 1; }(); // (development: 1 = the first line only, A/B)
     uint2 const *const slices = b->h_slices.p;
     std::vector<uint32_t> dev_count(n_devices + 1, 0);
     std::vector<uint32_t> ev_off;
@@ -672,8 +674,18 @@ int r433_batch_dispatch_ordered(r433_batch *b, r433_r_device *const *devices, ui
                 uint32_t walked_here = 0;
                 for (uint32_t e = items[k].first; e < items[k].last && go_on; ++e) {
                     // a decoder's records lie a package's worth of other decoders' apart: every slice a cache miss
-                    if (e + 12 < items[k].last)
-                        __builtin_prefetch(ev + (by_slice ? slices[e + 12].x : ev_off[e + 12]));
+                    // (... and a slice is 4-5 records, half a kilobyte: every line of it, not the first alone)
+                    if (e + pf_dist < items[k].last) {
+                        if (by_slice) {
+                            uint2 const nx = slices[e + pf_dist];
+                            uint8_t const *const q = ev + nx.x;
+                            uint32_t const nb = pf_lines_all ? std::min<uint32_t>(nx.y, 768u) : 1u;
+                            for (uint32_t o = 0; o < nb; o += 64)
+                                __builtin_prefetch(q + o);
+                        }
+                        else
+                            __builtin_prefetch(ev + ev_off[e + pf_dist]);
+                    }
                     if (!by_slice) {
                         uint8_t const *rec = ev + ev_off[e];
                         r433_evt_rec eh;
