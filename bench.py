@@ -631,6 +631,9 @@ class Pipeline:
 
     def h2d_timeline(self, last=16):
         """development (R433_BENCH_H2D_TRACE=1): start / end of the last input copies on the device's clock, and the link's idle time between them"""
+        if self.leg_tm:  # the parts of a GPU leg as they were beside the other engines' legs (mean over the legs of the region)
+            parts = list(self.leg_tm.values())[-last:]
+            sys.stderr.write("legs overlapped, mean parts: " + " ".join(f"{n[:-3]} {float(np.mean([p[1][n] for p in parts])):.2f}" for n in parts[0][1]) + "\n")
         tr = self.h2d_trace[-last:]
         if len(tr) < 2:
             return
@@ -865,7 +868,7 @@ def run_batched(args, ctxd):
     cpu0, cg0 = os.times(), cgroup_cpu_stat()
     elapsed, (det_ms, tot_ms, disp_s, n_pkgs) = timed(dist, torch, timed_region)
     cpu1, cg1 = os.times(), cgroup_cpu_stat()
-    if pipe.h2d_trace:
+    if pipe.h2d_trace is not None:
         pipe.h2d_timeline()
     replay_ms = float(np.mean(pipe.replay_s)) * 1e3 if pipe.replay_s else 0.0
 
