@@ -1,7 +1,7 @@
 """Development aid (GPU box): the slicers' passes over one bench step (8192 captures, the 335 real decoders' timing rows) WITH
 the pre-filter tables of the real decoders -- what the pipeline runs -- for one build of the library.
     python tools/slice_pf_bench.py [lib.so] [reps] [debug flags]"""
-import ctypes, os, sys
+import ctypes, hashlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
@@ -28,4 +28,5 @@ for rep in range(reps):
     n = eng.run(d)
     ts.append(eng.timing())
 best = {k: min(t[k] for t in ts[2:] or ts) for k in ts[0]}
-print(f"lib={os.path.basename(so) if so else 'default'} debug={debug} grid={os.environ.get('R433_SLICE_GRID', '-')} pkgs={n} records={eng.events()[1]} " + " ".join(f"{k}={v:.3f}" for k, v in best.items()))
+print(f"lib={os.path.basename(so) if so else 'default'} debug={debug} grid={os.environ.get('R433_SLICE_GRID', '-')} pkgs={n} records={eng.events()[1]} " + " ".join(f"{k}={v:.3f}" for k, v in best.items())
+      + f" evt_digest={hashlib.sha1(bytes(eng.events()[0])).hexdigest()[:12]} multi={'off' if os.environ.get('R433_SLICE_NO_MULTI') else 'on'}")
