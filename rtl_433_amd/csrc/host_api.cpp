@@ -258,21 +258,76 @@ r433_batch *r433_batch_create_on(int device, r433_flow_cfg const *cfg, r433_dev_
             return x.is_fsk < y.is_fsk;
         return x.modulation < y.modulation;
     });
-    { // pad every (fsk, modulation) group to a multiple of 64 rows: one slicer per wavefront
-        std::vector<DevRow> padded;
+    { // Chunks of 64 rows, a wavefront's devices.  A line code with 64 decoders and more fills chunks of its own.  The rest --
+      // most line codes have a handful of decoders -- share chunks with other line codes of their kind (OOK or FSK: a chunk draws
+      // the packages of one kind, k_pkg_order): a wavefront then walks the package once per line code it holds, one after the
+      // other, but an item's fixed cost (the draw, four dependent loads, staging the pulses, two barriers: 38 us of a wavefront's
+      // life against 20-130 us for a walk, profiles/r04_slice_shares.txt) is paid once for all of them.  First fit, heaviest
+      // first, by the walk's measured weight per line code; a chunk takes no more than 1.2 times the heaviest walk, so that the
+      // longest item of the launch stays what it was.  (R433_SLICE_NO_PACK: a chunk per line code, development / A/B timing.)
+        auto const weight = [](DevRow const &r) -> double {
+            switch (r.modulation) { // mean wavefront microseconds of a walk over a bench package
+            case 4: case 16: return 135; // PCM
+            case 6: case 17: return 73;  // PWM
+            case 3: case 18: return 72;  // Manchester
+            case 11: return 46;          // PIWM DC
+            case 5: return 44;           // PPM
+            case 8: case 12: return 40;  // PIWM raw, NRZS (not in the default set: a guess)
+            case 9: return 23;           // DMC
+            case 13: return 18;
+            case 10: return 1;           // Oregon v1
+            default: return 40;
+            }
+        };
+        struct Piece { size_t begin, n; double w; };
+        struct Bin { std::vector<Piece> pieces; size_t rows = 0; double w = 0; int fsk = 0; };
         DevRow pad;
         memset(&pad, 0, sizeof(pad));
         pad.orig = -1;
         pad.pf = -1;
-        for (size_t i = 0; i < b->rows.size(); ++i) {
-            if (i > 0 && (b->rows[i].is_fsk != b->rows[i - 1].is_fsk || b->rows[i].modulation != b->rows[i - 1].modulation))
-                while (padded.size() % 64)
-                    padded.push_back(pad);
-            padded.push_back(b->rows[i]);
+        std::vector<DevRow> packed;
+        std::vector<Piece> rest[2];
+        double heaviest = 0;
+        for (size_t i = 0; i < b->rows.size();) {
+            size_t j = i;
+            while (j < b->rows.size() && b->rows[j].is_fsk == b->rows[i].is_fsk && b->rows[j].modulation == b->rows[i].modulation)
+                ++j;
+            for (; j - i >= 64; i += 64)
+                packed.insert(packed.end(), b->rows.begin() + (long)i, b->rows.begin() + (long)i + 64);
+            if (j > i) {
+                rest[b->rows[i].is_fsk != 0].push_back({i, j - i, weight(b->rows[i])});
+                heaviest = std::max(heaviest, weight(b->rows[i]));
+            }
+            i = j;
         }
-        while (padded.size() % 64)
-            padded.push_back(pad);
-        b->rows.swap(padded);
+        bool const no_pack = getenv("R433_SLICE_NO_PACK") != nullptr;
+        for (int kind = 0; kind < 2; ++kind) {
+            std::stable_sort(rest[kind].begin(), rest[kind].end(), [](Piece const &x, Piece const &y) { return x.w > y.w; });
+            std::vector<Bin> bins;
+            for (Piece const &pc : rest[kind]) {
+                Bin *into = nullptr;
+                if (!no_pack)
+                    for (Bin &bin : bins)
+                        if (bin.rows + pc.n <= 64 && bin.w + pc.w <= 1.2 * heaviest) {
+                            into = &bin;
+                            break;
+                        }
+                if (!into) {
+                    bins.emplace_back();
+                    into = &bins.back();
+                }
+                into->pieces.push_back(pc);
+                into->rows += pc.n;
+                into->w += pc.w;
+            }
+            for (Bin const &bin : bins) {
+                for (Piece const &pc : bin.pieces)
+                    packed.insert(packed.end(), b->rows.begin() + (long)pc.begin, b->rows.begin() + (long)(pc.begin + pc.n));
+                while (packed.size() % 64)
+                    packed.push_back(pad);
+            }
+        }
+        b->rows.swap(packed);
     }
     for (uint32_t i = 0; i < n_devs; ++i)
         b->prio_levels.push_back(devs[i].priority);

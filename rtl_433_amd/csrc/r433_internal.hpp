@@ -190,7 +190,7 @@ struct SliceParams {
     uint32_t const *dir_stream; // per package: capture index
     uint32_t const *dir_off;    // per package: byte offset of its record in that capture's arena
     uint32_t const *n_pkgs;     // device scalar: total packages
-    DevRow const *devs;         // n_rows slicer rows: grouped by modulation, every group padded to whole wavefronts
+    DevRow const *devs;         // n_rows slicer rows in chunks of 64, padded: a chunk holds one kind (OOK / FSK) and one or a few line codes (host_api.cpp)
     uint32_t n_rows;
     uint32_t n_devs;            // registered devices (width of `sizes`)
     uint32_t *sizes;            // [pkg][orig dev] bytes of event records

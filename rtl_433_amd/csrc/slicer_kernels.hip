@@ -2,9 +2,10 @@
 //
 // Work item = (package, chunk of 64 devices); one wavefront per item.  The package's (pulse, gap)
 // pairs are staged once in LDS (<= 9.6 KB, coalesced 8-byte loads) and every lane runs the slicer
-// of its own device over them (LDS broadcast reads).  Devices are grouped by modulation and every
-// group is padded to whole wavefronts, so a wavefront executes exactly one slicer: the slowest lane
-// of a mixed wavefront used to pay for every slicer present in it.  Records are built once into a
+// of its own device over them (LDS broadcast reads).  Devices are grouped by modulation: a line code
+// with 64 decoders and more has wavefronts of its own (the slowest lane of a mixed wavefront pays for
+// every slicer present in it), the line codes with a handful of decoders share chunks up to a bound
+// on the sum of their walks (host_api.cpp: an item's fixed cost is paid once).  Records are built once into a
 // fixed-size staging slot per (package, device); an exclusive scan of their sizes and a compaction
 // pass give a dense event stream in canonical (package, device, event) order without atomics on the
 // payload.  (A record that outgrows its slot is sliced a second time straight into the stream; if the

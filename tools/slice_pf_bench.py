@@ -29,4 +29,4 @@ for rep in range(reps):
     ts.append(eng.timing())
 best = {k: min(t[k] for t in ts[2:] or ts) for k in ts[0]}
 print(f"lib={os.path.basename(so) if so else 'default'} debug={debug} grid={os.environ.get('R433_SLICE_GRID', '-')} pkgs={n} records={eng.events()[1]} " + " ".join(f"{k}={v:.3f}" for k, v in best.items())
-      + f" evt_digest={hashlib.sha1(bytes(eng.events()[0])).hexdigest()[:12]} multi={'off' if os.environ.get('R433_SLICE_NO_MULTI') else 'on'}")
+      + f" evt_digest={hashlib.sha1(bytes(eng.events()[0])).hexdigest()[:12]} packed={'off' if os.environ.get('R433_SLICE_NO_PACK') else 'on'}")
