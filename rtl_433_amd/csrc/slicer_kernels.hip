@@ -52,12 +52,16 @@ enum { M_COUNT = 0, M_WRITE = 1, M_STAGE = 2, M_COMPACT = 3 };
 constexpr uint32_t kSmallW = 52;                 // weight (pulses / 5) from which a package is large
 constexpr uint32_t kSmallPulses = kSmallW * 5;   // a small package has fewer pulses than this
 
-// (the small-package form lives on six wavefronts to a SIMD -- 2 KB of LDS each --: held to the 80 registers that takes; the
-// sink's fields grew with the pre-filter's rules and one register over is a wavefront less)
+// (the small-package form lives on eight wavefronts to a SIMD -- 2 KB of LDS each --, held to the 64 registers that takes with 68
+// bytes of scratch a lane: a serial walk waits for every pulse it reads, and more walks in flight beat registers -- six / seven /
+// eight wavefronts: 1.62 / 1.52 / 1.50 ms for the sizing pass of a bench step, records identical, profiles/r06_n_slice_waves.txt)
+#ifndef R433_SLICE_MIN_WAVES
+#define R433_SLICE_MIN_WAVES 8
+#endif
 #ifdef R433_EMU
 #define R433_SLICE_WAVES(cap)
 #else
-#define R433_SLICE_WAVES(cap) __attribute__((amdgpu_waves_per_eu((cap) < R433_PD_MAX_PULSES ? 6 : 1, 8)))
+#define R433_SLICE_WAVES(cap) __attribute__((amdgpu_waves_per_eu((cap) < R433_PD_MAX_PULSES ? R433_SLICE_MIN_WAVES : 1, 8)))
 #endif
 template <int MODE, int CAP = R433_PD_MAX_PULSES> __global__ __launch_bounds__(64) R433_SLICE_WAVES(CAP) void k_slice(SliceParams p)
 {
@@ -508,7 +512,7 @@ uint32_t sizing_grid_cap()
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
                 cus = 256;
 #endif
-            cap = (uint32_t)std::min(16384, cus * 24);
+            cap = (uint32_t)std::min(16384, cus * 4 * R433_SLICE_MIN_WAVES);
         }
     }
     return cap;
