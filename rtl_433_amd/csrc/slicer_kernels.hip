@@ -278,7 +278,8 @@ template <int MODE, int CAP = R433_PD_MAX_PULSES> __global__ __launch_bounds__(6
 }
 
 // The packages [pkg_begin, n) by kind and pulse count: the OOK packages first, then the FSK ones, each kind heaviest first -- a
-// counting sort in one workgroup (a launch has a few thousand packages; pulse counts go up to 1200, five to a bucket).  A chunk
+// counting sort in one workgroup of 1024 threads (a launch has a few thousand packages, every key three dependent loads away;
+// pulse counts go up to 1200, five to a bucket).  A chunk
 // of devices only ever draws the packages of its own kind (a line code is an OOK or an FSK one, src/r_api.c:438-550): an OOK
 // package under an FSK slicer is no work, but as an item it still cost a draw, four dependent loads and two barriers -- 38 us of
 // a wavefront's life, 8948 times per chunk (five of the thirteen chunks of the default decoders never had anything else to do:
@@ -286,7 +287,7 @@ template <int MODE, int CAP = R433_PD_MAX_PULSES> __global__ __launch_bounds__(6
 //   cursor[chunk]            the chunk's next entry of its kind's list (one launch), or of its large part (two launches)
 //   cursor[chunks + chunk]   ... of its small part
 //   cursor[2 * chunks + k]   k = 0..3: the ends of OOK large / OOK / FSK large / FSK (= everything) in `order`
-__global__ __launch_bounds__(256) void k_pkg_order(uint8_t const *arena, uint32_t arena_stride, uint32_t const *dir_stream,
+__global__ __launch_bounds__(1024) void k_pkg_order(uint8_t const *arena, uint32_t arena_stride, uint32_t const *dir_stream,
         uint32_t const *dir_off, uint32_t const *n_pkgs_ptr, uint32_t max_pkgs, uint32_t pkg_begin, uint32_t pkg_end,
         uint32_t *order, uint32_t *cursor, uint32_t chunks, DevRow const *devs, uint32_t by_kind, unsigned long long *work_start)
 {
@@ -297,9 +298,10 @@ __global__ __launch_bounds__(256) void k_pkg_order(uint8_t const *arena, uint32_
         uint32_t const *rec = (uint32_t const *)(arena + (uint64_t)dir_stream[pkg] * arena_stride + dir_off[pkg]);
         return (by_kind && rec[2] == R433_PKG_FSK ? 256u : 0u) + min(rec[3] / 5u, 255u);
     };
-    count[threadIdx.x] = count[256 + threadIdx.x] = 0;
+    for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x)
+        count[i] = 0;
     __syncthreads();
-    for (uint32_t pkg = pkg_begin + threadIdx.x; pkg < n_pkgs; pkg += 256)
+    for (uint32_t pkg = pkg_begin + threadIdx.x; pkg < n_pkgs; pkg += blockDim.x)
         atomicAdd(&count[key(pkg)], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(256) void k_pkg_order(uint8_t const *arena, uint32_
         }
         __syncthreads();
     }
-    for (uint32_t c = threadIdx.x; c < chunks; c += 256) {
+    for (uint32_t c = threadIdx.x; c < chunks; c += blockDim.x) {
         bool const fsk = by_kind && devs[c * 64].is_fsk != 0; // (a chunk is one line code; padding rows follow the real ones)
         cursor[c] = fsk ? bound[1] : 0u;
         cursor[chunks + c] = fsk ? bound[2] : bound[0];
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(256) void k_pkg_order(uint8_t const *arena, uint32_
     if (threadIdx.x == 0 && work_start)
         *work_start = (unsigned long long)wall_clock64(); // (the sizing launches begin when this kernel ends)
 #endif
-    for (uint32_t pkg = pkg_begin + threadIdx.x; pkg < n_pkgs; pkg += 256)
+    for (uint32_t pkg = pkg_begin + threadIdx.x; pkg < n_pkgs; pkg += blockDim.x)
         order[atomicAdd(&first[key(pkg)], 1u)] = pkg;
 }
 
@@ -414,9 +416,17 @@ __global__ __launch_bounds__(64) void k_index_count(uint32_t const *sizes, uint3
     uint32_t const p0 = blk * kIdxBlock, p1 = min(n_pkgs, p0 + kIdxBlock);
     if (d >= n_devs)
         return;
+    // (210 wavefronts for the bench's step: the walk is memory latency, so eight loads in flight)
     uint32_t c = 0;
-    for (uint32_t p = p0; p < p1; ++p)
-        c += sizes[(uint64_t)p * n_devs + d] != 0u;
+    for (uint32_t p = p0; p < p1; p += 8) {
+        uint32_t sz[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u)
+            sz[u] = p + u < p1 ? sizes[(uint64_t)(p + u) * n_devs + d] : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u)
+            c += sz[u] != 0u;
+    }
     cnt[(uint64_t)blk * n_devs + d] = c;
 }
 
@@ -473,13 +483,21 @@ __global__ __launch_bounds__(64) void k_index_fill(uint32_t const *sizes, uint32
     if (d >= n_devs)
         return;
     uint32_t at = base[(uint64_t)blk * n_devs + d];
-    for (uint32_t p = p0; p < p1; ++p) {
-        uint32_t const sz = sizes[(uint64_t)p * n_devs + d];
-        if (sz) {
-            if (at < cap)
-                slices[at] = make_uint2(pkg_off[p] + dev_off[(uint64_t)p * n_devs + d], sz);
-            at += 1;
+    for (uint32_t p = p0; p < p1; p += 8) { // eight packages' sizes and offsets in flight (an offset is read whether its size is zero or not)
+        uint32_t sz[8], off[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            bool const in = p + u < p1;
+            sz[u] = in ? sizes[(uint64_t)(p + u) * n_devs + d] : 0u;
+            off[u] = in ? pkg_off[p + u] + dev_off[(uint64_t)(p + u) * n_devs + d] : 0u;
         }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u)
+            if (sz[u]) {
+                if (at < cap)
+                    slices[at] = make_uint2(off[u], sz[u]);
+                at += 1;
+            }
     }
 }
 
@@ -594,7 +612,7 @@ void launch_slice_count(SliceParams const &p_in, uint32_t grid_pkgs, hipStream_t
     }
     uint32_t const chunks = p.n_rows / 64 ? p.n_rows / 64 : 1u;
     if (p.draw)
-        hipLaunchKernelGGL(k_pkg_order, dim3(1), dim3(256), 0, st, p.arena, p.arena_stride, p.dir_stream, p.dir_off, p.n_pkgs, p.max_pkgs,
+        hipLaunchKernelGGL(k_pkg_order, dim3(1), dim3(1024), 0, st, p.arena, p.arena_stride, p.dir_stream, p.dir_off, p.n_pkgs, p.max_pkgs,
                 p.pkg_begin, p.pkg_end, p.pkg_order, p.cursor, chunks, p.devs, big ? 1u : 0u, p.chunk_work ? p.chunk_work + 64 : nullptr);
     dim3 const grid(slice_grid(grid_pkgs, p.n_rows, p.draw && grid_pkgs >= 4096 ? sizing_grid_cap() : 16384u));
     if (p.draw == 2) {
